@@ -1,0 +1,173 @@
+/* mm355.h -- C-ABI of the MI355X-native mapping path (libmm355.so).
+ *
+ * Drop-in boundary for the ONE hot path of Adoni5/mappy-rs: the per-read minimap2
+ * mapping call.  In the reference that call is `minimap2::Aligner::map` ->
+ * `mm_map` of minimap2-sys (reference call sites /root/reference/src/lib.rs:482-488
+ * for Aligner.map and :587-593 for the map_batch worker), surrounded by the
+ * index/option FFI at lib.rs:333-416 and the sequence accessors at :716/:747.
+ * Each entry point below names the reference FFI symbol it replaces.
+ *
+ * Plain pointers and sizes only; no torch / HIP types cross this boundary.
+ * All functions return 0 on success or a negative MM355_E* code; mm355_strerror
+ * gives the message.  The library refuses to run (MM355_ENODEV) when no gfx950
+ * device is visible: there is no CPU fallback.
+ */
+#ifndef MM355_H
+#define MM355_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM355_OK        0
+#define MM355_ENODEV   (-1)   /* no HIP device / kernel image not loadable */
+#define MM355_EINVAL   (-2)
+#define MM355_ENOMEM   (-3)
+#define MM355_EIO      (-4)   /* cannot open / parse index or FASTA */
+#define MM355_ENOIDX   (-5)   /* "No index" (L2 crate error string) */
+#define MM355_EEMPTY   (-6)   /* "Sequence is empty" (L2 crate error string) */
+#define MM355_EUNSUP   (-7)   /* option outside the long-read hot path (HPC index, sr/splice presets) */
+#define MM355_EHIP     (-8)   /* a HIP runtime call failed */
+
+typedef struct mm355_index mm355_index_t;     /* replaces mm_idx_t* (lib.rs:400-410) */
+typedef struct mm355_ctx   mm355_ctx_t;       /* replaces mm_tbuf_t: one per host thread / GPU */
+
+/* replaces mm_idxopt_t (lib.rs:332) */
+typedef struct {
+	int16_t k, w, flag, bucket_bits;
+	int64_t mini_batch_size;
+	uint64_t batch_size;
+} mm355_idxopt_t;
+
+/* replaces mm_mapopt_t (lib.rs:331); same field meaning as minimap2 2.26 */
+typedef struct {
+	int64_t flag;
+	int32_t seed, sdust_thres, max_qlen;
+	int32_t bw, bw_long, max_gap, max_gap_ref, max_frag_len;
+	int32_t max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
+	float chain_gap_scale, chain_skip_scale;
+	int32_t rmq_size_cap, rmq_inner_dist, rmq_rescue_size;
+	float rmq_rescue_ratio, mask_level;
+	int32_t mask_len;
+	float pri_ratio;
+	int32_t best_n;
+	float alt_drop;
+	int32_t a, b, q, e, q2, e2, sc_ambi;
+	int32_t zdrop, zdrop_inv, end_bonus, min_dp_max, min_ksw_len;
+	float max_clip_ratio;
+	float mid_occ_frac, q_occ_frac;
+	int32_t min_mid_occ, max_mid_occ, mid_occ, max_occ, max_max_occ, occ_dist;
+	int64_t max_sw_mat;
+} mm355_mapopt_t;
+
+/* one alignment; mirrors mappy_rs::Mapping (lib.rs:109-154) filled from mm_reg1_t */
+typedef struct {
+	int32_t query_start, query_end;
+	int32_t strand;                 /* +1 forward, -1 reverse */
+	int32_t rid;                    /* index into mm355_index_info names */
+	int32_t target_len, target_start, target_end;
+	int32_t match_len, block_len;
+	uint32_t mapq;
+	int32_t is_primary;
+	int32_t NM;
+	int32_t n_cigar;
+	int64_t cigar_off;              /* into mm355_hits_t::cigar, u32 = len<<4|op */
+	int64_t cs_off, cs_len;         /* into mm355_hits_t::str; cs_len < 0 => None */
+	int64_t md_off, md_len;
+	int32_t score0, dp_max, dp_max2, dp_score, cnt, n_sub, subsc, reserved;
+} mm355_hit_t;
+
+/* result of one batch; owned by the library until mm355_free_hits */
+typedef struct {
+	int64_t n_reads;
+	int64_t *hit_off;               /* n_reads+1 offsets into hits[] */
+	int32_t *status;                /* per read: 0 ok, MM355_EEMPTY for an empty sequence */
+	mm355_hit_t *hits;
+	uint32_t *cigar;
+	char *str;
+	int64_t n_hits, n_cigar, n_str;
+} mm355_hits_t;
+
+/* --- options: replaces mm_set_opt (lib.rs:333,336) and mm_mapopt_update (lib.rs:414) --- */
+int mm355_set_opt(const char *preset, mm355_idxopt_t *io, mm355_mapopt_t *mo);
+int mm355_mapopt_update(mm355_mapopt_t *mo, const mm355_index_t *idx);
+
+/* --- index: replaces mm_idx_reader_open/read/close + mm_idx_index_name (lib.rs:397-416) --- */
+int mm355_index_load(const char *path, const mm355_idxopt_t *io, int n_threads, mm355_index_t **out);
+int mm355_index_build(const mm355_idxopt_t *io, int n_seq, const char *const *seqs, const int64_t *lens,
+                      const char *const *names, int n_threads, mm355_index_t **out);
+void mm355_index_free(mm355_index_t *idx);
+/* header fields read at lib.rs:655-670 (k, w, n_seq) */
+int mm355_index_info(const mm355_index_t *idx, int32_t *k, int32_t *w, int32_t *b, int32_t *flag, uint32_t *n_seq);
+const char *mm355_index_seq_name(const mm355_index_t *idx, uint32_t rid);   /* lib.rs:447-455 */
+int64_t mm355_index_seq_len(const mm355_index_t *idx, uint32_t rid);
+int mm355_index_name2id(const mm355_index_t *idx, const char *name);        /* mm_idx_name2id, lib.rs:716 */
+int mm355_index_getseq(const mm355_index_t *idx, uint32_t rid, uint32_t st, uint32_t en, uint8_t *seq); /* mm_idx_getseq, lib.rs:747 */
+/* host-side diagnostic equivalent of mm_idx_get(): occurrences of one minimizer (returns the count) */
+int mm355_index_get(const mm355_index_t *idx, uint64_t minier, uint64_t *vals, int cap);
+int mm355_index_stat(const mm355_index_t *idx, int64_t *n_minimizers, int64_t *n_distinct, int64_t *table_bytes, int64_t *pos_bytes);
+
+/* --- device context (one per host thread / GPU): replaces mm_tbuf_init/destroy --- */
+int mm355_ctx_create(const mm355_index_t *idx, int device_id, mm355_ctx_t **out);   /* uploads the index to HBM once */
+void mm355_ctx_destroy(mm355_ctx_t *ctx);
+
+/* --- the hot path: replaces mm_map (+ mm_gen_cs / mm_gen_MD) for a whole batch of reads.
+ * seqs[i] need not be NUL-terminated.  flags: bit0 = cs (short form), bit1 = MD. --- */
+#define MM355_OUT_CS 1
+#define MM355_OUT_MD 2
+int mm355_map_batch(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
+                    const int32_t *lens, int flags, mm355_hits_t **out);
+void mm355_free_hits(mm355_hits_t *hits);
+
+/* --- per-stage entry points (same kernels as mm355_map_batch; used by the parity tests and
+ * by bench.py to time one kernel with HIP events).  Outputs are caller-allocated host buffers. --- */
+typedef struct {
+	int64_t n_reads, n_bases;
+	int64_t n_mz, n_hit, n_a, n_a_multi;       /* SURVEY 8(d) counters of the seed stage */
+	int64_t chain_pairs, dp_cells, n_dp_jobs;
+	double ms_sketch, ms_seed, ms_sort, ms_chain, ms_backtrack, ms_dp, ms_host, ms_total;
+	double ms_seed_lookup, ms_seed_expand;
+	int64_t n_launch_seed;
+} mm355_stats_t;
+
+/* sketch: minimizers of each read (mm_sketch). mz_off[n_reads+1] host array is filled; mz = (x,y) pairs */
+int mm355_stage_sketch(mm355_ctx_t *ctx, int64_t n_reads, const char *const *seqs, const int32_t *lens,
+                       int64_t *mz_off, uint64_t *mz, int64_t mz_cap);
+/* seeds: sketch + mm_seed_mz_flt + mm_collect_matches + collect_seed_hits; anchors in generation order
+ * (sorted = 0) or after the radix_sort_128x emulation (sorted = 1). */
+int mm355_stage_anchors(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
+                        const int32_t *lens, int sorted, int64_t *a_off, uint64_t *a, int64_t a_cap,
+                        int32_t *rep_len, int32_t *n_mini_pos);
+/* chaining DP fill (mg_lchain_dp) on the sorted anchors: f, p, v per anchor (p as int32, -1 = none) */
+int mm355_stage_chain(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
+                      const int32_t *lens, int64_t *a_off, uint64_t *a, int32_t *f, int32_t *p, int32_t *v, int64_t a_cap);
+/* chains after backtrack + compact_a: u (score<<32|cnt) and the compacted anchors */
+int mm355_stage_chains(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
+                       const int32_t *lens, int64_t *u_off, uint64_t *u, int64_t u_cap,
+                       int64_t *a_off, uint64_t *a, int64_t a_cap);
+/* one batch of banded extension problems (ksw_extd2_sse semantics); see mm355_dpjob_t */
+typedef struct {
+	int32_t qlen, tlen;
+	int64_t qoff, toff;     /* offsets into the code arrays (0..4 per byte) */
+	int32_t w, zdrop, end_bonus, flag;
+} mm355_dpjob_t;
+typedef struct {
+	int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar;
+	int64_t cigar_off;
+} mm355_dpres_t;
+int mm355_stage_dp(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_jobs, const mm355_dpjob_t *jobs,
+                   const uint8_t *qcodes, int64_t n_q, const uint8_t *tcodes, int64_t n_t,
+                   mm355_dpres_t *res, uint32_t *cigar, int64_t cigar_cap);
+
+int mm355_get_stats(mm355_ctx_t *ctx, mm355_stats_t *st);   /* counters/timers of the last call on ctx */
+int mm355_device_count(void);
+const char *mm355_strerror(int code);
+const char *mm355_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

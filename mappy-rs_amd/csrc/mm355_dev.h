@@ -1,0 +1,72 @@
+// mm355_dev.h -- device-side structs and kernel launch prototypes (host <-> .hip boundary inside the library)
+#pragma once
+#include "mm355_core.h"
+
+struct DevIndex {
+	const mm355_slot *slots;   // n_lines * 8 slots, 128-B lines
+	uint64_t line_mask;        // n_lines - 1
+	const uint64_t *pos;       // y words of multi-occurrence minimizers, ascending inside a run
+	const uint32_t *S;         // 4-bit packed reference (code 0..4), 8 bases per u32
+	const uint64_t *seq_off;   // per contig offset into S (bases)
+	const uint32_t *seq_len;
+	int32_t k, w, b, flag;
+	uint32_t n_seq;
+};
+
+struct DevParams {           // subset of mm_mapopt_t the kernels read
+	int64_t flag;
+	int32_t mid_occ, max_max_occ, occ_dist;
+	float q_occ_frac;
+	int32_t max_gap, max_gap_ref, max_frag_len;
+	int32_t bw, max_chain_skip, max_chain_iter, min_cnt, min_chain_score;
+	float pen_gap, pen_skip;
+};
+
+struct DevBatch {            // one batch of reads resident in HBM
+	int32_t n_reads;
+	const uint8_t *seq;        // ASCII (or raw codes), each read starts 16-B aligned
+	const int64_t *roff;       // byte offset of read r in seq; also its slot offset in mz/seed arrays
+	const int32_t *rlen;
+	const int32_t *order;      // reads sorted by length (desc) for the lane-per-read kernels
+};
+
+struct DevSeeds {
+	mm128 *mz;                 // [total padded bases] minimizers, read r at roff[r]
+	mm128 *mz_tmp;             // scratch of the same size (mz_flt sort)
+	int32_t *n_mz;             // [n_reads]
+	uint32_t *sn;              // per minimizer: #occurrences in the index (0 = absent)
+	uint64_t *sv;              // per minimizer: y word (n==1) or offset into pos[]
+	uint8_t *sflt;             // per minimizer: 1 = filtered by mm_seed_select
+	int32_t *hl;               // per minimizer scratch: hit list
+	uint32_t *soff;            // per minimizer: exclusive prefix of kept n within the read
+	int32_t *n_a;              // [n_reads] anchors per read
+	int32_t *rep_len;          // [n_reads]
+	int32_t *n_mini;           // [n_reads] kept seeds
+	uint64_t *mini_pos;        // per minimizer slot: q_span<<32 | q_pos>>1 of kept seeds (compacted per read)
+	unsigned long long *counters; // [8]: n_hit, n_a_multi, probes, chain_pairs ...
+};
+
+struct DevAnchors {
+	const int64_t *aoff;       // [n_reads+1] anchor offsets
+	mm128 *a;                  // anchors (generation order, then sorted in place)
+	int32_t *f, *p, *v;        // chaining DP arrays
+	uint64_t *z;               // backtrack scratch: f<<32|i
+	uint8_t *t8;               // backtrack marks
+	int32_t *vi;               // backtrack chain member list
+	mm128 *b;                  // compacted anchors (output of compact_a)
+	mm128 *wk;                 // chain sort keys scratch
+	uint64_t *u;               // [total anchors / 1] chain descriptors, read r at aoff[r]
+	uint64_t *u2;
+	int32_t *n_u, *n_v;        // [n_reads]
+};
+
+#ifdef __HIPCC__
+void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
+void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
+void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
+void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
+void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st);
+void mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st);
+void mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, hipStream_t st);
+void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st);
+#endif

@@ -1,0 +1,638 @@
+// mm355_kernels.hip -- hand-written gfx950 kernels of the seeding + chaining half of the path.
+//
+// Rows of SURVEY.md section 8(a) implemented here (U: = minimap2 2.26 unit reproduced; the reference
+// reaches all of them through mm_map at /root/reference/src/lib.rs:482 and :587):
+//   a1  k_sketch        U:sketch.c::mm_sketch            one lane per read (order-dependent window logic), ring in LDS
+//   a2  k_mzflt         U:seed.c::mm_seed_mz_flt         one wave per read
+//   a3  k_seed_lookup   U:index.c::mm_idx_get            one lane per minimizer, 128-B-line flat table in HBM
+//   a4  k_seed_select   U:seed.c::mm_seed_select / mm_collect_matches   one wave per read
+//   a5  k_seed_expand   U:map.c::collect_seed_hits       one lane per anchor
+//   a6  k_sort_anchors  U:ksort.h::radix_sort_128x       one wave per read, literal in-place MSD radix (unstable!)
+//   a7  k_chain         U:lchain.c::mg_lchain_dp         one wave per read, 64 predecessors per step, ballot/prefix-max
+//   a8  k_backtrack     U:lchain.c::mg_chain_backtrack + compact_a    one wave per read
+// These are integer/byte, HBM- and latency-bound kernels: no MFMA anywhere (BASELINE.json north_star).
+// wave = 64 lanes; every workgroup below is exactly one wave unless stated.
+#include <hip/hip_runtime.h>
+#include "mm355_dev.h"
+
+#define WAVE 64
+#define LANE_LT_MASK(lane) ((lane) == 0? 0ULL : (~0ULL >> (64 - (lane))))
+
+// ------------------------------------------------------------------ a1: sketch
+struct BaseReader {
+	const uint8_t *s; uint64_t wd; int wi;
+	__device__ int operator()(int i) {
+		int q = i >> 3;
+		if (q != wi) { wd = ((const uint64_t*)s)[q]; wi = q; }   // reads start 16-B aligned and are padded
+		return mm_nt4((uint8_t)(wd >> ((i & 7) * 8)));
+	}
+};
+
+__global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSeeds sd)
+{
+	extern __shared__ mm128 ring[];   // w entries per lane, lane-interleaved
+	int t = blockIdx.x * WAVE + threadIdx.x;
+	if (t >= bt.n_reads) return;
+	int r = bt.order[t];
+	int len = bt.rlen[r];
+	int64_t off = bt.roff[r];
+	BaseReader rd = { bt.seq + off, 0, -1 };
+	int64_t n = 0;
+	if (len > 0) n = mm_sketch_seq(rd, len, ix.w, ix.k, 0u, sd.mz + off, (int64_t)len, ring + threadIdx.x, WAVE);
+	sd.n_mz[r] = (int32_t)n;
+}
+
+// ------------------------------------------------------------------ literal radix_sort_128x, one wave
+#define RS_STK 1024
+struct SortLds {
+	uint32_t cnt[256], bb[256], be[256];
+	uint32_t stk_beg[RS_STK], stk_end[RS_STK];
+	uint32_t stk_n, overflow;
+};
+
+template <typename T, typename Key>
+__device__ void wave_rank_sort_small(T *a, uint32_t n, Key key)   // n <= 64: stable == rs_insertsort's result
+{
+	const uint32_t lane = threadIdx.x & 63;
+	T mine; uint64_t kx = 0;
+	if (lane < n) { mine = a[lane]; kx = key(mine); }
+	uint32_t rank = 0;
+	for (uint32_t j = 0; j < n; ++j) {
+		uint64_t kj = __shfl(kx, (int)j);
+		rank += (kj < kx) || (kj == kx && j < lane);
+	}
+	__syncthreads();
+	if (lane < n) a[rank] = mine;
+	__syncthreads();
+}
+
+// sort a[0..n0) starting at byte shift s0, exactly as rs_sort_128x(beg,end,8,s0) would.
+template <bool STAGE, typename T, typename Key>
+__device__ void wave_rs_core(T *a, uint32_t n0, int s0, Key key, SortLds *L, T *stage, uint32_t stage_cap)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t base = L->stk_n;
+	__syncthreads();
+	if (lane == 0) { L->stk_beg[base] = 0; L->stk_end[base] = n0 | ((uint32_t)(s0 >> 3) << 28); L->stk_n = base + 1; }
+	__syncthreads();
+	for (;;) {
+		uint32_t sn = L->stk_n;
+		if (sn <= base) break;
+		uint32_t beg = L->stk_beg[sn - 1], e = L->stk_end[sn - 1];
+		uint32_t end = e & 0x0fffffffu, tot = end - beg;
+		int s = (int)(e >> 28) * 8;
+		__syncthreads();
+		if (lane == 0) L->stk_n = sn - 1;
+		__syncthreads();
+		if (STAGE && tot <= stage_cap) {   // the whole sub-problem fits the LDS stage: finish it there
+			for (uint32_t i = lane; i < tot; i += WAVE) stage[i] = a[beg + i];
+			__syncthreads();
+			wave_rs_core<false>(stage, tot, s, key, L, (T*)0, 0u);
+			__syncthreads();
+			for (uint32_t i = lane; i < tot; i += WAVE) a[beg + i] = stage[i];
+			__syncthreads();
+			continue;
+		}
+		for (uint32_t i = lane; i < 256; i += WAVE) L->cnt[i] = 0;
+		__syncthreads();
+		for (uint32_t i = beg + lane; i < end; i += WAVE) atomicAdd(&L->cnt[(uint32_t)(key(a[i]) >> s) & 255u], 1u);
+		__syncthreads();
+		bool single = false;
+		for (uint32_t i = lane; i < 256; i += WAVE) if (L->cnt[i] == tot) single = true;
+		if (__any(single)) {   // one bucket holds everything: the cycle-leader pass is the identity
+			if (s > 0 && lane == 0) {
+				uint32_t slot = L->stk_n;
+				L->stk_beg[slot] = beg; L->stk_end[slot] = end | ((uint32_t)((s - 8) >> 3) << 28); L->stk_n = slot + 1;
+			}
+			__syncthreads();
+			continue;
+		}
+		if (lane == 0) mm_rs_permute(a + beg, (int64_t)tot, s, L->cnt, L->bb, L->be, key);
+		__syncthreads();
+		if (s > 0) {
+			uint32_t s2 = (uint32_t)((s - 8) >> 3);
+			for (uint32_t k = lane; k < 256; k += WAVE) {
+				uint32_t b0 = L->bb[k], sz = L->cnt[k];
+				if (sz > MM355_RS_MIN_SIZE) {
+					uint32_t slot = atomicAdd(&L->stk_n, 1u);
+					if (slot < RS_STK) { L->stk_beg[slot] = beg + b0; L->stk_end[slot] = (beg + b0 + sz) | (s2 << 28); }
+					else L->overflow = 1;
+				} else if (sz > 1) mm_rs_insertsort(a + beg + b0, a + beg + b0 + sz, key);
+			}
+		}
+		__syncthreads();
+		if (L->overflow) { if (lane == 0 && L->stk_n > RS_STK) L->stk_n = RS_STK; __syncthreads(); }
+	}
+	__syncthreads();
+}
+
+template <typename T, typename Key>
+__device__ void wave_radix_sort(T *a, uint32_t n, Key key, SortLds *L, T *stage, uint32_t stage_cap)
+{
+	if (n <= 1) return;
+	if (n <= MM355_RS_MIN_SIZE) { wave_rank_sort_small(a, n, key); return; }
+	if ((threadIdx.x & 63) == 0) { L->stk_n = 0; L->overflow = 0; }
+	__syncthreads();
+	wave_rs_core<true>(a, n, 56, key, L, stage, stage_cap);
+}
+
+struct key_hi32 { __host__ __device__ uint64_t operator()(const uint64_t &v) const { return v >> 32; } };
+
+// ------------------------------------------------------------------ a2: mm_seed_mz_flt
+#define MZ_STAGE 2048
+__global__ __launch_bounds__(WAVE) void k_mzflt(DevParams pr, DevBatch bt, DevSeeds sd)
+{
+	__shared__ SortLds L;
+	__shared__ mm128 stage[MZ_STAGE];
+	const int r = blockIdx.x, lane = threadIdx.x;
+	const int n = sd.n_mz[r];
+	const int q_occ_max = pr.mid_occ;
+	if (n <= q_occ_max || pr.q_occ_frac <= 0.0f || q_occ_max <= 0) return;
+	const int64_t off = bt.roff[r];
+	mm128 *mz = sd.mz + off, *tmp = sd.mz_tmp + off;
+	for (int i = lane; i < n; i += WAVE) { tmp[i].x = mz[i].x; tmp[i].y = (uint64_t)i; }
+	__syncthreads();
+	wave_radix_sort(tmp, (uint32_t)n, mm_key_x(), &L, stage, (uint32_t)MZ_STAGE);
+	__syncthreads();
+	const float thr = (float)n * pr.q_occ_frac;
+	for (int i = lane; i < n; i += WAVE) {
+		if (i == 0 || tmp[i].x != tmp[i-1].x) {   // run start
+			int e = i + 1;
+			while (e < n && tmp[e].x == tmp[i].x) ++e;
+			int cnt = e - i;
+			if (cnt > q_occ_max && (float)cnt > thr)
+				for (int j = i; j < e; ++j) mz[tmp[j].y].x = 0;
+		}
+	}
+	__syncthreads();
+	int m = 0;   // order-preserving in-place compaction
+	for (int base = 0; base < n; base += WAVE) {
+		int i = base + lane;
+		mm128 v; v.x = 0; v.y = 0;
+		if (i < n) v = mz[i];
+		bool keep = i < n && v.x != 0;
+		unsigned long long mask = __ballot(keep);
+		__syncthreads();
+		if (keep) mz[m + __popcll(mask & LANE_LT_MASK(lane))] = v;
+		m += __popcll(mask);
+		__syncthreads();
+	}
+	if (lane == 0) sd.n_mz[r] = m;
+}
+
+// ------------------------------------------------------------------ a3: seed lookup (the HBM-gather kernel)
+// Algorithmic bytes per minimizer: 16 (minimizer read) + 16 (one slot, when present).
+__global__ __launch_bounds__(256) void k_seed_lookup(DevIndex ix, DevBatch bt, DevSeeds sd)
+{
+	const int r = blockIdx.x;
+	const int n = sd.n_mz[r];
+	const int64_t off = bt.roff[r];
+	const mm128 *mz = sd.mz + off;
+	unsigned int hits = 0;
+	for (int j = threadIdx.x; j < n; j += 256) {
+		const uint64_t minier = mz[j].x >> 8;
+		uint64_t line = mm_table_hash(minier) & ix.line_mask;
+		uint32_t cnt = 0; uint64_t val = 0;
+		for (;;) {
+			const mm355_slot *ln = ix.slots + line * MM355_SLOTS_PER_LINE;
+			bool done = false;
+#pragma unroll 1
+			for (int q = 0; q < MM355_SLOTS_PER_LINE; ++q) {
+				const uint4 raw = *(const uint4*)(ln + q);   // one 16-B slot
+				const uint64_t key = (uint64_t)raw.y << 32 | raw.x, v = (uint64_t)raw.w << 32 | raw.z;
+				if (key == UINT64_MAX) { done = true; break; }
+				if ((key >> 1) == minier) {
+					if (key & 1) cnt = 1, val = v;
+					else cnt = (uint32_t)v, val = v >> 32;
+					done = true; break;
+				}
+			}
+			if (done) break;
+			line = (line + 1) & ix.line_mask;
+		}
+		sd.sn[off + j] = cnt; sd.sv[off + j] = val;
+		hits += cnt > 0;
+	}
+	for (int o = 32; o > 0; o >>= 1) hits += __shfl_down(hits, o);
+	if ((threadIdx.x & 63) == 0 && hits) atomicAdd(&sd.counters[0], (unsigned long long)hits);
+}
+
+// ------------------------------------------------------------------ a4: mm_seed_select + mm_collect_matches
+__device__ inline void heapdown_u64(uint32_t i, uint32_t n, uint64_t *l)
+{
+	uint32_t k = i;
+	uint64_t tmp = l[i];
+	while ((k = (k << 1) + 1) < n) {
+		if (k != n - 1 && l[k] < l[k+1]) ++k;
+		if (l[k] < tmp) break;
+		l[i] = l[k]; i = k;
+	}
+	l[i] = tmp;
+}
+
+__global__ __launch_bounds__(WAVE) void k_seed_select(DevIndex ix, DevParams pr, DevBatch bt, DevSeeds sd)
+{
+	__shared__ uint64_t heap[128];
+	const int r = blockIdx.x, lane = threadIdx.x;
+	const int n = sd.n_mz[r], qlen = bt.rlen[r];
+	const int64_t off = bt.roff[r];
+	const mm128 *mz = sd.mz + off;
+	const uint32_t *sn = sd.sn + off;
+	uint8_t *sflt = sd.sflt + off;
+	int32_t *hl = sd.hl + off;
+	uint32_t *soff = sd.soff + off;
+	uint64_t *mini_pos = sd.mini_pos + off;
+	const int max_occ = pr.mid_occ;
+	int n_m0 = 0, n_high = 0;
+	for (int base = 0; base < n; base += WAVE) {   // hit list, order preserving
+		int j = base + lane;
+		uint32_t c = j < n? sn[j] : 0;
+		bool hit = c > 0;
+		unsigned long long mask = __ballot(hit);
+		if (hit) hl[n_m0 + __popcll(mask & LANE_LT_MASK(lane))] = j;
+		if (j < n) sflt[j] = 0;
+		n_m0 += __popcll(mask);
+		n_high += __popcll(__ballot(hit && c > (uint32_t)max_occ));
+	}
+	__syncthreads();
+	if (lane != 0) return;
+	if (pr.occ_dist > 0 && pr.max_max_occ > max_occ) {   // mm_seed_select
+		if (n_m0 >= 2 && n_high > 0) {
+			const int dist = pr.occ_dist;
+			for (int i = 0, last0 = -1; i <= n_m0; ++i) {
+				if (i == n_m0 || sn[hl[i]] <= (uint32_t)max_occ) {
+					if (i - last0 > 1) {
+						int32_t ps = last0 < 0? 0 : (int32_t)((uint32_t)mz[hl[last0]].y >> 1);
+						int32_t pe = i == n_m0? qlen : (int32_t)((uint32_t)mz[hl[i]].y >> 1);
+						int32_t j, k, st = last0 + 1, en = i;
+						int32_t max_high_occ = (int32_t)((double)(pe - ps) / dist + .499);
+						if (max_high_occ > 0) {
+							if (max_high_occ > 128) max_high_occ = 128;
+							for (j = st, k = 0; j < en && k < max_high_occ; ++j, ++k)
+								heap[k] = (uint64_t)sn[hl[j]] << 32 | (uint32_t)j;
+							for (uint32_t h = ((uint32_t)k >> 1) - 1; h != (uint32_t)-1; --h) heapdown_u64(h, (uint32_t)k, heap);
+							for (; j < en; ++j) {
+								if ((int32_t)sn[hl[j]] < (int32_t)(heap[0] >> 32)) {
+									heap[0] = (uint64_t)sn[hl[j]] << 32 | (uint32_t)j;
+									heapdown_u64(0, (uint32_t)k, heap);
+								}
+							}
+							for (j = 0; j < k; ++j) sflt[hl[(uint32_t)heap[j]]] = 1;
+						}
+						for (j = st; j < en; ++j) sflt[hl[j]] ^= 1;
+						for (j = st; j < en; ++j)
+							if (sn[hl[j]] > (uint32_t)pr.max_max_occ) sflt[hl[j]] = 1;
+					}
+					last0 = i;
+				}
+			}
+		}
+	} else {
+		for (int i = 0; i < n_m0; ++i)
+			if (sn[hl[i]] > (uint32_t)max_occ) sflt[hl[i]] = 1;
+	}
+	// mm_collect_matches tail: rep_len, n_a, mini_pos, kept list (hl/soff are rewritten in place, kept ordinal <= i)
+	int rep_st = 0, rep_en = 0, rep_len = 0, n_kept = 0;
+	uint32_t n_a = 0; unsigned long long multi = 0;
+	for (int i = 0; i < n_m0; ++i) {
+		const int j = hl[i];
+		const mm128 m = mz[j];
+		const uint32_t q_pos = (uint32_t)m.y, q_span = (uint32_t)(m.x & 0xff);
+		if (sflt[j]) {
+			int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
+			if (st > rep_en) {
+				rep_len += rep_en - rep_st;
+				rep_st = st, rep_en = en;
+			} else rep_en = en;
+		} else {
+			const uint32_t c = sn[j];
+			hl[n_kept] = j; soff[n_kept] = n_a;
+			mini_pos[n_kept] = (uint64_t)q_span << 32 | q_pos >> 1;
+			n_a += c; ++n_kept;
+			if (c > 1) multi += c;
+		}
+	}
+	rep_len += rep_en - rep_st;
+	sd.n_a[r] = (int32_t)n_a; sd.rep_len[r] = rep_len; sd.n_mini[r] = n_kept;
+	if (multi) atomicAdd(&sd.counters[1], multi);
+}
+
+// ------------------------------------------------------------------ a5: collect_seed_hits (anchor expansion)
+__global__ __launch_bounds__(256) void k_seed_expand(DevIndex ix, DevParams pr, DevBatch bt, DevSeeds sd, DevAnchors an)
+{
+	const int r = blockIdx.x;
+	const int na = sd.n_a[r], nk = sd.n_mini[r], nmz = sd.n_mz[r], qlen = bt.rlen[r];
+	const int64_t off = bt.roff[r];
+	const mm128 *mz = sd.mz + off;
+	const int32_t *hl = sd.hl + off;
+	const uint32_t *soff = sd.soff + off;
+	mm128 *a = an.a + an.aoff[r];
+	for (int t = threadIdx.x; t < na; t += 256) {
+		int lo = 0, hi = nk;
+		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (soff[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
+		const int j = hl[lo];
+		const uint32_t kq = (uint32_t)t - soff[lo];
+		const mm128 m = mz[j];
+		const uint32_t c = sd.sn[off + j];
+		const uint64_t v = sd.sv[off + j];
+		const uint64_t rk = c == 1? v : ix.pos[v + kq];
+		const uint32_t q_pos = (uint32_t)m.y, q_span = (uint32_t)(m.x & 0xff);
+		const uint32_t rpos = (uint32_t)rk >> 1;
+		bool tandem = (j > 0 && (mz[j-1].x >> 8) == (m.x >> 8)) || (j < nmz - 1 && (mz[j+1].x >> 8) == (m.x >> 8));
+		mm128 o;
+		if ((rk & 1) == (q_pos & 1)) {   // forward strand
+			o.x = (rk & 0xffffffff00000000ULL) | rpos;
+			o.y = (uint64_t)q_span << 32 | q_pos >> 1;
+		} else {                          // reverse strand
+			o.x = 1ULL << 63 | (rk & 0xffffffff00000000ULL) | rpos;
+			o.y = (uint64_t)q_span << 32 | (uint32_t)(qlen - (int)((q_pos >> 1) + 1 - q_span) - 1);
+		}
+		if (tandem) o.y |= MM355_SEED_TANDEM;
+		a[t] = o;
+	}
+}
+
+// ------------------------------------------------------------------ a6: radix_sort_128x on the anchors
+#define A_STAGE 2048
+__global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors an, int *err)
+{
+	__shared__ SortLds L;
+	__shared__ mm128 stage[A_STAGE];
+	const int r = blockIdx.x;
+	const int64_t o = an.aoff[r];
+	const uint32_t n = (uint32_t)(an.aoff[r+1] - o);
+	wave_radix_sort(an.a + o, n, mm_key_x(), &L, stage, (uint32_t)A_STAGE);
+	if (threadIdx.x == 0 && n > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
+}
+
+// ------------------------------------------------------------------ a7: mg_lchain_dp (fill)
+#define TW_SIZE 8192
+#define TW_MASK (TW_SIZE - 1)
+
+__device__ inline int32_t wave_excl_prefix_max(int32_t v, int lane)   // exclusive prefix max over lanes, INT32_MIN identity
+{
+	int32_t x = v;
+	for (int o = 1; o < 64; o <<= 1) {
+		int32_t y = __shfl_up(x, o);
+		if (lane >= o) x = x > y? x : y;
+	}
+	int32_t e = __shfl_up(x, 1);
+	return lane == 0? INT32_MIN : e;
+}
+
+__global__ __launch_bounds__(WAVE) void k_chain(DevParams pr, DevBatch bt, DevAnchors an, unsigned long long *pairs_ctr)
+{
+	__shared__ int32_t tw[TW_SIZE];   // t[] marks of the active window, circular by anchor index
+	const int r = blockIdx.x, lane = threadIdx.x;
+	const int64_t o = an.aoff[r];
+	const int n = (int)(an.aoff[r+1] - o);
+	if (n == 0) return;
+	const mm128 *a = an.a + o;
+	int32_t *f = an.f + o, *p = an.p + o, *v = an.v + o;
+	const int qlen = bt.rlen[r];
+	int32_t max_dist_x, max_dist_y = pr.max_gap;
+	if (pr.max_gap_ref > 0) max_dist_x = pr.max_gap_ref;
+	else if (pr.max_frag_len > 0) { max_dist_x = pr.max_frag_len - qlen; if (max_dist_x < pr.max_gap) max_dist_x = pr.max_gap; }
+	else max_dist_x = pr.max_gap;
+	const int bw = pr.bw, max_skip = pr.max_chain_skip, max_iter = pr.max_chain_iter;
+	if (max_dist_x < bw) max_dist_x = bw;
+	if (max_dist_y < bw) max_dist_y = bw;
+	const float pen_gap = pr.pen_gap, pen_skip = pr.pen_skip;
+	for (int i = lane; i < TW_SIZE; i += WAVE) tw[i] = -1;
+	__syncthreads();
+	int st = 0, max_ii = -1;
+	unsigned long long pairs = 0;
+	for (int i = 0; i < n; ++i) {
+		const mm128 ai = a[i];
+		// advance st (U: while (st < i && (other rid/strand || too far)) ++st)
+		for (;;) {
+			int idx = st + lane;
+			bool c = false;
+			if (idx < i) { uint64_t xs = a[idx].x; c = (ai.x >> 32 != xs >> 32) || ai.x > xs + (uint64_t)(int64_t)max_dist_x; }
+			unsigned long long m = __ballot(c);
+			if (m == ~0ULL) { st += 64; continue; }
+			st += __builtin_ctzll(~m);
+			break;
+		}
+		if (i - st > max_iter) st = i - max_iter;
+		int32_t max_f = (int32_t)(ai.y >> 32 & 0xff), max_j = -1, n_skip = 0;
+		int end_j = st - 1;
+		for (int jb = i - 1; jb >= st; jb -= WAVE) {
+			const int j = jb - lane;
+			const bool active = j >= st;
+			int32_t sc = MM355_SC_NONE, pj = -1;
+			if (active) {
+				const mm128 aj = a[j];
+				sc = mm_comput_sc(ai.x, ai.y, aj.x, aj.y, max_dist_x, max_dist_y, bw, pen_gap, pen_skip);
+				if (sc != MM355_SC_NONE) { sc += f[j]; pj = p[j]; }
+			}
+			const bool valid = sc != MM355_SC_NONE;
+			pairs += __popcll(__ballot(active));
+			if (valid && pj >= st) tw[pj & TW_MASK] = i;   // t[p[j]] = i; marks below st are never tested
+			__syncthreads();
+			const bool marked = valid && tw[j & TW_MASK] == i;
+			const int32_t scv = valid? sc : INT32_MIN;
+			int32_t pm = wave_excl_prefix_max(scv, lane);
+			pm = pm > max_f? pm : max_f;
+			const bool improved = valid && sc > pm;
+			unsigned long long imask = __ballot(improved), mmask = __ballot(marked && !improved);
+			unsigned long long ev = imask | mmask;
+			int brk = -1;
+			while (ev) {   // wave-uniform replay of the n_skip counter over the event lanes
+				int l = __builtin_ctzll(ev);
+				ev &= ev - 1;
+				if (imask >> l & 1) { if (n_skip > 0) --n_skip; }
+				else if (++n_skip > max_skip) { brk = l; break; }
+			}
+			const bool considered = brk < 0 || lane <= brk;
+			int32_t cv = (valid && considered)? sc : INT32_MIN;
+			int32_t cmax = cv;
+			for (int of = 32; of > 0; of >>= 1) { int32_t y2 = __shfl_xor(cmax, of); cmax = cmax > y2? cmax : y2; }
+			if (cmax > max_f) {
+				unsigned long long w = __ballot(cv == cmax);
+				int wl = __builtin_ctzll(w);   // lowest lane = highest j = first met by the sequential scan
+				max_f = cmax; max_j = jb - wl;
+			}
+			__syncthreads();
+			if (brk >= 0) { end_j = jb - brk; break; }
+		}
+		// max_ii rescue
+		bool need = max_ii < 0;
+		if (!need) need = ai.x - a[max_ii].x > (uint64_t)(int64_t)max_dist_x;
+		if (need) {
+			int32_t bf = INT32_MIN, bj = -1;
+			for (int j = i - 1 - lane; j >= st; j -= WAVE) { int32_t fj = f[j]; if (bf < fj) bf = fj, bj = j; }
+			for (int of = 32; of > 0; of >>= 1) {
+				int32_t of_f = __shfl_xor(bf, of), of_j = __shfl_xor(bj, of);
+				if (of_f > bf || (of_f == bf && of_j > bj)) bf = of_f, bj = of_j;
+			}
+			max_ii = bj;
+		}
+		if (max_ii >= 0 && max_ii < end_j) {
+			const mm128 am = a[max_ii];
+			int32_t tmp = mm_comput_sc(ai.x, ai.y, am.x, am.y, max_dist_x, max_dist_y, bw, pen_gap, pen_skip);
+			if (tmp != MM355_SC_NONE) { int32_t fm = f[max_ii]; if (max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii; }
+		}
+		int32_t vi = max_f;
+		if (max_j >= 0) { int32_t vm = v[max_j]; if (vm > max_f) vi = vm; }
+		if (lane == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
+		if (max_ii < 0) max_ii = i;
+		else {
+			uint64_t d = ai.x - a[max_ii].x;
+			int32_t fm = (max_ii == i)? max_f : f[max_ii];
+			if (d <= (uint64_t)(int64_t)max_dist_x && fm < max_f) max_ii = i;
+		}
+		__syncthreads();   // f/p/v[i] visible to the whole wave before the next anchor reads them
+	}
+	if (lane == 0 && pairs) atomicAdd(pairs_ctr, pairs);
+}
+
+// ------------------------------------------------------------------ a8: mg_chain_backtrack + compact_a
+#define Z_STAGE 4096
+__global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, DevAnchors an, int *err)
+{
+	__shared__ SortLds L;
+	__shared__ uint64_t zstage[Z_STAGE];
+	const int r = blockIdx.x, lane = threadIdx.x;
+	const int64_t o = an.aoff[r];
+	const int n = (int)(an.aoff[r+1] - o);
+	if (lane == 0) { an.n_u[r] = 0; an.n_v[r] = 0; }
+	if (n == 0) return;
+	const mm128 *a = an.a + o;
+	const int32_t *f = an.f + o, *p = an.p + o;
+	uint64_t *z = an.z + o;
+	uint8_t *t8 = an.t8 + o;
+	int32_t *vi = an.vi + o;
+	mm128 *b = an.b + o;
+	uint64_t *u = an.u + o, *u2 = an.u2 + o;
+	mm128 *wk = an.wk + o;
+	const int min_sc = pr.min_chain_score, min_cnt = pr.min_cnt, max_drop = pr.bw;
+	// z[] = (f, i) for f >= min_sc, in anchor order
+	int n_z = 0;
+	for (int base = 0; base < n; base += WAVE) {
+		int i = base + lane;
+		int32_t fi = i < n? f[i] : INT32_MIN;
+		bool keep = i < n && fi >= min_sc;
+		unsigned long long mask = __ballot(keep);
+		if (keep) z[n_z + __popcll(mask & LANE_LT_MASK(lane))] = (uint64_t)(uint32_t)fi << 32 | (uint32_t)i;
+		if (i < n) t8[i] = 0;
+		n_z += __popcll(mask);
+	}
+	__syncthreads();
+	if (n_z == 0) return;
+	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE);
+	if (lane == 0 && n_z > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
+	__syncthreads();
+	__shared__ int s_nu, s_nv;
+	if (lane == 0) {
+		int n_v = 0, n_u = 0;
+		for (int k = n_z - 1; k >= 0; --k) {
+			const int zi = (int)(uint32_t)z[k];
+			const int32_t zx = (int32_t)(z[k] >> 32);
+			if (t8[zi] != 0) continue;
+			// mg_chain_bk_end
+			int i = zi, end_i = -1, max_i = i;
+			int32_t max_s = 0;
+			do {
+				int32_t s;
+				t8[i] = 2;
+				end_i = i = p[i];
+				s = i < 0? zx : zx - f[i];
+				if (s > max_s) max_s = s, max_i = i;
+				else if (max_s - s > max_drop) break;
+			} while (i >= 0 && t8[i] == 0);
+			for (i = zi; i >= 0 && i != end_i; i = p[i]) t8[i] = 0;
+			end_i = max_i;
+			// collect
+			const int n_v0 = n_v;
+			for (i = zi; i != end_i; i = p[i]) vi[n_v++] = i, t8[i] = 1;
+			const int32_t sc = i < 0? zx : zx - f[i];
+			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt)
+				u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)(n_v - n_v0);
+			else n_v = n_v0;
+		}
+		s_nu = n_u; s_nv = n_v;
+	}
+	__syncthreads();
+	const int n_u = s_nu, n_v = s_nv;
+	if (n_u == 0) return;
+	// compact_a: chains written forward; then chains re-ordered by the x of their first anchor
+	// (1) per-chain start offsets into wk[].y (k<<32|i), b[] filled in forward order
+	if (lane == 0) {
+		int k = 0;
+		for (int i = 0; i < n_u; ++i) { wk[i].y = (uint64_t)(uint32_t)k << 32 | (uint32_t)i; k += (int32_t)u[i]; }
+	}
+	__syncthreads();
+	for (int c = 0; c < n_u; ++c) {
+		const int k0 = (int)(wk[c].y >> 32), ni = (int32_t)u[c];
+		for (int j = lane; j < ni; j += WAVE) b[k0 + j] = a[vi[k0 + (ni - j - 1)]];
+	}
+	__syncthreads();
+	for (int c = lane; c < n_u; c += WAVE) wk[c].x = b[wk[c].y >> 32].x;
+	__syncthreads();
+	wave_radix_sort(wk, (uint32_t)n_u, mm_key_x(), &L, (mm128*)zstage, (uint32_t)(Z_STAGE / 2));
+	__syncthreads();
+	// (2) final order: anchors go back into a[] region as the compacted list (written to an.a, length n_v)
+	mm128 *aout = an.a + o;
+	if (lane == 0) {
+		int k = 0;
+		for (int i = 0; i < n_u; ++i) {
+			const int j = (int)(uint32_t)wk[i].y;
+			u2[i] = u[j];
+			wk[i].x = (uint64_t)(uint32_t)k;   // destination offset
+			k += (int32_t)u[j];
+		}
+	}
+	__syncthreads();
+	for (int c = 0; c < n_u; ++c) {
+		const int src = (int)(wk[c].y >> 32), dst = (int)wk[c].x, ni = (int32_t)u2[c];
+		for (int j = lane; j < ni; j += WAVE) aout[dst + j] = b[src + j];
+	}
+	__syncthreads();
+	for (int c = lane; c < n_u; c += WAVE) u[c] = u2[c];
+	if (lane == 0) { an.n_u[r] = n_u; an.n_v[r] = n_v; }
+}
+
+// ------------------------------------------------------------------ launchers
+void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
+{
+	if (bt.n_reads == 0) return;
+	int blocks = (bt.n_reads + WAVE - 1) / WAVE;
+	size_t lds = (size_t)ix.w * WAVE * sizeof(mm128);
+	hipLaunchKernelGGL(k_sketch, dim3(blocks), dim3(WAVE), lds, st, ix, bt, sd);
+}
+void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
+{
+	if (bt.n_reads == 0) return;
+	hipLaunchKernelGGL(k_mzflt, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, sd);
+}
+void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
+{
+	if (bt.n_reads == 0) return;
+	hipLaunchKernelGGL(k_seed_lookup, dim3(bt.n_reads), dim3(256), 0, st, ix, bt, sd);
+}
+void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
+{
+	if (bt.n_reads == 0) return;
+	hipLaunchKernelGGL(k_seed_select, dim3(bt.n_reads), dim3(WAVE), 0, st, ix, pr, bt, sd);
+}
+void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st)
+{
+	if (bt.n_reads == 0) return;
+	hipLaunchKernelGGL(k_seed_expand, dim3(bt.n_reads), dim3(256), 0, st, ix, pr, bt, sd, an);
+}
+void mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st)
+{
+	if (bt.n_reads == 0) return;
+	hipLaunchKernelGGL(k_sort_anchors, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, an, err);
+}
+void mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, hipStream_t st)
+{
+	if (bt.n_reads == 0) return;
+	hipLaunchKernelGGL(k_chain, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, an, pairs);
+}
+void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st)
+{
+	if (bt.n_reads == 0) return;
+	hipLaunchKernelGGL(k_backtrack, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, an, err);
+}

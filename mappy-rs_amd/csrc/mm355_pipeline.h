@@ -1,0 +1,59 @@
+// mm355_pipeline.h -- per-GPU batch context: device buffers, streams, stage drivers
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "mm355_host.h"
+#include "mm355_dev.h"
+
+struct DBuf {
+	void *p = 0; size_t cap = 0;
+	int ensure(size_t bytes) {
+		if (bytes <= cap) return 0;
+		if (p) (void)hipFree(p);
+		size_t want = bytes + bytes / 4 + 256;
+		if (hipMalloc(&p, want) != hipSuccess) { p = 0; cap = 0; return -1; }
+		cap = want; return 0;
+	}
+	void release() { if (p) (void)hipFree(p); p = 0; cap = 0; }
+	template <typename T> T *as() const { return (T*)p; }
+};
+
+struct HostBatch {            // packed reads of one sub-batch
+	int64_t n_reads = 0, n_bytes = 0, n_bases = 0;
+	std::vector<uint8_t> seq; std::vector<int64_t> roff; std::vector<int32_t> rlen, order;
+	std::vector<int32_t> n_mz, n_a, rep_len, n_mini, n_u, n_v;
+	std::vector<int64_t> aoff;
+	int64_t tot_a = 0;
+};
+
+struct mm355_ctx {
+	const mm355_index *mi = 0;
+	int dev = 0;
+	hipStream_t st = 0;
+	DevIndex dix;
+	DBuf ix_slots, ix_pos, ix_S, ix_off, ix_len;
+	// per-batch device buffers
+	DBuf seq, roff, rlen, order;
+	DBuf mz, mz_tmp, n_mz, sn, sv, sflt, hl, soff, n_a, rep_len, n_mini, mini_pos, counters, err;
+	DBuf aoff, a, f, p, v, z, t8, vi, b, wk, u, u2, n_u, n_v;
+	// dp buffers
+	DBuf dp_jobs, dp_res, dp_q, dp_t, dp_bt, dp_cig, dp_work, dp_H;
+	DBuf rq;       // per-read query codes fwd|rev
+	mm355_stats_t stats;
+	hipEvent_t ev0 = 0, ev1 = 0;
+	HostBatch hb;
+};
+
+DevParams mm355_make_params(const mm355_mapopt_t *mo, const mm355_index *mi);
+int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi);
+
+// stage drivers (each leaves its outputs resident on the device and the per-read counts in ctx->hb)
+int mm355_run_pack(mm355_ctx *ctx, int64_t n_reads, const char *const *seqs, const int32_t *lens);
+int mm355_run_sketch(mm355_ctx *ctx);
+int mm355_run_seeds(mm355_ctx *ctx, const DevParams &pr);                  // mz_flt + lookup + select (+ D2H counts, anchor offsets)
+int mm355_run_expand(mm355_ctx *ctx, const DevParams &pr);
+int mm355_run_sort(mm355_ctx *ctx);
+int mm355_run_chain(mm355_ctx *ctx, const DevParams &pr);
+int mm355_run_backtrack(mm355_ctx *ctx, const DevParams &pr);
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)

@@ -1,0 +1,337 @@
+// mm355_pipeline.hip -- per-GPU context and the stage drivers of the seeding + chaining half of the path.
+// Replaces the reference's per-thread mm_tbuf_t + the worker loop body at /root/reference/src/lib.rs:587-593:
+// instead of N OS threads each calling mm_map on one read, one context owns one GPU, the index is uploaded
+// once into its HBM, and a whole batch of reads moves through the kernels of mm355_kernels.hip.
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <numeric>
+#include "mm355_pipeline.h"
+
+// ------------------------------------------------------------------ options -> kernel parameters
+int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi)
+{
+	if (mi->flag & 1) return MM355_EUNSUP;                                           // HPC index
+	if (mo->flag & (MMF_SPLICE | MMF_SR | MMF_QSTRAND | MMF_HEAP_SORT)) return MM355_EUNSUP;
+	if (mo->flag & (MMF_FOR_ONLY | MMF_REV_ONLY)) return MM355_EUNSUP;               // skip_seed() variants: next round
+	if (!(mo->flag & MMF_CIGAR)) return MM355_EUNSUP;                                // the reference always sets it (lib.rs:339)
+	if (mo->max_chain_iter > 8000 || mo->max_chain_iter < 1) return MM355_EUNSUP;    // LDS mark window of k_chain
+	if (mi->w > 64 || mi->k > 28 || mi->k < 1) return MM355_EUNSUP;
+	if (mo->sdust_thres > 0) return MM355_EUNSUP;
+	return 0;
+}
+
+DevParams mm355_make_params(const mm355_mapopt_t *mo, const mm355_index *mi)
+{
+	DevParams p;
+	memset(&p, 0, sizeof(p));
+	p.flag = mo->flag;
+	p.mid_occ = mo->mid_occ; p.max_max_occ = mo->max_max_occ; p.occ_dist = mo->occ_dist;
+	p.q_occ_frac = mo->q_occ_frac;
+	p.max_gap = mo->max_gap; p.max_gap_ref = mo->max_gap_ref; p.max_frag_len = mo->max_frag_len;
+	p.bw = mo->bw; p.max_chain_skip = mo->max_chain_skip; p.max_chain_iter = mo->max_chain_iter;
+	p.min_cnt = mo->min_cnt; p.min_chain_score = mo->min_chain_score;
+	p.pen_gap = (float)(mo->chain_gap_scale * 0.01 * mi->k);     // U:map.c: float <- double product
+	p.pen_skip = (float)(mo->chain_skip_scale * 0.01 * mi->k);
+	return p;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int mm355_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ctx_t **out)
+{
+	*out = 0;
+	if (mi == 0) return MM355_ENOIDX;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n == 0 || device_id >= n) return MM355_ENODEV;
+	HIPCHK(hipSetDevice(device_id));
+	mm355_ctx *c = new mm355_ctx();
+	c->mi = mi; c->dev = device_id;
+	HIPCHK(hipStreamCreate(&c->st));
+	HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+	// index -> HBM (replicated per GPU; no collective is ever needed)
+	size_t sb = mi->slots.size() * sizeof(mm355_slot), pb = std::max<size_t>(mi->pos.size(), 1) * 8, Sb = std::max<size_t>(mi->S.size(), 1) * 4;
+	if (c->ix_slots.ensure(sb) || c->ix_pos.ensure(pb) || c->ix_S.ensure(Sb + 16) || c->ix_off.ensure(mi->n_seq * 8) || c->ix_len.ensure(mi->n_seq * 4)) { delete c; return MM355_ENOMEM; }
+	HIPCHK(hipMemcpy(c->ix_slots.p, mi->slots.data(), sb, hipMemcpyHostToDevice));
+	if (!mi->pos.empty()) HIPCHK(hipMemcpy(c->ix_pos.p, mi->pos.data(), mi->pos.size() * 8, hipMemcpyHostToDevice));
+	if (!mi->S.empty()) HIPCHK(hipMemcpy(c->ix_S.p, mi->S.data(), mi->S.size() * 4, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(c->ix_off.p, mi->seq_off.data(), mi->n_seq * 8, hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(c->ix_len.p, mi->seq_len.data(), mi->n_seq * 4, hipMemcpyHostToDevice));
+	c->dix.slots = c->ix_slots.as<mm355_slot>(); c->dix.line_mask = mi->n_lines - 1;
+	c->dix.pos = c->ix_pos.as<uint64_t>(); c->dix.S = c->ix_S.as<uint32_t>();
+	c->dix.seq_off = c->ix_off.as<uint64_t>(); c->dix.seq_len = c->ix_len.as<uint32_t>();
+	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
+	if (c->counters.ensure(64) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
+	memset(&c->stats, 0, sizeof(c->stats));
+	*out = c;
+	return 0;
+}
+
+extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
+{
+	if (c == 0) return;
+	(void)hipSetDevice(c->dev);
+	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->seq, &c->roff, &c->rlen, &c->order,
+		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
+		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
+		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq };
+	for (DBuf *b : bufs) b->release();
+	if (c->ev0) (void)hipEventDestroy(c->ev0);
+	if (c->ev1) (void)hipEventDestroy(c->ev1);
+	if (c->st) (void)hipStreamDestroy(c->st);
+	delete c;
+}
+
+extern "C" int mm355_get_stats(mm355_ctx_t *c, mm355_stats_t *st) { if (c == 0) return MM355_EINVAL; *st = c->stats; return 0; }
+
+// time one launch group on the context's stream with HIP events
+struct EvTimer {
+	mm355_ctx *c; double *acc;
+	EvTimer(mm355_ctx *c_, double *a) : c(c_), acc(a) { (void)hipEventRecord(c->ev0, c->st); }
+	~EvTimer() { float ms = 0; (void)hipEventRecord(c->ev1, c->st); (void)hipEventSynchronize(c->ev1); (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *acc += ms; }
+};
+
+static DevBatch dev_batch(mm355_ctx *c)
+{
+	DevBatch b;
+	b.n_reads = (int32_t)c->hb.n_reads; b.seq = c->seq.as<uint8_t>(); b.roff = c->roff.as<int64_t>();
+	b.rlen = c->rlen.as<int32_t>(); b.order = c->order.as<int32_t>();
+	return b;
+}
+static DevSeeds dev_seeds(mm355_ctx *c)
+{
+	DevSeeds s;
+	s.mz = c->mz.as<mm128>(); s.mz_tmp = c->mz_tmp.as<mm128>(); s.n_mz = c->n_mz.as<int32_t>();
+	s.sn = c->sn.as<uint32_t>(); s.sv = c->sv.as<uint64_t>(); s.sflt = c->sflt.as<uint8_t>(); s.hl = c->hl.as<int32_t>();
+	s.soff = c->soff.as<uint32_t>(); s.n_a = c->n_a.as<int32_t>(); s.rep_len = c->rep_len.as<int32_t>();
+	s.n_mini = c->n_mini.as<int32_t>(); s.mini_pos = c->mini_pos.as<uint64_t>(); s.counters = c->counters.as<unsigned long long>();
+	return s;
+}
+static DevAnchors dev_anchors(mm355_ctx *c)
+{
+	DevAnchors a;
+	a.aoff = c->aoff.as<int64_t>(); a.a = c->a.as<mm128>(); a.f = c->f.as<int32_t>(); a.p = c->p.as<int32_t>(); a.v = c->v.as<int32_t>();
+	a.z = c->z.as<uint64_t>(); a.t8 = c->t8.as<uint8_t>(); a.vi = c->vi.as<int32_t>(); a.b = c->b.as<mm128>(); a.wk = c->wk.as<mm128>();
+	a.u = c->u.as<uint64_t>(); a.u2 = c->u2.as<uint64_t>(); a.n_u = c->n_u.as<int32_t>(); a.n_v = c->n_v.as<int32_t>();
+	return a;
+}
+
+// ------------------------------------------------------------------ stage drivers
+int mm355_run_pack(mm355_ctx *c, int64_t n_reads, const char *const *seqs, const int32_t *lens)
+{
+	HIPCHK(hipSetDevice(c->dev));
+	HostBatch &hb = c->hb;
+	hb.n_reads = n_reads; hb.roff.resize(n_reads + 1); hb.rlen.assign(lens, lens + n_reads); hb.order.resize(n_reads);
+	int64_t off = 0, bases = 0;
+	for (int64_t i = 0; i < n_reads; ++i) { hb.roff[i] = off; off += ((int64_t)lens[i] + 15) / 16 * 16; bases += lens[i]; }
+	hb.roff[n_reads] = off; hb.n_bytes = off; hb.n_bases = bases;
+	hb.seq.assign((size_t)off + 32, 'N');
+	for (int64_t i = 0; i < n_reads; ++i) if (lens[i] > 0) memcpy(&hb.seq[hb.roff[i]], seqs[i], lens[i]);
+	std::iota(hb.order.begin(), hb.order.end(), 0);
+	std::stable_sort(hb.order.begin(), hb.order.end(), [&](int32_t x, int32_t y) { return hb.rlen[x] > hb.rlen[y]; });
+	size_t nb = (size_t)off + 32, nr = (size_t)std::max<int64_t>(n_reads, 1);
+	if (c->seq.ensure(nb) || c->roff.ensure((nr + 1) * 8) || c->rlen.ensure(nr * 4) || c->order.ensure(nr * 4)) return MM355_ENOMEM;
+	size_t slots = (size_t)off + 64;   // one slot per (padded) base is the worst case for every per-minimizer array
+	if (c->mz.ensure(slots * 16) || c->mz_tmp.ensure(slots * 16) || c->n_mz.ensure(nr * 4) || c->sn.ensure(slots * 4) || c->sv.ensure(slots * 8) ||
+	    c->sflt.ensure(slots) || c->hl.ensure(slots * 4) || c->soff.ensure(slots * 4) || c->n_a.ensure(nr * 4) || c->rep_len.ensure(nr * 4) ||
+	    c->n_mini.ensure(nr * 4) || c->mini_pos.ensure(slots * 8) || c->n_u.ensure(nr * 4) || c->n_v.ensure(nr * 4)) return MM355_ENOMEM;
+	HIPCHK(hipMemcpyAsync(c->seq.p, hb.seq.data(), nb, hipMemcpyHostToDevice, c->st));
+	HIPCHK(hipMemcpyAsync(c->roff.p, hb.roff.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->st));
+	if (n_reads) {
+		HIPCHK(hipMemcpyAsync(c->rlen.p, hb.rlen.data(), n_reads * 4, hipMemcpyHostToDevice, c->st));
+		HIPCHK(hipMemcpyAsync(c->order.p, hb.order.data(), n_reads * 4, hipMemcpyHostToDevice, c->st));
+	}
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, 64, c->st));
+	HIPCHK(hipMemsetAsync(c->err.p, 0, 16, c->st));
+	c->stats.n_reads = n_reads; c->stats.n_bases = bases;
+	return 0;
+}
+
+int mm355_run_sketch(mm355_ctx *c)
+{
+	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c);
+	{ EvTimer t(c, &c->stats.ms_sketch); mm355_launch_sketch(c->dix, b, s, c->st); }
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
+{
+	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c);
+	HostBatch &hb = c->hb;
+	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_mzflt(pr, b, s, c->st); }
+	{ EvTimer t(c, &c->stats.ms_seed_lookup); mm355_launch_seed_lookup(c->dix, b, s, c->st); }
+	++c->stats.n_launch_seed;
+	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_seed_select(c->dix, pr, b, s, c->st); }
+	HIPCHK(hipGetLastError());
+	int64_t n = hb.n_reads;
+	hb.n_mz.resize(n); hb.n_a.resize(n); hb.rep_len.resize(n); hb.n_mini.resize(n); hb.aoff.resize(n + 1);
+	if (n) {
+		HIPCHK(hipMemcpyAsync(hb.n_mz.data(), c->n_mz.p, n * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(hb.n_a.data(), c->n_a.p, n * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(hb.rep_len.data(), c->rep_len.p, n * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(hb.n_mini.data(), c->n_mini.p, n * 4, hipMemcpyDeviceToHost, c->st));
+	}
+	unsigned long long ctr[8];
+	HIPCHK(hipMemcpyAsync(ctr, c->counters.p, 64, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	int64_t tot = 0, tmz = 0;
+	for (int64_t i = 0; i < n; ++i) { hb.aoff[i] = tot; tot += hb.n_a[i]; tmz += hb.n_mz[i]; }
+	hb.aoff[n] = tot; hb.tot_a = tot;
+	c->stats.n_mz += tmz; c->stats.n_hit += (int64_t)ctr[0]; c->stats.n_a_multi += (int64_t)ctr[1]; c->stats.n_a += tot;
+	size_t na = (size_t)tot + 64;
+	if (c->aoff.ensure((n + 1) * 8) || c->a.ensure(na * 16) || c->f.ensure(na * 4) || c->p.ensure(na * 4) || c->v.ensure(na * 4) ||
+	    c->z.ensure(na * 8) || c->t8.ensure(na) || c->vi.ensure(na * 4) || c->b.ensure(na * 16) || c->wk.ensure(na * 16) ||
+	    c->u.ensure(na * 8) || c->u2.ensure(na * 8)) return MM355_ENOMEM;
+	HIPCHK(hipMemcpyAsync(c->aoff.p, hb.aoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->st));
+	return 0;
+}
+
+int mm355_run_expand(mm355_ctx *c, const DevParams &pr)
+{
+	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c); DevAnchors a = dev_anchors(c);
+	{ EvTimer t(c, &c->stats.ms_seed_expand); mm355_launch_seed_expand(c->dix, pr, b, s, a, c->st); }
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+static int check_err(mm355_ctx *c)
+{
+	int e[4] = {0,0,0,0};
+	HIPCHK(hipMemcpyAsync(e, c->err.p, 16, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return e[0]? MM355_ENOMEM : 0;
+}
+
+int mm355_run_sort(mm355_ctx *c)
+{
+	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
+	{ EvTimer t(c, &c->stats.ms_sort); mm355_launch_sort(b, a, c->err.as<int>(), c->st); }
+	HIPCHK(hipGetLastError());
+	return check_err(c);
+}
+
+int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
+{
+	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
+	{ EvTimer t(c, &c->stats.ms_chain); mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + 3, c->st); }
+	HIPCHK(hipGetLastError());
+	unsigned long long pairs = 0;
+	HIPCHK(hipMemcpyAsync(&pairs, c->counters.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	c->stats.chain_pairs = (int64_t)pairs;
+	return 0;
+}
+
+int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
+{
+	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
+	HostBatch &hb = c->hb;
+	{ EvTimer t(c, &c->stats.ms_backtrack); mm355_launch_backtrack(pr, b, a, c->err.as<int>(), c->st); }
+	HIPCHK(hipGetLastError());
+	int64_t n = hb.n_reads;
+	hb.n_u.resize(n); hb.n_v.resize(n);
+	if (n) {
+		HIPCHK(hipMemcpyAsync(hb.n_u.data(), c->n_u.p, n * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(hb.n_v.data(), c->n_v.p, n * 4, hipMemcpyDeviceToHost, c->st));
+	}
+	return check_err(c);
+}
+
+// ------------------------------------------------------------------ per-stage C-ABI (tests + bench)
+static int stage_prologue(mm355_ctx *c, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs, const int32_t *lens, DevParams *pr)
+{
+	if (c == 0) return MM355_EINVAL;
+	if (mo) { int rc = mm355_check_opts(mo, c->mi); if (rc) return rc; *pr = mm355_make_params(mo, c->mi); }
+	memset(&c->stats, 0, sizeof(c->stats));
+	return mm355_run_pack(c, n_reads, seqs, lens);
+}
+
+extern "C" int mm355_stage_sketch(mm355_ctx_t *c, int64_t n_reads, const char *const *seqs, const int32_t *lens, int64_t *mz_off, uint64_t *mz, int64_t mz_cap)
+{
+	DevParams pr; int rc;
+	if ((rc = stage_prologue(c, 0, n_reads, seqs, lens, &pr))) return rc;
+	if ((rc = mm355_run_sketch(c))) return rc;
+	std::vector<int32_t> n_mz(n_reads);
+	if (n_reads) HIPCHK(hipMemcpyAsync(n_mz.data(), c->n_mz.p, n_reads * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	int64_t tot = 0;
+	for (int64_t i = 0; i < n_reads; ++i) { mz_off[i] = tot; tot += n_mz[i]; }
+	mz_off[n_reads] = tot;
+	if (tot > mz_cap) return MM355_ENOMEM;
+	for (int64_t i = 0; i < n_reads; ++i)
+		if (n_mz[i]) HIPCHK(hipMemcpyAsync(mz + mz_off[i] * 2, c->mz.as<mm128>() + c->hb.roff[i], (size_t)n_mz[i] * 16, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int mm355_stage_anchors(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs, const int32_t *lens, int sorted,
+                                   int64_t *a_off, uint64_t *a, int64_t a_cap, int32_t *rep_len, int32_t *n_mini_pos)
+{
+	DevParams pr; int rc;
+	if ((rc = stage_prologue(c, mo, n_reads, seqs, lens, &pr))) return rc;
+	if ((rc = mm355_run_sketch(c))) return rc;
+	if ((rc = mm355_run_seeds(c, pr))) return rc;
+	if ((rc = mm355_run_expand(c, pr))) return rc;
+	if (sorted && (rc = mm355_run_sort(c))) return rc;
+	HostBatch &hb = c->hb;
+	for (int64_t i = 0; i <= n_reads; ++i) a_off[i] = hb.aoff[i];
+	if (hb.tot_a > a_cap) return MM355_ENOMEM;
+	if (hb.tot_a) HIPCHK(hipMemcpyAsync(a, c->a.p, (size_t)hb.tot_a * 16, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	for (int64_t i = 0; i < n_reads; ++i) { if (rep_len) rep_len[i] = hb.rep_len[i]; if (n_mini_pos) n_mini_pos[i] = hb.n_mini[i]; }
+	return 0;
+}
+
+extern "C" int mm355_stage_chain(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs, const int32_t *lens,
+                                 int64_t *a_off, uint64_t *a, int32_t *f, int32_t *p, int32_t *v, int64_t a_cap)
+{
+	DevParams pr; int rc;
+	if ((rc = stage_prologue(c, mo, n_reads, seqs, lens, &pr))) return rc;
+	if ((rc = mm355_run_sketch(c))) return rc;
+	if ((rc = mm355_run_seeds(c, pr))) return rc;
+	if ((rc = mm355_run_expand(c, pr))) return rc;
+	if ((rc = mm355_run_sort(c))) return rc;
+	if ((rc = mm355_run_chain(c, pr))) return rc;
+	HostBatch &hb = c->hb;
+	for (int64_t i = 0; i <= n_reads; ++i) a_off[i] = hb.aoff[i];
+	if (hb.tot_a > a_cap) return MM355_ENOMEM;
+	if (hb.tot_a) {
+		HIPCHK(hipMemcpyAsync(a, c->a.p, (size_t)hb.tot_a * 16, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(f, c->f.p, (size_t)hb.tot_a * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(p, c->p.p, (size_t)hb.tot_a * 4, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipMemcpyAsync(v, c->v.p, (size_t)hb.tot_a * 4, hipMemcpyDeviceToHost, c->st));
+	}
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}
+
+extern "C" int mm355_stage_chains(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs, const int32_t *lens,
+                                  int64_t *u_off, uint64_t *u, int64_t u_cap, int64_t *a_off, uint64_t *a, int64_t a_cap)
+{
+	DevParams pr; int rc;
+	if ((rc = stage_prologue(c, mo, n_reads, seqs, lens, &pr))) return rc;
+	if ((rc = mm355_run_sketch(c))) return rc;
+	if ((rc = mm355_run_seeds(c, pr))) return rc;
+	if ((rc = mm355_run_expand(c, pr))) return rc;
+	if ((rc = mm355_run_sort(c))) return rc;
+	if ((rc = mm355_run_chain(c, pr))) return rc;
+	if ((rc = mm355_run_backtrack(c, pr))) return rc;
+	HostBatch &hb = c->hb;
+	int64_t tu = 0, tv = 0;
+	for (int64_t i = 0; i < n_reads; ++i) { u_off[i] = tu; a_off[i] = tv; tu += hb.n_u[i]; tv += hb.n_v[i]; }
+	u_off[n_reads] = tu; a_off[n_reads] = tv;
+	if (tu > u_cap || tv > a_cap) return MM355_ENOMEM;
+	for (int64_t i = 0; i < n_reads; ++i) {
+		if (hb.n_u[i]) HIPCHK(hipMemcpyAsync(u + u_off[i], c->u.as<uint64_t>() + hb.aoff[i], (size_t)hb.n_u[i] * 8, hipMemcpyDeviceToHost, c->st));
+		if (hb.n_v[i]) HIPCHK(hipMemcpyAsync(a + a_off[i] * 2, c->a.as<mm128>() + hb.aoff[i], (size_t)hb.n_v[i] * 16, hipMemcpyDeviceToHost, c->st));
+	}
+	HIPCHK(hipStreamSynchronize(c->st));
+	return 0;
+}

@@ -132,6 +132,11 @@ def lib():
                                     C.c_int8, C.c_int8, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Extz)]
         L.mmo_ksw_gen_simple_mat.argtypes = [C.c_int, C.c_void_p, C.c_int8, C.c_int8, C.c_int8]
         L.free.argtypes = [C.c_void_p]
+        L.malloc.restype = C.c_void_p
+        L.malloc.argtypes = [C.c_size_t]
+        L.mmo_lchain_dp.restype = C.c_void_p
+        L.mmo_lchain_dp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_int, C.c_int, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
         _LIB = L
     return _LIB
 
@@ -243,6 +248,29 @@ class OracleAligner:
             L.mmo_lchain_dp_fill(gap_ref, mo.max_gap, mo.bw, mo.max_chain_skip, mo.max_chain_iter, pen_gap, pen_skip,
                                  n, a.ctypes.data, f.ctypes.data, p.ctypes.data, v.ctypes.data, t.ctypes.data)
         return f, p, v, t
+
+    def chains(self, anchors, qlen):
+        """u[] and compacted anchors after mg_lchain_dp (fill + backtrack + compact_a)"""
+        L = lib()
+        n = anchors.shape[0]
+        if n == 0:
+            return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+        buf = L.malloc(n * 16)
+        C.memmove(buf, np.ascontiguousarray(anchors, dtype=np.uint64).ctypes.data, n * 16)
+        mo = self.mo
+        gap_ref = mo.max_gap_ref if mo.max_gap_ref > 0 else (max(mo.max_frag_len - qlen, mo.max_gap) if mo.max_frag_len > 0 else mo.max_gap)
+        pen_gap = np.float32(np.float64(mo.chain_gap_scale) * 0.01 * self.k)
+        pen_skip = np.float32(np.float64(mo.chain_skip_scale) * 0.01 * self.k)
+        n_u, u = C.c_int(), C.c_void_p()
+        b = L.mmo_lchain_dp(gap_ref, mo.max_gap, mo.bw, mo.max_chain_skip, mo.max_chain_iter, mo.min_cnt, mo.min_chain_score,
+                            pen_gap, pen_skip, 0, 1, n, buf, C.byref(n_u), C.byref(u))
+        if n_u.value == 0:
+            return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+        ua = np.ctypeslib.as_array(C.cast(u, C.POINTER(C.c_uint64)), shape=(n_u.value,)).copy()
+        nv = int((ua & np.uint64(0xffffffff)).sum())
+        aa = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint64)), shape=(nv, 2)).copy()
+        L.free(u); L.free(b)
+        return ua, aa
 
     def map(self, seq, cs=False, MD=False):
         L = lib()

@@ -1,0 +1,116 @@
+"""Kernel-by-kernel parity: HIP path (through the C-ABI of libmm355.so) vs the CPU oracle on the same
+seeded inputs.  Bit-exact (integer/index work): minimizers, anchor lists in generation order and after the
+literal radix_sort_128x emulation, chaining f/p/v, chains after backtrack+compact."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+import synthdata as S
+
+
+@pytest.fixture(scope="module")
+def world(built, tmp_path_factory):
+    import mappy_rs
+    td = tmp_path_factory.mktemp("gs")
+    g = S.make_genome(31, [400000, 250000], repeats=((4000, 6, 0.01), (900, 40, 0.02), (300, 120, 0.05)), n_runs=3)
+    fa = str(td / "ref.fa")
+    S.write_fasta(fa, g, ["chrA", "chrB"])
+    reads, truth = S.make_reads(32, g, 160, n50=5000, lo=200)
+    # edge cases: tiny reads, a read with Ns, a read made of a tandem repeat, an unrelated random read, a 1-base read
+    rng = np.random.default_rng(7)
+    unit = S.codes_to_str(g[0][1000:1037])
+    extra = ["ACGT", "A", reads[0][:14], reads[1][:600] + "NNNNNNNNNN" + reads[1][600:1500], unit * 60,
+             S.codes_to_str(S.random_codes(rng, 3000)), S.codes_to_str(g[1][5000:5400]), "N" * 50]
+    reads = reads + extra
+    al = mappy_rs.Aligner(fa, preset="map-ont")
+    orc = O.OracleAligner(fa, preset="map-ont")
+    sr = al._stage_runner()
+    yield dict(al=al, orc=orc, sr=sr, reads=reads, genome=g)
+    sr.close()
+
+
+def test_sketch_parity(world):
+    got = world["sr"].sketch(world["reads"])
+    for rd, g in zip(world["reads"], got):
+        exp = world["orc"].sketch(rd)
+        assert g.shape == exp.shape and np.array_equal(g, exp)
+
+
+def test_anchor_parity_generation_order(world):
+    got, rep, nmp = world["sr"].anchors(world["reads"], sorted_=False)
+    tot = 0
+    for i, rd in enumerate(world["reads"]):
+        exp, erep, emp, _ = world["orc"].anchors(rd, sorted_=False)
+        assert got[i].shape == exp.shape, (i, got[i].shape, exp.shape)
+        assert np.array_equal(got[i], exp), i
+        assert rep[i] == erep and nmp[i] == len(emp)
+        tot += len(exp)
+    assert tot > 10000
+
+
+def test_anchor_parity_sorted(world):
+    """same permutation as the unstable in-place radix sort, including equal-x ties"""
+    got, _, _ = world["sr"].anchors(world["reads"], sorted_=True)
+    n_ties = 0
+    for i, rd in enumerate(world["reads"]):
+        exp, _, _, _ = world["orc"].anchors(rd, sorted_=True)
+        assert np.array_equal(got[i], exp), i
+        if len(exp) > 1:
+            n_ties += int((exp[1:, 0] == exp[:-1, 0]).sum())
+    assert n_ties > 0, "test data must exercise equal-key ties"
+
+
+def test_chain_fill_parity(world):
+    got = world["sr"].chain(world["reads"])
+    for i, rd in enumerate(world["reads"]):
+        a, f, p, v = got[i]
+        ea, _, _, _ = world["orc"].anchors(rd, sorted_=True)
+        ef, ep, ev, _ = world["orc"].chain_fill(ea, len(rd))
+        assert np.array_equal(a, ea)
+        assert np.array_equal(f, ef), i
+        assert np.array_equal(p.astype(np.int64), ep), i
+        assert np.array_equal(v, ev), i
+
+
+def test_chains_parity(world):
+    got = world["sr"].chains(world["reads"])
+    n_multi = 0
+    for i, rd in enumerate(world["reads"]):
+        u, a = got[i]
+        ea, _, _, _ = world["orc"].anchors(rd, sorted_=True)
+        eu, eb = world["orc"].chains(ea, len(rd))
+        assert np.array_equal(u, eu), i
+        assert np.array_equal(a, eb), i
+        n_multi += len(eu) > 1
+    assert n_multi > 0
+
+
+def test_empty_and_ragged_batches(world):
+    sr = world["sr"]
+    assert sr.sketch([]) == []
+    got = sr.sketch(["", "ACGT", world["reads"][0]])
+    assert len(got[0]) == 0 and len(got[1]) == 0 and len(got[2]) > 0
+    ch = sr.chains(["", "ACGTACGTAC"])
+    assert len(ch[0][0]) == 0 and len(ch[1][0]) == 0
+
+
+def test_hifi_preset_parity(built, tmp_path):
+    import mappy_rs
+    g = S.make_genome(41, [300000], repeats=((2500, 5, 0.005),))
+    fa = str(tmp_path / "h.fa")
+    S.write_fasta(fa, g, ["chrH"])
+    reads, _ = S.make_reads(42, g, 24, n50=9000, lo=3000, sub=0.0005, ins=0.00075, dele=0.00075)
+    al = mappy_rs.Aligner(fa, preset="map-hifi")
+    orc = O.OracleAligner(fa, preset="map-hifi")
+    assert al.k == 19 and al.w == 19
+    sr = al._stage_runner()
+    got = sr.chains(reads)
+    for i, rd in enumerate(reads):
+        ea, _, _, _ = orc.anchors(rd, sorted_=True)
+        eu, eb = orc.chains(ea, len(rd))
+        assert np.array_equal(got[i][0], eu) and np.array_equal(got[i][1], eb)
+    sr.close()

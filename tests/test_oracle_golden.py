@@ -1,0 +1,151 @@
+"""Oracle vs the reference's own fixtures: CPU-only.
+
+G1  test.fa <-> test.mmi : mm_sketch + index key/value encoding + MMI\\2 format, bit-exact
+G2  map_one (R:src/lib.rs:1094-1106, R:tests/python_test.py:124-137) + the derived full record
+plus the reference's property tests (k, w, n_seq, seq_names, seq).
+"""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+ENTERO = ("AGAGCAGGTAGGATCGTTGAAAAAAGAGTACTCAGGATTCCATTCAACTTTTACTGATTTGAAGCGTAC"
+          "TGTTTATGGCCAAGAATATTTACGTCTTTACAACCAATACGCAAAAAAAGGTTCATTGAGTTTGGTTGT"
+          "GATTTGATGAAAATTACTGAGAATAACAGGATTATTAAGCTGATTGATGAACTAAATCAGCTTAATAAA"
+          "TATTCTTTGCAGATAGGAATATTTGGGGAAAATGATTCTTTTATGGCGATGTTGGCCCAAGTTCATGAA"
+          "TTTGGGGTGACTATTCGTCCCAAAGGTCGTTTTCTTGTTATACCACTTATGAAAAAGTATAGAGGTAAA"
+          "AGTCCACGTCAATTTGATTTGTTTTTTATGCAAACTAAAGAAAATCACAAGTTTT")
+BACILLUS = ("AGAGTGAAGCCAATATTCCGATAACGATTGCTTTCATGATATCCCTCATTCTGGCATTATTTTTTTATA"
+            "CTATACTATTCGATATCGCACAGATCAATGGAGTCGTGAGAAAATAAACATGTTTTGCGAACCGCTATG"
+            "TGTGGAAGACAAAAAATGGAGGTGAAATTGATGGAAGCAAAGACACAGGCGTACTTTTTTCAGGATGAT"
+            "GGCAGGATTCCGAATCACCCTGATTTTCCGCTCGTTGTGTATCAAAACGCACTCAAGGACACCGGTCAG"
+            "GCAGAGCGGATCGTCAACCGGCATGGCTGGTCAAACAGCTGGTCGGGGAGTGTTTTTCCATACCATCAT"
+            "TATCACAGCAATACGCATGAAGTCCTGATTGCAGTTCGGGGAGAGGCTGTGATTC")
+
+
+def parse_mmi(fn):
+    d = open(fn, "rb").read()
+    assert d[:4] == b"MMI\x02"
+    w, k, b, n, flag = struct.unpack("<5I", d[4:24])
+    o = 24
+    seqs = []
+    for _ in range(n):
+        l = d[o]; o += 1
+        nm = d[o:o + l]; o += l
+        ln, = struct.unpack("<I", d[o:o + 4]); o += 4
+        seqs.append((nm.decode(), ln))
+    ent = {}
+    for i in range(1 << b):
+        nn, = struct.unpack("<i", d[o:o + 4]); o += 4
+        p = struct.unpack("<%dQ" % nn, d[o:o + 8 * nn]); o += 8 * nn
+        sz, = struct.unpack("<I", d[o:o + 4]); o += 4
+        for _ in range(sz):
+            kk, vv = struct.unpack("<2Q", d[o:o + 16]); o += 16
+            minier = (kk >> 1) << b | i
+            ent[minier] = (vv,) if kk & 1 else tuple(p[(vv >> 32):(vv >> 32) + (vv & 0xffffffff)])
+    S = d[o:]
+    return dict(w=w, k=k, b=b, flag=flag, seqs=seqs, ent=ent, S=S)
+
+
+def read_fasta(fn):
+    out, name, buf = [], None, []
+    for line in open(fn):
+        if line.startswith(">"):
+            if name is not None: out.append((name, "".join(buf)))
+            name, buf = line[1:].split()[0], []
+        else:
+            buf.append(line.strip())
+    out.append((name, "".join(buf)))
+    return out
+
+
+@pytest.fixture(scope="module")
+def mmi(golden_dir):
+    return parse_mmi(os.path.join(golden_dir, "test.mmi"))
+
+
+@pytest.fixture(scope="module")
+def al(golden_dir):
+    return O.OracleAligner(os.path.join(golden_dir, "test.mmi"))
+
+
+def test_fixture_header(mmi):
+    assert (mmi["w"], mmi["k"], mmi["b"], mmi["flag"]) == (10, 15, 14, 0)
+    assert mmi["seqs"] == [("Bacillus_subtilis", 400), ("Enterococcus_faecalis", 400), ("Escherichia_coli_1", 400), ("Escherichia_coli_2", 400)]
+    assert len(mmi["ent"]) == 280 and all(len(v) == 1 for v in mmi["ent"].values())
+
+
+def test_sketch_reproduces_fixture(mmi, al, golden_dir):
+    """mm_sketch over test.fa with rid=0..3 yields exactly the 280 (minimizer -> y) entries of test.mmi"""
+    got = {}
+    per = []
+    for rid, (name, seq) in enumerate(read_fasta(os.path.join(golden_dir, "test.fa"))):
+        mz = al.sketch(seq, rid)
+        per.append(len(mz))
+        for x, y in mz:
+            assert int(x) & 0xff == 15
+            got.setdefault(int(x) >> 8, []).append(int(y))
+    assert per == [66, 75, 73, 66]
+    assert {k: tuple(sorted(v)) for k, v in got.items()} == mmi["ent"]
+
+
+def test_index_rebuild_is_identical(mmi, golden_dir, tmp_path):
+    b = O.OracleAligner(os.path.join(golden_dir, "test.fa"))
+    out = str(tmp_path / "rebuilt.mmi")
+    assert O.lib().mmo_idx_dump(b.idx, out.encode()) == 0
+    r = parse_mmi(out)
+    assert r["ent"] == mmi["ent"] and r["S"] == mmi["S"] and r["seqs"] == mmi["seqs"]
+    assert b.mo.mid_occ == 10
+
+
+def test_properties(al):
+    assert al.k == 15 and al.w == 10 and al.n_seq == 4
+    assert sorted(al.seq_names) == ["Bacillus_subtilis", "Enterococcus_faecalis", "Escherichia_coli_1", "Escherichia_coli_2"]
+    assert al.seq("Bacillus_subtilis") == BACILLUS
+    assert al.seq("Bacillus_subtilis", 10, 20) == BACILLUS[10:20]
+    assert al.seq("nope") is None and al.seq("Bacillus_subtilis", 400) is None
+    assert al.mo.mid_occ == 10
+
+
+def test_map_one(al):
+    hits = al.map(ENTERO, cs=True)
+    assert len(hits) == 1                                   # asserted by the reference
+    h = hits[0]
+    assert h["target_start"] == 0 and h["target_end"] == 400    # asserted by the reference
+    # derived full record
+    assert (h["query_start"], h["query_end"], h["strand"], h["target_name"], h["target_len"]) == (0, 400, 1, "Enterococcus_faecalis", 400)
+    assert (h["match_len"], h["block_len"], h["NM"], h["mapq"], h["is_primary"]) == (400, 400, 0, 60, True)
+    assert h["cigar"] == [(400, 0)] and h["cs"] == ":400" and h["MD"] is None
+    assert h["score0"] == 393 and h["cnt"] == 75 and h["dp_max"] == 800
+
+
+def test_map_all_contigs_and_revcomp(al, golden_dir):
+    comp = str.maketrans("ACGT", "TGCA")
+    for name, seq in read_fasta(os.path.join(golden_dir, "test.fa")):
+        h = al.map(seq, cs=True, MD=True)
+        assert len(h) == 1 and h[0]["target_name"] == name and h[0]["cigar_str"] == "400M" and h[0]["strand"] == 1 and h[0]["MD"] == "400"
+        h = al.map(seq.translate(comp)[::-1])
+        assert len(h) == 1 and h[0]["strand"] == -1 and (h[0]["target_start"], h[0]["target_end"]) == (0, 400)
+
+
+def test_errors(al):
+    with pytest.raises(RuntimeError, match="Sequence is empty"):
+        al.map("")
+    assert al.map("ACGT") == []
+
+
+def test_region_hash_salt():
+    """salt for qlen=400, seed=11, qname=NULL is 0x734db24f"""
+    def wang(k):
+        k &= 0xffffffff
+        k = (k + (~(k << 15) & 0xffffffff)) & 0xffffffff
+        k ^= k >> 10
+        k = (k + (k << 3)) & 0xffffffff
+        k ^= k >> 6
+        k = (k + (~(k << 11) & 0xffffffff)) & 0xffffffff
+        k ^= k >> 16
+        return k
+    assert wang((wang(400) + wang(11)) & 0xffffffff) == 0x734db24f
