@@ -1,0 +1,33 @@
+// mm355_dp.h -- descriptors of the banded-extension stage (host <-> mm355_dp.hip)
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "mm355_pipeline.h"
+
+struct DpConst {            // scoring constants after ksw_extd2_sse's (q,e)/(q2,e2) ordering
+	int32_t q, e, q2, e2, qe_preswap;
+	int8_t sc_mch, sc_mis, sc_N;
+	int32_t long_thres, long_diff, valid;
+};
+
+struct DpJobDev {
+	int32_t qlen, tlen;
+	int64_t qoff, toff;      // into the device code buffers
+	int32_t w, zdrop, end_bonus, flag;
+	int32_t skip, pad;
+	int64_t p_off, off_off, cig_off, st_off;
+};
+
+struct DpGather {           // where the code strings of a job come from
+	int32_t qlen, tlen;
+	int64_t qoff, toff;      // destination offsets
+	int64_t q_src;           // offset into the per-read code buffer (already strand-adjusted)
+	uint32_t rid; int32_t t_st;
+	int32_t rev, pad;
+};
+
+DpConst mm355_dp_const(const mm355_mapopt_t *mo);
+int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
+                 std::vector<mm355_dpres_t> &res, std::vector<uint32_t> &cigar);
+int mm355_dp_gather(mm355_ctx *c, const std::vector<DpGather> &g, size_t q_tot, size_t t_tot);
+int mm355_run_read_codes(mm355_ctx *c);

@@ -1,4 +1,466 @@
+// mm355_dp.hip -- banded gap-affine extension on gfx950: row a12 of SURVEY.md section 8(a).
+//
+// Reproduces minimap2 2.26's U:ksw2_extd2_sse.c::ksw_extd2_sse (two-piece affine, the kernel map-ont and
+// map-hifi execute; reached from /root/reference/src/lib.rs:482 and :587 via mm_map -> mm_align_skeleton ->
+// mm_align_pair) including U:ksw2.h::ksw_backtrack / ksw_apply_zdrop, bit for bit:
+//   * anti-diagonal sweep in the Suzuki-Kasahara difference form, int8 wrap-around arithmetic;
+//   * the SIMD kernel's cell set: whole 16-lane blocks [st/16*16, (en+16)/16*16-1] per diagonal, i.e. cells outside
+//     the band are evaluated on stale inputs and can feed in-band cells at the band edge -- the same cells are
+//     evaluated here, on the same stale values, so band-edge results agree;
+//   * the SSE4.1 4-lane strided H-max (tie order), exact and approximate (KSW_EZ_APPROX_MAX) score tracking,
+//     z-drop, and the 1-byte/cell direction matrix that ksw_backtrack walks.
+// One wave = one alignment; lane = target position t inside a 64-cell chunk of the diagonal; the per-t state
+// (u,v,x,y,x2,y2,s packed in 8 bytes, plus int32 H) lives in LDS when the target fits, else in an HBM work area.
+// x[t-1]/v[t-1] of the previous diagonal arrive by a one-lane wave shuffle.  No MFMA: this is an int8 recurrence.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
 #include "mm355_pipeline.h"
-extern "C" int mm355_stage_dp(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_jobs, const mm355_dpjob_t *jobs,
-                   const uint8_t *qcodes, int64_t n_q, const uint8_t *tcodes, int64_t n_t,
-                   mm355_dpres_t *res, uint32_t *cigar, int64_t cigar_cap) { return MM355_EUNSUP; }
+#include "mm355_dp.h"
+
+#define WAVE 64
+#define KSW_NEG_INF (-0x40000000)
+#define EZ_SCORE_ONLY  0x01
+#define EZ_RIGHT       0x02
+#define EZ_APPROX_MAX  0x08
+#define EZ_APPROX_DROP 0x10
+#define EZ_EXTZ_ONLY   0x40
+#define EZ_REV_CIGAR   0x80
+
+struct EzState { int32_t max, max_q, max_t, mqe, mqe_t, mte, mte_q, score, zdropped, reach_end; };
+
+__device__ inline int8_t I8(int v) { return (int8_t)v; }
+
+__device__ inline bool apply_zdrop(EzState &ez, int32_t H, int r, int t, int zdrop, int e2)
+{
+	if (H > ez.max) {
+		ez.max = H, ez.max_t = t, ez.max_q = r - t;
+	} else if (t >= ez.max_t && r - t >= ez.max_q) {
+		int tl = t - ez.max_t, ql = (r - t) - ez.max_q, l;
+		l = tl > ql? tl - ql : ql - tl;
+		if (zdrop >= 0 && ez.max - H > zdrop + l * e2) { ez.zdropped = 1; return true; }
+	}
+	return false;
+}
+
+__device__ inline uint32_t *push_cigar(uint32_t *cigar, int &n, uint32_t op, int len)
+{
+	if (n == 0 || op != (cigar[n - 1] & 0xf)) cigar[n++] = (uint32_t)len << 4 | op;
+	else cigar[n - 1] += (uint32_t)len << 4;
+	return cigar;
+}
+
+// state word: byte0 u, 1 v, 2 x, 3 y, 4 x2, 5 y2, 6 s
+__device__ inline int8_t SB(uint64_t w, int i) { return (int8_t)(w >> (8 * i)); }
+
+__global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+                                                    const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, int32_t *offbase,
+                                                    uint32_t *cigbase, uint64_t *stbase, int32_t *Hbase, mm355_dpres_t *res,
+                                                    int lds_cap, unsigned long long *cells_ctr)
+{
+	extern __shared__ uint64_t lds[];   // [lds_cap] state words, then [lds_cap] int32 H
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_jobs) return;
+	const int jid = job_ids[blockIdx.x];
+	const DpJobDev jb = jobs[jid];
+	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop, end_bonus = jb.end_bonus;
+	EzState ez;
+	ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
+	ez.max = 0; ez.score = ez.mqe = ez.mte = KSW_NEG_INF; ez.zdropped = 0; ez.reach_end = 0;
+	int n_cigar = 0;
+	uint32_t *cigar = cigbase + jb.cig_off;
+	if (qlen <= 0 || tlen <= 0 || jb.skip) {   // skip: tlen*qlen > max_sw_mat => treated as z-dropped by mm_align_pair
+		if (lane == 0) {
+			mm355_dpres_t o; o.max = 0; o.zdropped = jb.skip? 1 : 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1;
+			o.mqe = o.mte = o.score = KSW_NEG_INF; o.reach_end = 0; o.n_cigar = 0; o.cigar_off = jb.cig_off;
+			res[jid] = o;
+		}
+		return;
+	}
+	const uint8_t *query = qbase + jb.qoff, *target = tbase + jb.toff;
+	const int q = dc.q, e = dc.e, q2 = dc.q2, e2 = dc.e2, qe = dc.qe_preswap;
+	const int8_t qe8 = I8(q + e), qe28 = I8(q2 + e2), sc_mch = dc.sc_mch, sc_mis = dc.sc_mis, sc_N = dc.sc_N;
+	const int long_thres = dc.long_thres, long_diff = dc.long_diff;
+	const bool approx_max = flag & EZ_APPROX_MAX, right = flag & EZ_RIGHT;
+	int w = jb.w;
+	if (w < 0) w = tlen > qlen? tlen : qlen;
+	const int tlen_ = (tlen + 15) / 16, T = tlen_ * 16;
+	int n_col_ = qlen < tlen? qlen : tlen;
+	n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
+	const int n_col = n_col_ * 16;
+	uint64_t *S; int32_t *H;
+	if (T <= lds_cap) { S = lds; H = (int32_t*)(lds + lds_cap); }
+	else { S = stbase + jb.st_off; H = Hbase + jb.st_off; }
+	uint8_t *p = pbase + jb.p_off;
+	int32_t *off = offbase + jb.off_off, *off_end = off + (qlen + tlen - 1);
+	{   // memset(u,v,x,y = -q-e; x2,y2 = -q2-e2); s = 0; H = NEG_INF
+		const uint8_t a = (uint8_t)I8(-q - e), b = (uint8_t)I8(-q2 - e2);
+		const uint64_t init = (uint64_t)a | (uint64_t)a << 8 | (uint64_t)a << 16 | (uint64_t)a << 24 | (uint64_t)b << 32 | (uint64_t)b << 40;
+		for (int t = lane; t < T; t += WAVE) { S[t] = init; if (!approx_max) H[t] = KSW_NEG_INF; }
+	}
+	__syncthreads();
+	int last_st = -1, last_en = -1;
+	int32_t H0 = 0, last_H0_t = 0;
+	unsigned long long cells = 0;
+	for (int r = 0; r < qlen + tlen - 1; ++r) {
+		int st = 0, en = tlen - 1, st0, en0;
+		if (st < r - qlen + 1) st = r - qlen + 1;
+		if (en > r) en = r;
+		if (st < (r - w + 1) >> 1) st = (r - w + 1) >> 1;
+		if (en > (r + w) >> 1) en = (r + w) >> 1;
+		if (st > en) { ez.zdropped = 1; break; }
+		st0 = st, en0 = en;
+		st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;
+		int8_t x1, x21, v1;
+		if (st > 0) {
+			if (st - 1 >= last_st && st - 1 <= last_en) {
+				const uint64_t wv = S[st - 1];
+				x1 = SB(wv, 2), x21 = SB(wv, 4), v1 = SB(wv, 1);
+			} else { x1 = I8(-q - e), x21 = I8(-q2 - e2); v1 = I8(-q - e); }
+		} else {
+			x1 = I8(-q - e), x21 = I8(-q2 - e2);
+			v1 = r == 0? I8(-q - e) : r < long_thres? I8(-e) : r == long_thres? I8(long_diff) : I8(-e2);
+		}
+		const bool edge = en >= r;
+		const int8_t edge_u = r == 0? I8(-q - e) : r < long_thres? I8(-e) : r == long_thres? I8(long_diff) : I8(-e2);
+		const int sc_end = st0 + ((en0 - st0) / 16 + 1) * 16;   // scores are (re)written for t in [st0, sc_end)
+		int8_t cx = x1, cv = v1, cx2 = x21;
+		uint8_t *pr = p + (size_t)r * n_col - st;
+		if (lane == 0) { off[r] = st; off_end[r] = en; }
+		for (int c0 = st; c0 <= en; c0 += WAVE) {
+			const int t = c0 + lane;
+			const bool act = t <= en;
+			uint64_t old = act? S[t] : 0;
+			int8_t ou = SB(old, 0), ov = SB(old, 1), ox = SB(old, 2), oy = SB(old, 3), ox2 = SB(old, 4), oy2 = SB(old, 5), os = SB(old, 6);
+			if (edge && t == r) { oy = I8(-q - e); oy2 = I8(-q2 - e2); ou = edge_u; }
+			// x[t-1], v[t-1], x2[t-1] of the previous diagonal: neighbour lane, or the carry from the previous chunk
+			int pk = (uint8_t)ox | (uint8_t)ov << 8 | (uint8_t)ox2 << 16;
+			int nb = __shfl_up(pk, 1);
+			int8_t xt1 = (int8_t)nb, vt1 = (int8_t)(nb >> 8), x2t1 = (int8_t)(nb >> 16);
+			if (lane == 0) { xt1 = cx; vt1 = cv; x2t1 = cx2; }
+			int last = __shfl(pk, 63);
+			cx = (int8_t)last; cv = (int8_t)(last >> 8); cx2 = (int8_t)(last >> 16);
+			int8_t z;
+			if (t >= st0 && t < sc_end) {
+				const uint8_t sq = t < tlen? target[t] : 0;
+				const int qi = r - t;
+				const uint8_t sqq = qi >= 0? query[qi] : 0;   // qr[] is zero beyond the query
+				z = sq == sqq? sc_mch : sc_mis;
+				if (sq == 4 || sqq == 4) z = sc_N;
+			} else z = os;
+			const int8_t sc = z;
+			int8_t a = I8(xt1 + vt1), b = I8(oy + ou), a2 = I8(x2t1 + vt1), b2 = I8(oy2 + ou);
+			uint8_t d;
+			int8_t nx, ny, nx2, ny2, tmp;
+			if (!right) {
+				d = a > z? 1 : 0;   z = z > a? z : a;
+				d = b > z? 2 : d;   z = z > b? z : b;
+				d = a2 > z? 3 : d;  z = z > a2? z : a2;
+				d = b2 > z? 4 : d;  z = z > b2? z : b2;
+				z = z < sc_mch? z : sc_mch;
+				tmp = I8(z - q);  a = I8(a - tmp);  b = I8(b - tmp);
+				tmp = I8(z - q2); a2 = I8(a2 - tmp); b2 = I8(b2 - tmp);
+				nx  = I8((a  > 0? a  : 0) - qe8);  if (a  > 0) d |= 0x08;
+				ny  = I8((b  > 0? b  : 0) - qe8);  if (b  > 0) d |= 0x10;
+				nx2 = I8((a2 > 0? a2 : 0) - qe28); if (a2 > 0) d |= 0x20;
+				ny2 = I8((b2 > 0? b2 : 0) - qe28); if (b2 > 0) d |= 0x40;
+			} else {
+				d = z > a? 0 : 1;   z = z > a? z : a;
+				d = z > b? d : 2;   z = z > b? z : b;
+				d = z > a2? d : 3;  z = z > a2? z : a2;
+				d = z > b2? d : 4;  z = z > b2? z : b2;
+				z = z < sc_mch? z : sc_mch;
+				tmp = I8(z - q);  a = I8(a - tmp);  b = I8(b - tmp);
+				tmp = I8(z - q2); a2 = I8(a2 - tmp); b2 = I8(b2 - tmp);
+				nx  = I8((0 > a?  0 : a)  - qe8);  if (!(0 > a))  d |= 0x08;
+				ny  = I8((0 > b?  0 : b)  - qe8);  if (!(0 > b))  d |= 0x10;
+				nx2 = I8((0 > a2? 0 : a2) - qe28); if (!(0 > a2)) d |= 0x20;
+				ny2 = I8((0 > b2? 0 : b2) - qe28); if (!(0 > b2)) d |= 0x40;
+			}
+			const int8_t nu = I8(z - vt1), nv = I8(z - ou);
+			if (act) {
+				S[t] = (uint64_t)(uint8_t)nu | (uint64_t)(uint8_t)nv << 8 | (uint64_t)(uint8_t)nx << 16 | (uint64_t)(uint8_t)ny << 24 |
+				       (uint64_t)(uint8_t)nx2 << 32 | (uint64_t)(uint8_t)ny2 << 40 | (uint64_t)(uint8_t)sc << 48;
+				pr[t] = d;
+			}
+		}
+		{   // the last unaligned 16-byte score store may reach past `en`: those s[] bytes persist for later diagonals
+			const int t = en + 1 + lane;
+			if (t < sc_end && t < T) {
+				const uint8_t sq = t < tlen? target[t] : 0;
+				const int qi = r - t;
+				const uint8_t sqq = (qi >= 0 && qi < qlen)? query[qi] : 0;
+				int8_t z = sq == sqq? sc_mch : sc_mis;
+				if (sq == 4 || sqq == 4) z = sc_N;
+				S[t] = (S[t] & ~(0xffULL << 48)) | (uint64_t)(uint8_t)z << 48;
+			}
+		}
+		cells += (unsigned long long)(en0 - st0 + 1);
+		__syncthreads();
+		if (!approx_max) {
+			int32_t max_H, max_t;
+			if (r > 0) {
+				const int en1 = st0 + (en0 - st0) / 4 * 4;
+				int32_t hen = en0 > 0? H[en0 - 1] + SB(S[en0], 0) : H[en0] + SB(S[en0], 1);
+				__syncthreads();
+				max_H = hen; max_t = en0;
+				// 4-lane strided maxima over [st0,en1): class = (t - st0) & 3, strict > keeps the first t of a class
+				int32_t bh = INT32_MIN, bt = 0x7fffffff;
+				for (int t = st0 + lane; t < en1; t += WAVE) {
+					int32_t h = H[t] + (int32_t)SB(S[t], 1);
+					H[t] = h;
+					if (h > bh) bh = h, bt = t;
+				}
+				for (int o = 4; o < 64; o <<= 1) {   // reduce lanes of the same class (lane & 3): max, tie -> smaller t
+					int32_t oh = __shfl_xor(bh, o), ot = __shfl_xor(bt, o);
+					if (oh > bh || (oh == bh && ot < bt)) bh = oh, bt = ot;
+				}
+				for (int i = 0; i < 4; ++i) {        // HH[i] starts at H[en0]; combine in class order with strict <
+					int32_t hh = __shfl(bh, i), tt = __shfl(bt, i);
+					if (hh > hen) { if (max_H < hh) max_H = hh, max_t = tt; }
+				}
+				if (lane == 0) H[en0] = hen;
+				for (int t = en1; t < en0; ++t) {    // scalar tail (at most 3 cells), strict >
+					int32_t h = H[t] + (int32_t)SB(S[t], 1);
+					__syncthreads();
+					if (lane == 0) H[t] = h;
+					if (h > max_H) max_H = h, max_t = t;
+				}
+				__syncthreads();
+			} else {
+				int32_t h0 = (int32_t)SB(S[0], 1) - qe;
+				if (lane == 0) H[0] = h0;
+				max_H = h0; max_t = 0;
+				__syncthreads();
+			}
+			const int32_t Hen0 = H[en0], Hst0 = H[st0];
+			if (en0 == tlen - 1 && Hen0 > ez.mte) ez.mte = Hen0, ez.mte_q = r - en;
+			if (r - st0 == qlen - 1 && Hst0 > ez.mqe) ez.mqe = Hst0, ez.mqe_t = st0;
+			if (apply_zdrop(ez, max_H, r, max_t, zdrop, e2)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H[tlen - 1];
+		} else {
+			if (r > 0) {
+				if (last_H0_t >= st0 && last_H0_t <= en0 && last_H0_t + 1 >= st0 && last_H0_t + 1 <= en0) {
+					int32_t d0 = SB(S[last_H0_t], 1);
+					int32_t d1 = SB(S[last_H0_t + 1], 0);
+					if (d0 > d1) H0 += d0;
+					else H0 += d1, ++last_H0_t;
+				} else if (last_H0_t >= st0 && last_H0_t <= en0) {
+					H0 += SB(S[last_H0_t], 1);
+				} else {
+					++last_H0_t, H0 += SB(S[last_H0_t], 0);
+				}
+			} else H0 = (int32_t)SB(S[0], 1) - qe, last_H0_t = 0;
+			if ((flag & EZ_APPROX_DROP) && apply_zdrop(ez, H0, r, last_H0_t, zdrop, e2)) break;
+			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
+		}
+		last_st = st, last_en = en;
+		__syncthreads();
+	}
+	__syncthreads();
+	// backtrack (U:ksw2.h::ksw_backtrack, is_rot=1): one lane walks the direction matrix
+	if (lane == 0) {
+		int i0 = -1, j0 = -1;
+		const bool rev_cigar = flag & EZ_REV_CIGAR;
+		if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) { i0 = tlen - 1; j0 = qlen - 1; }
+		else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) { ez.reach_end = 1; i0 = ez.mqe_t; j0 = qlen - 1; }
+		else if (ez.max_t >= 0 && ez.max_q >= 0) { i0 = ez.max_t; j0 = ez.max_q; }
+		if (i0 >= 0 || j0 >= 0) {
+			int i = i0, j = j0, state = 0;
+			while (i >= 0 && j >= 0) {
+				int force_state = -1, rr = i + j;
+				uint32_t tmp;
+				if (i < off[rr]) force_state = 2;
+				if (i > off_end[rr]) force_state = 1;
+				tmp = force_state < 0? p[(size_t)rr * n_col + i - off[rr]] : 0;
+				if (state == 0) state = tmp & 7;
+				else if (!(tmp >> (state + 2) & 1)) state = 0;
+				if (state == 0) state = tmp & 7;
+				if (force_state >= 0) state = force_state;
+				if (state == 0) push_cigar(cigar, n_cigar, 0, 1), --i, --j;
+				else if (state == 1 || state == 3) push_cigar(cigar, n_cigar, 2, 1), --i;
+				else push_cigar(cigar, n_cigar, 1, 1), --j;
+			}
+			if (i >= 0) push_cigar(cigar, n_cigar, 2, i + 1);
+			if (j >= 0) push_cigar(cigar, n_cigar, 1, j + 1);
+			if (!rev_cigar)
+				for (i = 0; i < n_cigar >> 1; ++i) { uint32_t t2 = cigar[i]; cigar[i] = cigar[n_cigar - 1 - i]; cigar[n_cigar - 1 - i] = t2; }
+		}
+		mm355_dpres_t o;
+		o.max = ez.max; o.zdropped = ez.zdropped; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe = ez.mqe; o.mqe_t = ez.mqe_t;
+		o.mte = ez.mte; o.mte_q = ez.mte_q; o.score = ez.score; o.reach_end = ez.reach_end; o.n_cigar = n_cigar; o.cigar_off = jb.cig_off;
+		res[jid] = o;
+		if (cells) atomicAdd(cells_ctr, cells);
+	}
+}
+
+// gather kernel: materialise query / target code strings of each job (optionally reversed) from the read batch and
+// the 4-bit packed reference (U:index.c::mm_idx_getseq semantics)
+__global__ __launch_bounds__(256) void k_dp_gather(DevIndex ix, const DpGather *g, int n_jobs, const uint8_t *rq, uint8_t *qbuf, uint8_t *tbuf)
+{
+	const int j = blockIdx.x;
+	if (j >= n_jobs) return;
+	const DpGather gj = g[j];
+	for (int i = threadIdx.x; i < gj.qlen; i += 256) {
+		const int src = gj.rev? gj.qlen - 1 - i : i;
+		qbuf[gj.qoff + i] = rq[gj.q_src + src];
+	}
+	const uint64_t base = ix.seq_off[gj.rid] + (uint64_t)gj.t_st;
+	for (int i = threadIdx.x; i < gj.tlen; i += 256) {
+		const int src = gj.rev? gj.tlen - 1 - i : i;
+		const uint64_t o = base + (uint64_t)src;
+		tbuf[gj.toff + i] = (uint8_t)(ix.S[o >> 3] >> ((o & 7) << 2) & 0xf);
+	}
+}
+
+// per-read query codes: [0,len) forward codes, [len,2len) reverse-complement codes (U:align.c::mm_align_skeleton)
+__global__ __launch_bounds__(256) void k_read_codes(DevBatch bt, uint8_t *rq)
+{
+	const int r = blockIdx.x;
+	const int len = bt.rlen[r];
+	const int64_t off = bt.roff[r];
+	for (int i = threadIdx.x; i < len; i += 256) {
+		const int c = mm_nt4(bt.seq[off + i]);
+		rq[2 * off + i] = (uint8_t)c;
+		rq[2 * off + len + (len - 1 - i)] = (uint8_t)(c < 4? 3 - c : 4);
+	}
+}
+
+// ------------------------------------------------------------------ host driver
+DpConst mm355_dp_const(const mm355_mapopt_t *mo)
+{
+	DpConst c;
+	int q = mo->q, e = mo->e, q2 = mo->q2, e2 = mo->e2, t;
+	int a = mo->a < 0? -mo->a : mo->a, b = mo->b > 0? -mo->b : mo->b, amb = mo->sc_ambi > 0? -mo->sc_ambi : mo->sc_ambi;
+	c.qe_preswap = (int8_t)q + (int8_t)e;
+	if (q2 + e2 < q + e) t = q, q = q2, q2 = t, t = e, e = e2, e2 = t;
+	c.q = q; c.e = e; c.q2 = q2; c.e2 = e2;
+	c.sc_mch = (int8_t)a; c.sc_mis = (int8_t)b; c.sc_N = amb == 0? (int8_t)(-e2) : (int8_t)amb;
+	c.long_thres = e != e2? (q2 - q) / (e - e2) - 1 : 0;
+	if (q2 + e2 + c.long_thres * e2 > q + e + c.long_thres * e) ++c.long_thres;
+	c.long_diff = c.long_thres * (e - e2) - (q2 - q) - e2;
+	int min_sc = b < amb? b : amb;
+	c.valid = !(-min_sc > 2 * (q + e));
+	return c;
+}
+
+#define DP_LDS_SMALL 1024
+#define DP_LDS_MED   4096
+
+// runs jobs whose code strings are already on the device (qbuf/tbuf); fills res[] and the cigar arena (host copies)
+int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
+                 std::vector<mm355_dpres_t> &res, std::vector<uint32_t> &cigar)
+{
+	const size_t n = jobs.size();
+	res.resize(n);
+	if (n == 0) { cigar.clear(); return 0; }
+	DpConst dc = mm355_dp_const(mo);
+	// lay out per-job work areas
+	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
+	std::vector<int32_t> ids[3];
+	for (size_t i = 0; i < n; ++i) {
+		DpJobDev &j = jobs[i];
+		j.skip = (mo->max_sw_mat > 0 && (int64_t)j.tlen * j.qlen > mo->max_sw_mat) || !dc.valid;
+		int w = j.w < 0? std::max(j.qlen, j.tlen) : j.w;
+		int n_col_ = std::min(j.qlen, j.tlen);
+		n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
+		int T = (j.tlen + 15) / 16 * 16;
+		j.p_off = (int64_t)p_tot; j.off_off = (int64_t)off_tot; j.cig_off = (int64_t)cig_tot; j.st_off = 0;
+		if (j.qlen > 0 && j.tlen > 0 && !j.skip) {
+			p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
+			off_tot += (size_t)(j.qlen + j.tlen - 1) * 2;
+			cig_tot += (size_t)j.qlen + j.tlen + 2;
+			int cls = T <= DP_LDS_SMALL? 0 : T <= DP_LDS_MED? 1 : 2;
+			if (cls == 2) { j.st_off = (int64_t)st_tot; st_tot += T; }
+			ids[cls].push_back((int32_t)i);
+		} else ids[0].push_back((int32_t)i);
+	}
+	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64) ||
+	    c->dp_work.ensure((off_tot + 16) * 4 + (n + 16) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_H.ensure((st_tot + 16) * 12)) return MM355_ENOMEM;
+	HIPCHK(hipMemcpyAsync(c->dp_jobs.p, jobs.data(), n * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
+	int32_t *d_off = c->dp_work.as<int32_t>();
+	int32_t *d_ids = d_off + off_tot + 16;
+	uint64_t *d_S = c->dp_H.as<uint64_t>();
+	int32_t *d_H = (int32_t*)(d_S + st_tot + 8);
+	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4;
+	{
+		EvTimer2 tm(c, &c->stats.ms_dp);
+		size_t done = 0;
+		for (int cls = 0; cls < 3; ++cls) {
+			if (ids[cls].empty()) continue;
+			HIPCHK(hipMemcpyAsync(d_ids + done, ids[cls].data(), ids[cls].size() * 4, hipMemcpyHostToDevice, c->st));
+			int cap = cls == 0? DP_LDS_SMALL : cls == 1? DP_LDS_MED : 0;
+			size_t lds = (size_t)cap * 12;
+			hipLaunchKernelGGL(k_ksw_extd2, dim3((unsigned)ids[cls].size()), dim3(WAVE), lds, c->st, dc, c->dp_jobs.as<DpJobDev>(), d_ids + done,
+			                   (int)ids[cls].size(), d_q, d_t, c->dp_bt.as<uint8_t>(), d_off, c->dp_cig.as<uint32_t>(), d_S, d_H,
+			                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells);
+			done += ids[cls].size();
+		}
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(res.data(), c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
+	cigar.resize(cig_tot + 1);
+	if (cig_tot) HIPCHK(hipMemcpyAsync(cigar.data(), c->dp_cig.p, cig_tot * 4, hipMemcpyDeviceToHost, c->st));
+	unsigned long long cells = 0;
+	HIPCHK(hipMemcpyAsync(&cells, d_cells, 8, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	c->stats.dp_cells = (int64_t)cells; c->stats.n_dp_jobs += (int64_t)n;
+	return 0;
+}
+
+int mm355_dp_gather(mm355_ctx *c, const std::vector<DpGather> &g, size_t q_tot, size_t t_tot)
+{
+	if (g.empty()) return 0;
+	if (c->dp_q.ensure(q_tot + 64) || c->dp_t.ensure(t_tot + 64) || c->dp_jobs.ensure(g.size() * sizeof(DpGather))) return MM355_ENOMEM;
+	// reuse dp_res as the staging area for the gather descriptors
+	if (c->dp_res.ensure(g.size() * sizeof(DpGather))) return MM355_ENOMEM;
+	HIPCHK(hipMemcpyAsync(c->dp_res.p, g.data(), g.size() * sizeof(DpGather), hipMemcpyHostToDevice, c->st));
+	hipLaunchKernelGGL(k_dp_gather, dim3((unsigned)g.size()), dim3(256), 0, c->st, c->dix, c->dp_res.as<DpGather>(), (int)g.size(),
+	                   c->rq.as<uint8_t>(), c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>());
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(c->st));   // dp_res is reused by mm355_dp_run
+	return 0;
+}
+
+int mm355_run_read_codes(mm355_ctx *c)
+{
+	if (c->hb.n_reads == 0) return 0;
+	if (c->rq.ensure((size_t)c->hb.n_bytes * 2 + 64)) return MM355_ENOMEM;
+	DevBatch b; b.n_reads = (int32_t)c->hb.n_reads; b.seq = c->seq.as<uint8_t>(); b.roff = c->roff.as<int64_t>(); b.rlen = c->rlen.as<int32_t>(); b.order = c->order.as<int32_t>();
+	hipLaunchKernelGGL(k_read_codes, dim3((unsigned)c->hb.n_reads), dim3(256), 0, c->st, b, c->rq.as<uint8_t>());
+	HIPCHK(hipGetLastError());
+	return 0;
+}
+
+// C-ABI: one batch of extension problems on caller-provided code strings (parity tests, kernel bench)
+extern "C" int mm355_stage_dp(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t n_jobs, const mm355_dpjob_t *jobs,
+                              const uint8_t *qcodes, int64_t n_q, const uint8_t *tcodes, int64_t n_t,
+                              mm355_dpres_t *res, uint32_t *cigar, int64_t cigar_cap)
+{
+	if (c == 0 || mo == 0) return MM355_EINVAL;
+	HIPCHK(hipSetDevice(c->dev));
+	memset(&c->stats, 0, sizeof(c->stats));
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, 64, c->st));
+	if (c->dp_q.ensure((size_t)n_q + 64) || c->dp_t.ensure((size_t)n_t + 64)) return MM355_ENOMEM;
+	if (n_q) HIPCHK(hipMemcpyAsync(c->dp_q.p, qcodes, n_q, hipMemcpyHostToDevice, c->st));
+	if (n_t) HIPCHK(hipMemcpyAsync(c->dp_t.p, tcodes, n_t, hipMemcpyHostToDevice, c->st));
+	std::vector<DpJobDev> dj(n_jobs);
+	for (int64_t i = 0; i < n_jobs; ++i) {
+		memset(&dj[i], 0, sizeof(DpJobDev));
+		dj[i].qlen = jobs[i].qlen; dj[i].tlen = jobs[i].tlen; dj[i].qoff = jobs[i].qoff; dj[i].toff = jobs[i].toff;
+		dj[i].w = jobs[i].w; dj[i].zdrop = jobs[i].zdrop; dj[i].end_bonus = jobs[i].end_bonus; dj[i].flag = jobs[i].flag;
+	}
+	std::vector<mm355_dpres_t> r; std::vector<uint32_t> cg;
+	int rc = mm355_dp_run(c, mo, dj, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), r, cg);
+	if (rc) return rc;
+	int64_t tot = 0;
+	for (int64_t i = 0; i < n_jobs; ++i) {
+		res[i] = r[i];
+		if (tot + r[i].n_cigar > cigar_cap) return MM355_ENOMEM;
+		memcpy(cigar + tot, cg.data() + r[i].cigar_off, (size_t)r[i].n_cigar * 4);
+		res[i].cigar_off = tot; tot += r[i].n_cigar;
+	}
+	return 0;
+}

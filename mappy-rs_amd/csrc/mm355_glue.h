@@ -1,2 +1,81 @@
+// mm355_glue.h -- host-resident tail of the path (small, strictly sequential per read; SURVEY.md 8a rows a9-a11,
+// a13): long-join re-chaining, chains -> regions, primary/secondary selection, the DP work generator that feeds
+// k_ksw_extd2 in rounds, CIGAR stitching, MAPQ, cs/MD.  Batch-oriented: one ReadState per read of the batch.
 #pragma once
+#include <stdint.h>
+#include <vector>
+#include <string>
 #include "mm355_host.h"
+
+struct Extra {
+	int32_t dp_score = 0, dp_max = 0, dp_max2 = 0;
+	uint32_t n_ambi = 0;
+	std::vector<uint32_t> cigar;
+};
+
+struct Reg {                // U:minimap.h::mm_reg1_t
+	int32_t id = 0, cnt = 0, rid = 0, score = 0;
+	int32_t qs = 0, qe = 0, rs = 0, re = 0;
+	int32_t parent = 0, subsc = 0, as = 0, mlen = 0, blen = 0, n_sub = 0, score0 = 0;
+	uint32_t mapq = 0, split = 0, rev = 0, inv = 0, sam_pri = 0, seg_split = 0, split_inv = 0, is_alt = 0, strand_retained = 0;
+	uint32_t hash = 0;
+	float div = -1.0f;
+	Extra *p = 0;
+	int task = -1;          // alignment task bound to this region (-1: none yet)
+};
+
+struct EzRes {              // U:ksw2.h::ksw_extz_t as returned by the DP kernel
+	int32_t max = 0, zdropped = 0, max_q = -1, max_t = -1, mqe = 0, mqe_t = -1, mte = 0, mte_q = -1, score = 0, reach_end = 0;
+	std::vector<uint32_t> cigar;
+	int state = 0;          // 0 none, 1 requested, 2 done
+};
+
+struct DpReq {              // one extension problem requested by a region task
+	int read, task, slot;    // slot: index into AlnTask::res
+	int32_t qlen, tlen;
+	int32_t q_st;            // start on the strand-adjusted query code string (qseq0[rev])
+	int rev_strand;          // which query strand buffer
+	uint32_t rid; int32_t t_st;
+	int reversed;            // both strings reversed (left extension)
+	int32_t w, zdrop, end_bonus, flag;
+};
+
+struct AlnTask {            // U:align.c::mm_align1 split into a one-off preamble and a replayable DP walk
+	int reg_uid;             // identifies the region (stable across inserts)
+	int32_t rid, rev, as1, cnt1;
+	int32_t rs, qs, re, qe;            // anchor-midpoint bounds of the first/last seed
+	int32_t rs0, qs0, re0, qe0;
+	int32_t bw, bw_long;
+	int split_inv;
+	bool prepared = false, done = false;
+	std::vector<EzRes> res;            // slot 0 left, 1 right, 2+2*i approx fill at seed i, 3+2*i exact fill at seed i
+	// inversion attempt (U:align.c::mm_align1_inv)
+	EzRes inv_res; int inv_state = 0;  // 0 not tried, 1 waiting for DP, 2 finished
+};
+
+struct ReadState {
+	int32_t qlen = 0;
+	const char *seq = 0;
+	std::vector<uint8_t> qc[2];        // query codes forward / reverse-complement
+	std::vector<mm128> a;              // chained anchors (after compact_a, or after the RMQ re-chain)
+	std::vector<uint64_t> u;
+	std::vector<uint64_t> mini_pos;
+	int32_t rep_len = 0, n_a = 0;
+	std::vector<Reg> regs;
+	std::vector<AlnTask> tasks;
+	int cursor = 0;                    // U:align.c::mm_align_skeleton loop index
+	bool aligned = false;
+	int next_uid = 0;
+};
+
+struct GlueStats { int64_t n_rmq = 0, n_rounds = 0, n_jobs = 0; };
+
+// stage 1 (after the chain kernels): re-chain (if triggered), regions, pre-DP selection; leaves rs.regs ready for DP
+void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs);
+// stage 2: advance the skeleton of one read as far as cached DP results allow; appends missing DP problems to `reqs`.
+// returns true when the read needs no more DP.
+bool mm355_glue_align_step(const mm355_index *mi, const mm355_mapopt_t *opt, int read_id, ReadState &rs, std::vector<DpReq> &reqs);
+// stage 3: post-DP filtering, sorting, selection and MAPQ; emits hit records
+void mm355_glue_finish(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs, int flags,
+                       std::vector<mm355_hit_t> &hits, std::vector<uint32_t> &cigar, std::string &str);
+void mm355_glue_release(ReadState &rs);

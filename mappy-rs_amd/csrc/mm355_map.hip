@@ -1,4 +1,226 @@
+// mm355_map.hip -- mm355_map_batch: the drop-in for the reference's per-read mm_map call
+// (/root/reference/src/lib.rs:482-488 single read, :587-593 batch worker) over a whole batch of reads.
+//   device : sketch -> mz_flt -> seed lookup -> seed select -> anchor expansion -> radix sort -> chaining DP ->
+//            backtrack/compact -> [host: regions] -> banded extension in rounds (all pending problems of all reads
+//            per launch) -> [host: stitch, select, MAPQ, cs]
+//   host   : the O(#chains) sequential tail of mm355_glue.cpp on a few threads, never any per-base loop of the hot path.
+// Reads are independent, so a node shards them over its GPUs with one context per GPU and no collective.
+#include <stdio.h>
+#include <string.h>
+#include <thread>
+#include <atomic>
+#include <chrono>
+#include <algorithm>
 #include "mm355_pipeline.h"
-extern "C" int mm355_map_batch(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
-                    const int32_t *lens, int flags, mm355_hits_t **out) { return MM355_EUNSUP; }
-extern "C" void mm355_free_hits(mm355_hits_t *hits) {}
+#include "mm355_dp.h"
+#include "mm355_glue.h"
+
+// packs u[], compacted anchors and mini_pos[] of all reads into three dense arrays (one D2H copy each)
+__global__ __launch_bounds__(256) void k_pack_chains(int n_reads, const int64_t *aoff, const int64_t *roff, const int32_t *n_u, const int32_t *n_v, const int32_t *n_mini,
+                                                     const int64_t *uo, const int64_t *vo, const int64_t *mo, const uint64_t *u, const mm128 *a, const uint64_t *mini_pos,
+                                                     uint64_t *pu, mm128 *pa, uint64_t *pm)
+{
+	const int r = blockIdx.x;
+	if (r >= n_reads) return;
+	const int64_t ao = aoff[r], ro = roff[r];
+	for (int i = threadIdx.x; i < n_u[r]; i += 256) pu[uo[r] + i] = u[ao + i];
+	for (int i = threadIdx.x; i < n_v[r]; i += 256) pa[vo[r] + i] = a[ao + i];
+	for (int i = threadIdx.x; i < n_mini[r]; i += 256) pm[mo[r] + i] = mini_pos[ro + i];
+}
+
+template <typename F>
+static void parallel_for(int64_t n, int n_threads, F f)
+{
+	if (n_threads <= 1 || n < 2) { for (int64_t i = 0; i < n; ++i) f(i, 0); return; }
+	std::atomic<int64_t> next(0);
+	std::vector<std::thread> th;
+	auto work = [&](int tid) { for (;;) { int64_t i = next.fetch_add(1); if (i >= n) break; f(i, tid); } };
+	for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
+	work(0);
+	for (auto &t : th) t.join();
+}
+
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int host_threads()
+{
+	const char *e = getenv("MM355_HOST_THREADS");
+	int n = e? atoi(e) : (int)std::thread::hardware_concurrency();
+	if (n < 1) n = 1;
+	if (n > 32) n = 32;
+	return n;
+}
+
+static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<ReadState> &rs, const std::vector<DpReq> &reqs)
+{
+	// chunk the requests so that the direction matrices of one launch fit the HBM budget
+	size_t free_b = 0, total_b = 0;
+	(void)hipMemGetInfo(&free_b, &total_b);
+	size_t budget = std::min<size_t>((size_t)24 << 30, free_b / 3);
+	if (budget < ((size_t)256 << 20)) budget = (size_t)256 << 20;
+	size_t i = 0;
+	while (i < reqs.size()) {
+		std::vector<DpGather> g; std::vector<DpJobDev> jobs;
+		size_t q_tot = 0, t_tot = 0, p_tot = 0, j = i;
+		for (; j < reqs.size(); ++j) {
+			const DpReq &q = reqs[j];
+			int w = q.w < 0? std::max(q.qlen, q.tlen) : q.w;
+			int n_col_ = std::min(q.qlen, q.tlen);
+			n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
+			size_t pb = q.qlen > 0 && q.tlen > 0? ((size_t)(q.qlen + q.tlen - 1) * n_col_ + 1) * 16 : 0;
+			if (mo->max_sw_mat > 0 && (int64_t)q.tlen * q.qlen > mo->max_sw_mat) pb = 0;
+			if (j > i && p_tot + pb > budget) break;
+			DpGather gg; memset(&gg, 0, sizeof(gg));
+			gg.qlen = q.qlen > 0? q.qlen : 0; gg.tlen = q.tlen > 0? q.tlen : 0;
+			gg.qoff = (int64_t)q_tot; gg.toff = (int64_t)t_tot;
+			gg.q_src = 2 * c->hb.roff[q.read] + (q.rev_strand? rs[q.read].qlen : 0) + q.q_st;
+			gg.rid = q.rid; gg.t_st = q.t_st; gg.rev = q.reversed;
+			g.push_back(gg);
+			DpJobDev jd; memset(&jd, 0, sizeof(jd));
+			jd.qlen = q.qlen; jd.tlen = q.tlen; jd.qoff = gg.qoff; jd.toff = gg.toff; jd.w = q.w; jd.zdrop = q.zdrop; jd.end_bonus = q.end_bonus; jd.flag = q.flag;
+			jobs.push_back(jd);
+			q_tot += (size_t)gg.qlen + 16; t_tot += (size_t)gg.tlen + 16; p_tot += pb;
+		}
+		int rc = mm355_dp_gather(c, g, q_tot, t_tot);
+		if (rc) return rc;
+		std::vector<mm355_dpres_t> res; std::vector<uint32_t> cig;
+		rc = mm355_dp_run(c, mo, jobs, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), res, cig);
+		if (rc) return rc;
+		for (size_t k = i; k < j; ++k) {
+			const DpReq &q = reqs[k];
+			const mm355_dpres_t &r = res[k - i];
+			AlnTask &T = rs[q.read].tasks[q.task];
+			EzRes &e = q.slot >= 0? T.res[q.slot] : T.inv_res;
+			e.max = r.max; e.zdropped = r.zdropped; e.max_q = r.max_q; e.max_t = r.max_t; e.mqe = r.mqe; e.mqe_t = r.mqe_t;
+			e.mte = r.mte; e.mte_q = r.mte_q; e.score = r.score; e.reach_end = r.reach_end;
+			e.cigar.assign(cig.begin() + r.cigar_off, cig.begin() + r.cigar_off + r.n_cigar);
+			e.state = 2;
+		}
+		i = j;
+	}
+	return 0;
+}
+
+extern "C" int mm355_map_batch(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs, const int32_t *lens, int flags, mm355_hits_t **out)
+{
+	*out = 0;
+	if (c == 0 || mo == 0 || n_reads < 0) return MM355_EINVAL;
+	if (c->mi == 0) return MM355_ENOIDX;
+	int rc = mm355_check_opts(mo, c->mi);
+	if (rc) return rc;
+	const double t_start = now_ms();
+	const mm355_index *mi = c->mi;
+	DevParams pr = mm355_make_params(mo, mi);
+	memset(&c->stats, 0, sizeof(c->stats));
+	// reads the path does not map: empty ("Sequence is empty"), or longer than max_qlen (U:map.c::mm_map_frag)
+	std::vector<int32_t> dl(lens, lens + n_reads);
+	std::vector<int32_t> status(n_reads, 0);
+	for (int64_t i = 0; i < n_reads; ++i) {
+		if (lens[i] <= 0) { status[i] = MM355_EEMPTY; dl[i] = 0; }
+		else if (mo->max_qlen > 0 && lens[i] > mo->max_qlen) dl[i] = 0;
+	}
+	if ((rc = mm355_run_pack(c, n_reads, seqs, dl.data()))) return rc;
+	if ((rc = mm355_run_sketch(c))) return rc;
+	if ((rc = mm355_run_seeds(c, pr))) return rc;
+	if ((rc = mm355_run_expand(c, pr))) return rc;
+	if ((rc = mm355_run_sort(c))) return rc;
+	if ((rc = mm355_run_chain(c, pr))) return rc;
+	if ((rc = mm355_run_backtrack(c, pr))) return rc;
+	if ((rc = mm355_run_read_codes(c))) return rc;
+	HostBatch &hb = c->hb;
+	// pack chains / anchors / mini_pos and bring them to the host
+	std::vector<int64_t> uo(n_reads + 1), vo(n_reads + 1), mo_(n_reads + 1);
+	int64_t tu = 0, tv = 0, tm = 0;
+	for (int64_t i = 0; i < n_reads; ++i) { uo[i] = tu; vo[i] = tv; mo_[i] = tm; tu += hb.n_u[i]; tv += hb.n_v[i]; tm += hb.n_mini[i]; }
+	uo[n_reads] = tu; vo[n_reads] = tv; mo_[n_reads] = tm;
+	std::vector<uint64_t> pu(tu + 1), pm(tm + 1); std::vector<mm128> pa(tv + 1);
+	if (n_reads) {
+		DBuf &scr = c->b;   // b[] (compact_a scratch) is free again: reuse it for the packed copies
+		const size_t nr2 = ((size_t)n_reads + 2) & ~(size_t)1, tu2 = ((size_t)tu + 1) & ~(size_t)1;   // keep every sub-array 16-B aligned
+		size_t need = nr2 * 8 * 3 + tu2 * 8 + (size_t)tv * 16 + (size_t)tm * 8 + 256;
+		DBuf pack; if (pack.ensure(need)) return MM355_ENOMEM;
+		(void)scr;
+		int64_t *d_uo = pack.as<int64_t>(), *d_vo = d_uo + nr2, *d_mo = d_vo + nr2;
+		uint64_t *d_pu = (uint64_t*)(d_mo + nr2); mm128 *d_pa = (mm128*)(d_pu + tu2); uint64_t *d_pm = (uint64_t*)(d_pa + tv);
+		HIPCHK(hipMemcpyAsync(d_uo, uo.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->st));
+		HIPCHK(hipMemcpyAsync(d_vo, vo.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->st));
+		HIPCHK(hipMemcpyAsync(d_mo, mo_.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->st));
+		hipLaunchKernelGGL(k_pack_chains, dim3((unsigned)n_reads), dim3(256), 0, c->st, (int)n_reads, c->aoff.as<int64_t>(), c->roff.as<int64_t>(),
+		                   c->n_u.as<int32_t>(), c->n_v.as<int32_t>(), c->n_mini.as<int32_t>(), d_uo, d_vo, d_mo, c->u.as<uint64_t>(), c->a.as<mm128>(),
+		                   c->mini_pos.as<uint64_t>(), d_pu, d_pa, d_pm);
+		HIPCHK(hipGetLastError());
+		if (tu) HIPCHK(hipMemcpyAsync(pu.data(), d_pu, (size_t)tu * 8, hipMemcpyDeviceToHost, c->st));
+		if (tv) HIPCHK(hipMemcpyAsync(pa.data(), d_pa, (size_t)tv * 16, hipMemcpyDeviceToHost, c->st));
+		if (tm) HIPCHK(hipMemcpyAsync(pm.data(), d_pm, (size_t)tm * 8, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+		pack.release();
+	}
+	const double t_host0 = now_ms();
+	const int nt = host_threads();
+	std::vector<ReadState> rs(n_reads);
+	parallel_for(n_reads, nt, [&](int64_t i, int) {
+		ReadState &r = rs[i];
+		r.qlen = dl[i]; r.seq = seqs[i]; r.rep_len = hb.rep_len[i];
+		r.u.assign(pu.begin() + uo[i], pu.begin() + uo[i + 1]);
+		r.a.assign(pa.begin() + vo[i], pa.begin() + vo[i + 1]);
+		r.mini_pos.assign(pm.begin() + mo_[i], pm.begin() + mo_[i + 1]);
+		if (r.qlen > 0) mm355_glue_pre_align(mi, mo, r); else r.aligned = true;
+	});
+	double ms_host = now_ms() - t_host0;
+	// extension rounds: every pending problem of every read goes into the same launches
+	for (int round = 0; round < 64; ++round) {
+		const double th0 = now_ms();
+		std::vector<std::vector<DpReq>> treq(nt);
+		std::atomic<int64_t> n_open(0);
+		parallel_for(n_reads, nt, [&](int64_t i, int tid) {
+			if (!mm355_glue_align_step(mi, mo, (int)i, rs[i], treq[tid])) n_open.fetch_add(1);
+		});
+		std::vector<DpReq> reqs;
+		for (auto &v : treq) reqs.insert(reqs.end(), v.begin(), v.end());
+		ms_host += now_ms() - th0;
+		if (n_open.load() == 0) break;
+		if (reqs.empty()) return MM355_EINVAL;   // a read is waiting for a result nobody requested: logic error
+		if ((rc = run_dp_round(c, mo, rs, reqs))) return rc;
+	}
+	const double th1 = now_ms();
+	std::vector<std::vector<mm355_hit_t>> rh(n_reads);
+	std::vector<std::vector<uint32_t>> rc_(n_reads);
+	std::vector<std::string> rstr(n_reads);
+	parallel_for(n_reads, nt, [&](int64_t i, int) {
+		if (rs[i].qlen > 0) mm355_glue_finish(mi, mo, rs[i], flags, rh[i], rc_[i], rstr[i]);
+		mm355_glue_release(rs[i]);
+	});
+	mm355_hits_t *H = (mm355_hits_t*)calloc(1, sizeof(mm355_hits_t));
+	H->n_reads = n_reads;
+	H->hit_off = (int64_t*)malloc((n_reads + 1) * 8);
+	H->status = (int32_t*)malloc((n_reads > 0? n_reads : 1) * 4);
+	int64_t nh = 0, nc = 0, ns = 0;
+	for (int64_t i = 0; i < n_reads; ++i) { H->hit_off[i] = nh; H->status[i] = status[i]; nh += (int64_t)rh[i].size(); nc += (int64_t)rc_[i].size(); ns += (int64_t)rstr[i].size(); }
+	H->hit_off[n_reads] = nh; H->n_hits = nh; H->n_cigar = nc; H->n_str = ns;
+	H->hits = (mm355_hit_t*)malloc((nh > 0? nh : 1) * sizeof(mm355_hit_t));
+	H->cigar = (uint32_t*)malloc((nc > 0? nc : 1) * 4);
+	H->str = (char*)malloc(ns > 0? ns : 1);
+	nh = nc = ns = 0;
+	for (int64_t i = 0; i < n_reads; ++i) {
+		for (mm355_hit_t h : rh[i]) {
+			h.cigar_off += nc;
+			if (h.cs_len >= 0) h.cs_off += ns;
+			if (h.md_len >= 0) h.md_off += ns;
+			H->hits[nh++] = h;
+		}
+		if (!rc_[i].empty()) memcpy(H->cigar + nc, rc_[i].data(), rc_[i].size() * 4);
+		if (!rstr[i].empty()) memcpy(H->str + ns, rstr[i].data(), rstr[i].size());
+		nc += (int64_t)rc_[i].size(); ns += (int64_t)rstr[i].size();
+	}
+	ms_host += now_ms() - th1;
+	c->stats.ms_host = ms_host;
+	c->stats.ms_total = now_ms() - t_start;
+	*out = H;
+	return 0;
+}
+
+extern "C" void mm355_free_hits(mm355_hits_t *h)
+{
+	if (h == 0) return;
+	free(h->hit_off); free(h->status); free(h->hits); free(h->cigar); free(h->str); free(h);
+}

@@ -56,4 +56,12 @@ int mm355_run_sort(mm355_ctx *ctx);
 int mm355_run_chain(mm355_ctx *ctx, const DevParams &pr);
 int mm355_run_backtrack(mm355_ctx *ctx, const DevParams &pr);
 
+// time one launch group on the context's stream with HIP events (the stream the kernels are launched on)
+struct EvTimer {
+	mm355_ctx *c; double *acc;
+	EvTimer(mm355_ctx *c_, double *a) : c(c_), acc(a) { (void)hipEventRecord(c->ev0, c->st); }
+	~EvTimer() { float ms = 0; (void)hipEventRecord(c->ev1, c->st); (void)hipEventSynchronize(c->ev1); (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *acc += ms; }
+};
+typedef EvTimer EvTimer2;
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)

@@ -90,13 +90,6 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 
 extern "C" int mm355_get_stats(mm355_ctx_t *c, mm355_stats_t *st) { if (c == 0) return MM355_EINVAL; *st = c->stats; return 0; }
 
-// time one launch group on the context's stream with HIP events
-struct EvTimer {
-	mm355_ctx *c; double *acc;
-	EvTimer(mm355_ctx *c_, double *a) : c(c_), acc(a) { (void)hipEventRecord(c->ev0, c->st); }
-	~EvTimer() { float ms = 0; (void)hipEventRecord(c->ev1, c->st); (void)hipEventSynchronize(c->ev1); (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *acc += ms; }
-};
-
 static DevBatch dev_batch(mm355_ctx *c)
 {
 	DevBatch b;

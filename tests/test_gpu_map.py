@@ -1,0 +1,181 @@
+"""End-to-end parity on the GPU: full Mapping records from the HIP path (through mm355_map_batch) must equal the CPU
+oracle's on the same seeded inputs -- coordinates, strand, CIGAR, NM, cs, MD, MAPQ, primary flag (bit-exact).
+Also the banded-extension kernel alone vs the oracle's ksw_extd2 restatement on random problems."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+import synthdata as S
+
+FIELDS = ("target_name", "target_start", "target_end", "query_start", "query_end", "strand", "target_len", "match_len",
+          "block_len", "mapq", "is_primary", "NM", "cs", "MD")
+
+
+def rec(m):
+    return (m.target_name, m.target_start, m.target_end, m.query_start, m.query_end, m.strand, m.target_len, m.match_len,
+            m.block_len, m.mapq, m.is_primary, m.NM, m.cs, m.MD, m.cigar_str)
+
+
+def orec(o):
+    return tuple(o[k] for k in FIELDS) + (o["cigar_str"],)
+
+
+def check_reads(al, orc, reads, cs=True, MD=True):
+    al.enable_threading(2)
+    n_hits = n_sec = 0
+    batch = al._map_many(reads, (1 if cs else 0) | (2 if MD else 0))
+    for i, rd in enumerate(reads):
+        exp = orc.map(rd, cs=cs, MD=MD)
+        got = batch[i]
+        assert len(got) == len(exp), (i, len(got), len(exp))
+        for g, e in zip(got, exp):
+            assert rec(g) == orec(e), (i, rec(g), orec(e))
+            n_hits += 1
+            n_sec += not e["is_primary"]
+    return n_hits, n_sec
+
+
+@pytest.fixture(scope="module")
+def ont(built, tmp_path_factory):
+    import mappy_rs
+    td = tmp_path_factory.mktemp("gm")
+    g = S.make_genome(51, [500000, 300000], repeats=((5000, 6, 0.01), (1200, 30, 0.02), (300, 80, 0.05)), n_runs=4)
+    fa = str(td / "ref.fa")
+    S.write_fasta(fa, g, ["chr1", "chr2"])
+    return dict(al=mappy_rs.Aligner(fa, preset="map-ont"), orc=O.OracleAligner(fa, preset="map-ont"), g=g, fa=fa)
+
+
+def test_map_parity_ont(ont):
+    reads, _ = S.make_reads(52, ont["g"], 200, n50=6000, lo=200)
+    n_hits, n_sec = check_reads(ont["al"], ont["orc"], reads)
+    assert n_hits >= 195
+
+
+def test_map_parity_chimeric_and_sv(ont):
+    """reads that force z-drop splits, long-join re-chaining, inversions and secondary hits"""
+    g = ont["g"]
+    rng = np.random.default_rng(3)
+    comp = lambda c: np.where(c < 4, 3 - c, 4).astype(np.uint8)[::-1]
+    reads = []
+    for _ in range(12):   # chimera of two loci
+        a0 = int(rng.integers(0, 400000)); b0 = int(rng.integers(0, 250000))
+        c = np.concatenate([g[0][a0:a0 + 3000], comp(g[1][b0:b0 + 2500])])
+        reads.append(S.codes_to_str(S.mutate(c, rng, 0.02, 0.01, 0.01)))
+    for _ in range(12):   # large deletion / insertion relative to the reference
+        a0 = int(rng.integers(0, 400000))
+        c = np.concatenate([g[0][a0:a0 + 2500], g[0][a0 + 2500 + 1500:a0 + 6500]])
+        reads.append(S.codes_to_str(S.mutate(c, rng, 0.02, 0.01, 0.01)))
+        c = np.concatenate([g[0][a0:a0 + 2000], S.random_codes(rng, 800), g[0][a0 + 2000:a0 + 4500]])
+        reads.append(S.codes_to_str(S.mutate(c, rng, 0.02, 0.01, 0.01)))
+    for _ in range(10):   # inversion in the middle
+        a0 = int(rng.integers(0, 400000))
+        c = np.concatenate([g[0][a0:a0 + 2500], comp(g[0][a0 + 2500:a0 + 3300]), g[0][a0 + 3300:a0 + 6000]])
+        reads.append(S.codes_to_str(S.mutate(c, rng, 0.015, 0.01, 0.01)))
+    n_hits, n_sec = check_reads(ont["al"], ont["orc"], reads)
+    assert n_hits > len(reads)   # splits produce more than one hit per read
+
+
+def test_map_parity_edge_reads(ont):
+    g = ont["g"]
+    reads = ["ACGT", "A" * 500, "N" * 300, S.codes_to_str(g[0][1000:1400]), S.codes_to_str(g[1][50000:50100]),
+             S.codes_to_str(g[0][0:3000]), S.codes_to_str(g[0][-3000:]), S.codes_to_str(g[0][20000:21000]) + "N" * 40 + S.codes_to_str(g[0][21040:22000])]
+    check_reads(ont["al"], ont["orc"], reads)
+    with pytest.raises(RuntimeError, match="Sequence is empty"):
+        ont["al"].map("")
+
+
+def test_map_parity_hifi(built, tmp_path):
+    import mappy_rs
+    g = S.make_genome(61, [400000], repeats=((4000, 5, 0.005), (800, 20, 0.01)))
+    fa = str(tmp_path / "h.fa")
+    S.write_fasta(fa, g, ["chrH"])
+    reads, _ = S.make_reads(62, g, 40, n50=12000, lo=3000, sub=0.0005, ins=0.00075, dele=0.00075)
+    al = mappy_rs.Aligner(fa, preset="map-hifi")
+    orc = O.OracleAligner(fa, preset="map-hifi")
+    n_hits, _ = check_reads(al, orc, reads)
+    assert n_hits >= 40
+
+
+def test_map_parity_option_overrides(ont):
+    import mappy_rs
+    kw = dict(preset="map-ont", best_n=2, min_chain_score=60, bw=300, scoring=(2, 5, 5, 3, 20, 1))
+    al = mappy_rs.Aligner(ont["fa"], **kw)
+    orc = O.OracleAligner(ont["fa"], **kw)
+    reads, _ = S.make_reads(72, ont["g"], 40, n50=4000, lo=500)
+    check_reads(al, orc, reads)
+
+
+def test_dp_kernel_parity(ont):
+    """k_ksw_extd2 vs the oracle's restatement: extension (left/right) and global fills, approx and exact, band-limited"""
+    from mappy_rs import _ffi
+    L = _ffi.lib()
+    OL = O.lib()
+    rng = np.random.default_rng(9)
+    al = ont["al"]
+    jobs, qs, ts = [], [], []
+    EXTZ, RIGHT, REV, APPROX = 0x40, 0x02, 0x80, 0x08
+    for i in range(120):
+        tl = int(rng.integers(1, 700)) if i % 7 else int(rng.integers(900, 2600))
+        t = S.random_codes(rng, tl)
+        q = S.mutate(t, rng, 0.05, 0.03, 0.03)
+        if i % 11 == 0 and len(q) > 20:
+            q[len(q) // 2:len(q) // 2 + 3] = 4
+        if i % 13 == 0:
+            q = np.concatenate([q[:len(q) // 2], S.random_codes(rng, 300)])   # forces z-drop
+        if len(q) == 0:
+            q = S.random_codes(rng, 5)
+        kind = i % 4
+        flag = [EXTZ, EXTZ | RIGHT | REV, APPROX, 0][kind]
+        w = [751, 751, 30001, int(rng.integers(5, 200))][kind]
+        zd = [400, 200, 400, 400][kind]
+        eb = [-1, -1, -1, -1][kind]
+        jobs.append((len(q), tl, w, zd, eb, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
+    qcat = np.concatenate(qs); tcat = np.concatenate(ts)
+    ja = (_ffi.DpJob * len(jobs))()
+    qo = to = 0
+    for i, (ql, tl, w, zd, eb, fl) in enumerate(jobs):
+        ja[i].qlen, ja[i].tlen, ja[i].qoff, ja[i].toff, ja[i].w, ja[i].zdrop, ja[i].end_bonus, ja[i].flag = ql, tl, qo, to, w, zd, eb, fl
+        qo += ql; to += tl
+    res = (_ffi.DpRes * len(jobs))()
+    cap = int(qcat.size + tcat.size + 4 * len(jobs))
+    cig = np.zeros(cap, np.uint32)
+    sr = al._stage_runner()
+    _ffi.check(L.mm355_stage_dp(sr.ctx, C.byref(al._mo), len(jobs), ja, qcat.ctypes.data, qcat.size, tcat.ctypes.data, tcat.size, res, cig.ctypes.data, cap))
+    mat = np.zeros(25, np.int8)
+    mo = al._mo
+    OL.mmo_ksw_gen_simple_mat(5, mat.ctypes.data, mo.a, mo.b, mo.sc_ambi)
+    n_zd = 0
+    for i, (ql, tl, w, zd, eb, fl) in enumerate(jobs):
+        ez = O.Extz()
+        OL.mmo_ksw_extd2(ql, qs[i].ctypes.data, tl, ts[i].ctypes.data, 5, mat.ctypes.data, mo.q, mo.e, mo.q2, mo.e2, w, zd, eb, fl, C.byref(ez))
+        emax, ezd = ez.max_zd & 0x7fffffff, ez.max_zd >> 31
+        r = res[i]
+        assert (r.max, r.zdropped, r.max_q, r.max_t, r.mqe, r.mqe_t, r.mte, r.mte_q, r.score, r.reach_end, r.n_cigar) == \
+               (emax, ezd, ez.max_q, ez.max_t, ez.mqe, ez.mqe_t, ez.mte, ez.mte_q, ez.score, ez.reach_end, ez.n_cigar), (i, jobs[i])
+        exp = [ez.cigar[k] for k in range(ez.n_cigar)]
+        assert list(cig[r.cigar_off:r.cigar_off + r.n_cigar]) == exp, i
+        n_zd += ezd
+        if ez.n_cigar: OL.free(ez.cigar)
+    assert n_zd > 0
+    sr.close()
+
+
+def test_stats_counters(ont):
+    reads, _ = S.make_reads(82, ont["g"], 30, n50=3000, lo=500)
+    al = ont["al"]
+    al._map_many(reads, 1)
+    from mappy_rs import _ffi
+    st = _ffi.Stats()
+    _ffi.check(al._L.mm355_get_stats(al._ctx, C.byref(st)))
+    tot = dict(n_mz=0, n_hit=0, n_a=0, n_a_multi=0)
+    for rd in reads:
+        ont["orc"].map(rd)
+        s = ont["orc"].stats()
+        for k in tot: tot[k] += getattr(s, k)
+    assert (st.n_mz, st.n_hit, st.n_a, st.n_a_multi) == (tot["n_mz"], tot["n_hit"], tot["n_a"], tot["n_a_multi"])
+    assert st.dp_cells > 0 and st.n_dp_jobs > 0 and st.ms_seed_lookup > 0
