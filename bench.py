@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned Mbases/s of the MI355X mapping path (BASELINE.json metric).
+
+A "step" is one pass of the hot path (mm355_map_resident: sketch -> seed lookup -> chain -> extension -> hits) over
+one batch of synthetic ONT reads that is already resident in HBM when the timed region starts.  At --gpus N>1 the
+driver launches one rank per GPU (torch.distributed.run); every rank maps its OWN batch against its own replica of the
+index (weak scaling, reads are independent: no data-path collective), the timed region is bracketed by barriers, the
+MAX over ranks is taken and rank 0 prints ONE JSON line.
+
+Workloads (--workload):
+  ecoli   BASELINE.json configs[1]: synthetic 4.64 Mbp genome (seed 1), map-ont, reads N50 ~8 kb, 6 % error
+  human   BASELINE.json configs[2]: synthetic GRCh38-scale genome (seed 3), map-ont, reads N50 ~10 kb  [needs the
+          device index builder; selected automatically when available]
+The JSON line also carries `roofline` (dominant kernel; algorithmic bytes of SURVEY 8d / live HIP-event time on the
+launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample of the same reads).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "mappy-rs_amd"))
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def make_workload(name, n_reads, rank):
+    import synthdata as S
+    if name == "ecoli":
+        t0 = time.time()
+        g = S.make_genome(1, [4641652], gc=0.508, repeats=((5000, 7, 0.01), (1300, 20, 0.01)))
+        reads, _ = S.make_reads(2 + 1000 * rank, g, n_reads, n50=8000, sigma=0.75, lo=500, hi=100000)
+        log("[bench] synthetic E. coli-like genome + %d reads in %.1fs" % (n_reads, time.time() - t0))
+        return g, ["chrE"], reads, dict(workload="configs[1]: synthetic 4.64 Mbp E. coli-like genome (seed 1), map-ont k15 w10, "
+                                                 "synthetic ONT reads N50~8kb 6% error (seed 2)", preset="map-ont")
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(fa, preset, reads, budget_s, threads):
+    """oracle (CPU restatement of the minimap2 2.26 path) on host threads, bounded sample"""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    orc = O.OracleAligner(fa, preset=preset)
+    t0 = time.time()
+    done = {"bases": 0, "aligned": 0, "n": 0}
+    deadline = t0 + budget_s
+
+    def work(rd):
+        if time.time() > deadline:
+            return None
+        h = orc.map(rd, cs=True)
+        return len(rd), (len(rd) if h else 0)
+
+    with ThreadPoolExecutor(threads) as ex:
+        for r in ex.map(work, reads):
+            if r is None:
+                continue
+            done["bases"] += r[0]; done["aligned"] += r[1]; done["n"] += 1
+    dt = time.time() - t0
+    return dict(value=round(done["aligned"] / dt / 1e6, 4), unit="aligned Mbases/s", cores=threads, kind="port",
+                sample="%d reads (%.2f Mbases) of the same workload in %.1f s; CPU restatement of the minimap2 2.26 path "
+                       "(oracle/), scalar ksw2, one read per thread task" % (done["n"], done["bases"] / 1e6, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="ecoli")
+    ap.add_argument("--reads", type=int, default=8192, help="reads per step per GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        dist = dist_
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    from mappy_rs import _ffi
+    import synthdata as S
+    L = _ffi.lib()
+    if L.mm355_device_count() <= local_rank:
+        raise SystemExit("bench.py needs an MI355X: libmm355 has no CPU fallback (devices visible: %d)" % L.mm355_device_count())
+
+    g, names, reads, wl = make_workload(args.workload, args.reads, rank)
+    # index (host builder for now; replicated on every GPU)
+    t0 = time.time()
+    io, mo = _ffi.IdxOpt(), _ffi.MapOpt()
+    L.mm355_set_opt(None, C.byref(io), C.byref(mo))
+    _ffi.check(L.mm355_set_opt(wl["preset"].encode(), C.byref(io), C.byref(mo)))
+    mo.flag |= 4
+    seqs = [S.codes_to_str(c).encode() for c in g]
+    arr = (C.c_char_p * len(seqs))(*seqs)
+    lens = (C.c_int64 * len(seqs))(*[len(s) for s in seqs])
+    nm = (C.c_char_p * len(seqs))(*[n.encode() for n in names])
+    idx = C.c_void_p()
+    _ffi.check(L.mm355_index_build(C.byref(io), len(seqs), arr, lens, nm, min(16, os.cpu_count() or 1), C.byref(idx)))
+    L.mm355_mapopt_update(C.byref(mo), idx)
+    ctx = C.c_void_p()
+    _ffi.check(L.mm355_ctx_create(idx, local_rank, C.byref(ctx)))
+    log("[bench] index built + uploaded in %.1fs (mid_occ=%d)" % (time.time() - t0, mo.mid_occ))
+
+    rarr, rlens, keep = _ffi.pack_reads(reads)
+    n_bases = sum(len(b) for b in keep)
+    t0 = time.time()
+    _ffi.check(L.mm355_batch_upload(ctx, len(reads), rarr, rlens))
+    t_upload = time.time() - t0
+
+    def step():
+        hp = C.POINTER(_ffi.Hits)()
+        _ffi.check(L.mm355_map_resident(ctx, C.byref(mo), _ffi.OUT_CS, C.byref(hp)))
+        h = hp.contents
+        off = np.ctypeslib.as_array(h.hit_off, shape=(len(reads) + 1,))
+        mapped = np.diff(off) > 0
+        aligned = int(np.asarray(rlens)[mapped].sum())
+        n_hits = int(h.n_hits)
+        L.mm355_free_hits(hp)
+        st = _ffi.Stats()
+        L.mm355_get_stats(ctx, C.byref(st))
+        return aligned, n_hits, st
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    agg = {}
+    t0 = time.perf_counter()
+    aligned_tot = 0
+    for _ in range(args.steps):
+        aligned, n_hits, st = step()
+        aligned_tot += aligned
+        for k, _t in _ffi.Stats._fields_:
+            agg[k] = agg.get(k, 0) + getattr(st, k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        dev = "cuda" if torch.cuda.is_available() else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        a = torch.tensor([aligned_tot, n_bases * args.steps], dtype=torch.float64, device=dev)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        aligned_all, bases_all = float(a[0].item()), float(a[1].item())
+    else:
+        aligned_all, bases_all = float(aligned_tot), float(n_bases * args.steps)
+
+    # PCIe-inclusive variant (never `value`): upload + map of the same batch
+    t0 = time.perf_counter()
+    hp = C.POINTER(_ffi.Hits)()
+    _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(reads), rarr, rlens, _ffi.OUT_CS, C.byref(hp)))
+    L.mm355_free_hits(hp)
+    dt_pcie = time.perf_counter() - t0
+
+    if rank == 0:
+        K = args.steps
+        kern_ms = {"sketch": agg["ms_sketch"] / K, "seed_lookup": agg["ms_seed_lookup"] / K, "seed_expand": agg["ms_seed_expand"] / K,
+                   "seed_select+mzflt": agg["ms_seed"] / K, "sort": agg["ms_sort"] / K, "chain": agg["ms_chain"] / K,
+                   "backtrack": agg["ms_backtrack"] / K, "dp": agg["ms_dp"] / K, "host_glue": agg["ms_host"] / K}
+        n_mz, n_hit, n_a, n_am = agg["n_mz"] / K, agg["n_hit"] / K, agg["n_a"] / K, agg["n_a_multi"] / K
+        cells, pairs = agg["dp_cells"] / K, agg["chain_pairs"] / K
+        # algorithmic bytes per launch
+        seed_bytes = 16 * n_mz + 16 * n_hit + 8 * n_am + 16 * n_a
+        seed_ms = kern_ms["seed_lookup"] + kern_ms["seed_expand"]
+        dp_bytes = cells                                                   # 1 B/cell direction matrix written to HBM
+        chain_bytes = 36 * n_a
+        cand = {
+            "k_ksw_extd2": (dp_bytes, kern_ms["dp"], "1 B/cell backtrack write x %.3g cells per launch group" % cells),
+            "k_seed_lookup+k_seed_expand": (seed_bytes, seed_ms, "16*n_mz+16*n_hit+8*n_a_multi+16*n_a"),
+            "k_chain": (chain_bytes, kern_ms["chain"], "16*n_a read + 20*n_a written"),
+        }
+        dom = max(cand, key=lambda k: cand[k][1])
+        roof = {}
+        for k, (b, ms, how) in cand.items():
+            ach = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            roof[k] = dict(bound="hbm", achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                           traffic=None, kernel=k, ms_per_launch=round(ms, 4), algorithmic_bytes=int(b), formula=how)
+        out = {
+            "metric": "aligned Mbases/sec, synthetic ONT reads, map-ont, MI355X",
+            "value": round(aligned_all / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/int32 (+f32 chaining gap cost)", "data": "synthetic",
+            "config": dict(workload=wl["workload"], reads_per_step_per_gpu=len(reads), mbases_per_step_per_gpu=round(n_bases / 1e6, 3),
+                           preset=wl["preset"], parallelism="reads sharded over %d GPU(s), index replicated, no collective" % world),
+            "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
+            "pcie_inclusive_mbases_per_s": round(n_bases / dt_pcie / 1e6, 3),
+            "roofline": roof[dom], "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
+            "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
+                                      n_dp_jobs=int(agg["n_dp_jobs"] / K)),
+        }
+        if not args.no_cpu:
+            import tempfile
+            with tempfile.TemporaryDirectory() as td:
+                fa = os.path.join(td, "ref.fa")
+                S.write_fasta(fa, g, names)
+                out["cpu_baseline"] = cpu_baseline(fa, wl["preset"], reads, args.cpu_seconds, min(16, os.cpu_count() or 1))
+        print(json.dumps(out), flush=True)
+    barrier()
+    L.mm355_ctx_destroy(ctx)
+    L.mm355_index_free(idx)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

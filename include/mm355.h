@@ -120,6 +120,10 @@ void mm355_ctx_destroy(mm355_ctx_t *ctx);
 #define MM355_OUT_MD 2
 int mm355_map_batch(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
                     const int32_t *lens, int flags, mm355_hits_t **out);
+/* the same call split in two, for callers that keep a batch resident in HBM (bench.py times mm355_map_resident):
+ * mm355_map_batch == mm355_batch_upload + mm355_map_resident */
+int mm355_batch_upload(mm355_ctx_t *ctx, int64_t n_reads, const char *const *seqs, const int32_t *lens);
+int mm355_map_resident(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int flags, mm355_hits_t **out);
 void mm355_free_hits(mm355_hits_t *hits);
 
 /* --- per-stage entry points (same kernels as mm355_map_batch; used by the parity tests and

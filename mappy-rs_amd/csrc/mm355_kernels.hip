@@ -19,6 +19,21 @@
 #define LANE_LT_MASK(lane) ((lane) == 0? 0ULL : (~0ULL >> (64 - (lane))))
 
 // ------------------------------------------------------------------ a1: sketch
+// mm_sketch is a sequential state machine (ring of the last w k-mer records, rightmost minimum, run length l since
+// the last ambiguous base).  Its state after base i is a pure function of a bounded suffix of the read, so a read is
+// cut into chunks of SK_CHUNK bases and every chunk is sketched by its own lane:
+//   * the lane starts `warm` bases before its chunk with an empty machine and PROVES, while running, that by the time
+//     it reaches its first owned base the machine state equals the sequential one: both k-mers hold k real bases
+//     (j*), then either an ambiguous base resets l on both sides or >= w+k k-mers were counted (every test on l is
+//     saturated), then w ring writes happened (ring and rightmost minimum are then functions of exact records only);
+//     if the proof is not complete at the chunk start the lane retries with a 4x longer warm-up (0 = read start, which
+//     is exact by definition);
+//   * a lane emits only minimizers whose own position lies in its chunk, and runs past the chunk end until w ring
+//     writes lie beyond it (no record of the chunk can be emitted later); only the lane that reaches the end of the
+//     read performs the final flush.
+// mm_sketch emits minimizers in increasing position, so chunk outputs concatenated in chunk order are the sequential
+// output.  k_sketch_compact then packs the chunk outputs of a read to the front of its slot range.
+#define SK_CHUNK 384
 struct BaseReader {
 	const uint8_t *s; uint64_t wd; int wi;
 	__device__ int operator()(int i) {
@@ -28,18 +43,115 @@ struct BaseReader {
 	}
 };
 
-__global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSeeds sd)
+__device__ int sketch_chunk(const uint8_t *seq, int len, int w, int k, int cs, int ce, mm128 *out, mm128 *buf, int bstride)
+{
+	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+#define BUF(j) buf[(j) * bstride]
+	int warm = 2 * (w + k) + 2 * w + 24;
+	for (;;) {
+		int s0 = cs - warm;
+		if (s0 < 0) s0 = 0;
+		const bool from_start = s0 == 0;
+		BaseReader get = { seq, 0, -1 };
+		uint64_t kmer[2] = {0, 0};
+		int i, j, l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0, n = 0;
+		mm128 min = { UINT64_MAX, UINT64_MAX };
+		for (j = 0; j < w; ++j) BUF(j).x = BUF(j).y = UINT64_MAX;
+		// proof state
+		int n_real = 0, cnt_c = 0, writes_ok = 0, writes_after = 0;
+		bool jstar = from_start, seen_n = false, ok = from_start, trust = from_start, retry = false;
+#define MM_EMIT(v) do { uint32_t pp_ = (uint32_t)(v).y >> 1; if ((int)pp_ >= cs && (int)pp_ < ce) out[n++] = (v); } while (0)
+		for (i = s0; i < len; ++i) {
+			if (i == cs && !trust) { retry = true; break; }
+			int c = get(i);
+			mm128 info = { UINT64_MAX, UINT64_MAX };
+			if (c < 4) {
+				int z;
+				if (!jstar && ++n_real >= k) jstar = true;
+				kmer_span = l + 1 < k? l + 1 : k;
+				kmer[0] = (kmer[0] << 2 | c) & mask;
+				kmer[1] = (kmer[1] >> 2) | (3ULL^c) << shift1;
+				if (kmer[0] == kmer[1]) continue;
+				z = kmer[0] < kmer[1]? 0 : 1;
+				++l;
+				if (jstar) ++cnt_c;
+				if (l >= k && kmer_span < 256) {
+					info.x = mm_hash64(kmer[z], mask) << 8 | kmer_span;
+					info.y = (uint64_t)(uint32_t)i << 1 | z;
+				}
+			} else { l = 0, kmer_span = 0; if (jstar) seen_n = true; }
+			if (!ok) ok = jstar && (seen_n || cnt_c >= w + k);
+			if (ok && !trust) { if (++writes_ok > w) trust = true; }   // this write and w earlier ones are exact
+			BUF(buf_pos) = info;
+			if (l == w + k - 1 && min.x != UINT64_MAX) {
+				for (j = buf_pos + 1; j < w; ++j)
+					if (min.x == BUF(j).x && BUF(j).y != min.y) MM_EMIT(BUF(j));
+				for (j = 0; j < buf_pos; ++j)
+					if (min.x == BUF(j).x && BUF(j).y != min.y) MM_EMIT(BUF(j));
+			}
+			if (info.x <= min.x) {
+				if (l >= w + k && min.x != UINT64_MAX) MM_EMIT(min);
+				min = info, min_pos = buf_pos;
+			} else if (buf_pos == min_pos) {
+				if (l >= w + k - 1 && min.x != UINT64_MAX) MM_EMIT(min);
+				for (j = buf_pos + 1, min.x = UINT64_MAX; j < w; ++j)
+					if (min.x >= BUF(j).x) min = BUF(j), min_pos = j;
+				for (j = 0; j <= buf_pos; ++j)
+					if (min.x >= BUF(j).x) min = BUF(j), min_pos = j;
+				if (l >= w + k - 1 && min.x != UINT64_MAX) {
+					for (j = buf_pos + 1; j < w; ++j)
+						if (min.x == BUF(j).x && min.y != BUF(j).y) MM_EMIT(BUF(j));
+					for (j = 0; j <= buf_pos; ++j)
+						if (min.x == BUF(j).x && min.y != BUF(j).y) MM_EMIT(BUF(j));
+				}
+			}
+			if (++buf_pos == w) buf_pos = 0;
+			if (i >= ce && ++writes_after >= w) break;   // every ring record now lies beyond the chunk
+		}
+		if (retry) { warm = from_start? warm : warm * 4; continue; }
+		if (i >= len && min.x != UINT64_MAX) MM_EMIT(min);   // the sequential final flush
+#undef MM_EMIT
+#undef BUF
+		return n;
+	}
+}
+
+__global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
 {
 	extern __shared__ mm128 ring[];   // w entries per lane, lane-interleaved
 	int t = blockIdx.x * WAVE + threadIdx.x;
-	if (t >= bt.n_reads) return;
-	int r = bt.order[t];
-	int len = bt.rlen[r];
-	int64_t off = bt.roff[r];
-	BaseReader rd = { bt.seq + off, 0, -1 };
-	int64_t n = 0;
-	if (len > 0) n = mm_sketch_seq(rd, len, ix.w, ix.k, 0u, sd.mz + off, (int64_t)len, ring + threadIdx.x, WAVE);
-	sd.n_mz[r] = (int32_t)n;
+	if (t >= n_chunks) return;
+	const int r = chunk_read[t], cs = chunk_start[t];
+	const int len = bt.rlen[r];
+	const int64_t off = bt.roff[r];
+	int ce = cs + SK_CHUNK;
+	if (ce > len) ce = len;
+	chunk_n[t] = sketch_chunk(bt.seq + off, len, ix.w, ix.k, cs, ce, sd.mz + off + cs, ring + threadIdx.x, WAVE);
+}
+
+// packs the per-chunk outputs of a read to the front of its slot range (in place; destination never passes the source)
+__global__ __launch_bounds__(WAVE) void k_sketch_compact(DevBatch bt, DevSeeds sd, const int64_t *read_chunk0, const int32_t *chunk_n)
+{
+	const int r = blockIdx.x, lane = threadIdx.x;
+	const int len = bt.rlen[r];
+	const int64_t off = bt.roff[r], c0 = read_chunk0[r];
+	const int nch = (len + SK_CHUNK - 1) / SK_CHUNK;
+	mm128 *mz = sd.mz + off;
+	int m = 0;
+	for (int c = 0; c < nch; ++c) {
+		const int n = chunk_n[c0 + c], src = c * SK_CHUNK;
+		if (m != src) {
+			for (int b = 0; b < n; b += WAVE) {
+				mm128 v; v.x = v.y = 0;
+				if (b + lane < n) v = mz[src + b + lane];
+				__syncthreads();
+				if (b + lane < n) mz[m + b + lane] = v;
+				__syncthreads();
+			}
+		}
+		m += n;
+	}
+	if (lane == 0) sd.n_mz[r] = m;
 }
 
 // ------------------------------------------------------------------ literal radix_sort_128x, one wave
@@ -594,12 +706,17 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 }
 
 // ------------------------------------------------------------------ launchers
-void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
+int mm355_sketch_chunk_size(void) { return SK_CHUNK; }
+void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
+                         const int64_t *read_chunk0, int32_t *chunk_n, hipStream_t st)
 {
 	if (bt.n_reads == 0) return;
-	int blocks = (bt.n_reads + WAVE - 1) / WAVE;
-	size_t lds = (size_t)ix.w * WAVE * sizeof(mm128);
-	hipLaunchKernelGGL(k_sketch, dim3(blocks), dim3(WAVE), lds, st, ix, bt, sd);
+	if (n_chunks > 0) {
+		int blocks = (n_chunks + WAVE - 1) / WAVE;
+		size_t lds = (size_t)ix.w * WAVE * sizeof(mm128);
+		hipLaunchKernelGGL(k_sketch, dim3(blocks), dim3(WAVE), lds, st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+	}
+	hipLaunchKernelGGL(k_sketch_compact, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, sd, read_chunk0, chunk_n);
 }
 void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
 {

@@ -21,7 +21,7 @@ struct DBuf {
 struct HostBatch {            // packed reads of one sub-batch
 	int64_t n_reads = 0, n_bytes = 0, n_bases = 0;
 	std::vector<uint8_t> seq; std::vector<int64_t> roff; std::vector<int32_t> rlen, order;
-	std::vector<int32_t> n_mz, n_a, rep_len, n_mini, n_u, n_v;
+	std::vector<int32_t> n_mz, n_a, rep_len, n_mini, n_u, n_v, status;
 	std::vector<int64_t> aoff;
 	int64_t tot_a = 0;
 };
@@ -33,7 +33,8 @@ struct mm355_ctx {
 	DevIndex dix;
 	DBuf ix_slots, ix_pos, ix_S, ix_off, ix_len;
 	// per-batch device buffers
-	DBuf seq, roff, rlen, order;
+	DBuf seq, roff, rlen, order, ck_read, ck_start, ck_n, ck_r0;
+	int64_t n_chunks = 0;
 	DBuf mz, mz_tmp, n_mz, sn, sv, sflt, hl, soff, n_a, rep_len, n_mini, mini_pos, counters, err;
 	DBuf aoff, a, f, p, v, z, t8, vi, b, wk, u, u2, n_u, n_v;
 	// dp buffers
@@ -48,6 +49,7 @@ DevParams mm355_make_params(const mm355_mapopt_t *mo, const mm355_index *mi);
 int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi);
 
 // stage drivers (each leaves its outputs resident on the device and the per-read counts in ctx->hb)
+extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int flags, mm355_hits_t **out);
 int mm355_run_pack(mm355_ctx *ctx, int64_t n_reads, const char *const *seqs, const int32_t *lens);
 int mm355_run_sketch(mm355_ctx *ctx);
 int mm355_run_seeds(mm355_ctx *ctx, const DevParams &pr);                  // mz_flt + lookup + select (+ D2H counts, anchor offsets)

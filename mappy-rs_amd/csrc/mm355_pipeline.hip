@@ -77,7 +77,7 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 {
 	if (c == 0) return;
 	(void)hipSetDevice(c->dev);
-	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->seq, &c->roff, &c->rlen, &c->order,
+	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
 		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq };
@@ -143,13 +143,30 @@ int mm355_run_pack(mm355_ctx *c, int64_t n_reads, const char *const *seqs, const
 	HIPCHK(hipMemsetAsync(c->counters.p, 0, 64, c->st));
 	HIPCHK(hipMemsetAsync(c->err.p, 0, 16, c->st));
 	c->stats.n_reads = n_reads; c->stats.n_bases = bases;
+	{   // chunk table of the sketch kernel: longest reads first so that a wave holds chunks of similar cost
+		const int CH = mm355_sketch_chunk_size();
+		std::vector<int32_t> cr, cst; std::vector<int64_t> r0(nr, 0);
+		int64_t nc = 0;
+		for (int64_t i = 0; i < n_reads; ++i) { r0[i] = nc; nc += (lens[i] + CH - 1) / CH; }
+		cr.reserve(nc); cst.reserve(nc);
+		for (int64_t i = 0; i < n_reads; ++i) for (int32_t s0 = 0; s0 < lens[i]; s0 += CH) { cr.push_back((int32_t)i); cst.push_back(s0); }
+		c->n_chunks = nc;
+		if (c->ck_read.ensure((nc + 1) * 4) || c->ck_start.ensure((nc + 1) * 4) || c->ck_n.ensure((nc + 1) * 4) || c->ck_r0.ensure(nr * 8)) return MM355_ENOMEM;
+		if (nc) {
+			HIPCHK(hipMemcpyAsync(c->ck_read.p, cr.data(), nc * 4, hipMemcpyHostToDevice, c->st));
+			HIPCHK(hipMemcpyAsync(c->ck_start.p, cst.data(), nc * 4, hipMemcpyHostToDevice, c->st));
+		}
+		HIPCHK(hipMemcpyAsync(c->ck_r0.p, r0.data(), nr * 8, hipMemcpyHostToDevice, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));   // the staging vectors above are about to go out of scope
+	}
 	return 0;
 }
 
 int mm355_run_sketch(mm355_ctx *c)
 {
 	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c);
-	{ EvTimer t(c, &c->stats.ms_sketch); mm355_launch_sketch(c->dix, b, s, c->st); }
+	{ EvTimer t(c, &c->stats.ms_sketch); mm355_launch_sketch(c->dix, b, s, c->ck_read.as<int32_t>(), c->ck_start.as<int32_t>(), (int)c->n_chunks,
+	                                                         c->ck_r0.as<int64_t>(), c->ck_n.as<int32_t>(), c->st); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }

@@ -114,3 +114,29 @@ def test_hifi_preset_parity(built, tmp_path):
         eu, eb = orc.chains(ea, len(rd))
         assert np.array_equal(got[i][0], eu) and np.array_equal(got[i][1], eb)
     sr.close()
+
+
+def test_chunked_sketch_adversarial(built, tmp_path):
+    """the chunked sketch kernel must equal the sequential machine on inputs that stress its warm-up proof:
+    even k (symmetric k-mers are skipped without advancing the ring), N every few bases, long N runs, homopolymers,
+    palindromic repeats, and reads around the chunk size"""
+    import mappy_rs
+    rng = np.random.default_rng(11)
+    g = S.make_genome(71, [60000], repeats=())
+    fa = str(tmp_path / "s.fa")
+    S.write_fasta(fa, g, ["c"])
+    base = S.codes_to_str(g[0][:20000])
+    pal = "ACGT" * 300 + "AT" * 500 + "GATC" * 200
+    sparse_n = "".join(c if i % 9 else "N" for i, c in enumerate(base[:6000]))
+    runs = base[:1000] + "N" * 700 + base[1000:1400] + "N" * 33 + base[1400:3000]
+    reads = [base, pal, sparse_n, runs, "A" * 3000, "N" * 2000 + base[:900], base[:383], base[:384], base[:385], base[:769],
+             pal + base[:2000] + pal, S.codes_to_str(S.random_codes(rng, 5000, gc=0.1))]
+    for k, w in ((15, 10), (14, 8), (19, 19), (16, 5), (21, 11)):
+        al = mappy_rs.Aligner(fa, k=k, w=w)
+        orc = O.OracleAligner(fa, k=k, w=w)
+        sr = al._stage_runner()
+        got = sr.sketch(reads)
+        for i, rd in enumerate(reads):
+            exp = orc.sketch(rd)
+            assert got[i].shape == exp.shape and np.array_equal(got[i], exp), (k, w, i)
+        sr.close()
