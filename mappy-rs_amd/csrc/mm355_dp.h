@@ -28,6 +28,6 @@ struct DpGather {           // where the code strings of a job come from
 
 DpConst mm355_dp_const(const mm355_mapopt_t *mo);
 int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
-                 std::vector<mm355_dpres_t> &res, std::vector<uint32_t> &cigar);
+                 const mm355_dpres_t **res_out, const uint32_t **cigar_out);   // results live in pinned host buffers of the context
 int mm355_dp_gather(mm355_ctx *c, const std::vector<DpGather> &g, size_t q_tot, size_t t_tot);
 int mm355_run_read_codes(mm355_ctx *c);

@@ -58,9 +58,10 @@ __device__ inline int8_t SB(uint64_t w, int i) { return (int8_t)(w >> (8 * i)); 
 __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
                                                     const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, int32_t *offbase,
                                                     uint32_t *cigbase, uint64_t *stbase, int32_t *Hbase, mm355_dpres_t *res,
-                                                    int lds_cap, unsigned long long *cells_ctr)
+                                                    int lds_cap, unsigned long long *cells_ctr, uint32_t *dense, unsigned long long *dense_ctr)
 {
-	extern __shared__ uint64_t lds[];   // [lds_cap] state words, then [lds_cap] int32 H
+	extern __shared__ uint64_t lds[];
+	__shared__ long long s_dst; __shared__ int s_nc;   // [lds_cap] state words, then [lds_cap] int32 H
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_jobs) return;
 	const int jid = job_ids[blockIdx.x];
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 	if (qlen <= 0 || tlen <= 0 || jb.skip) {   // skip: tlen*qlen > max_sw_mat => treated as z-dropped by mm_align_pair
 		if (lane == 0) {
 			mm355_dpres_t o; o.max = 0; o.zdropped = jb.skip? 1 : 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1;
-			o.mqe = o.mte = o.score = KSW_NEG_INF; o.reach_end = 0; o.n_cigar = 0; o.cigar_off = jb.cig_off;
+			o.mqe = o.mte = o.score = KSW_NEG_INF; o.reach_end = 0; o.n_cigar = 0; o.cigar_off = 0;
 			res[jid] = o;
 		}
 		return;
@@ -290,10 +291,15 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 		}
 		mm355_dpres_t o;
 		o.max = ez.max; o.zdropped = ez.zdropped; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe = ez.mqe; o.mqe_t = ez.mqe_t;
-		o.mte = ez.mte; o.mte_q = ez.mte_q; o.score = ez.score; o.reach_end = ez.reach_end; o.n_cigar = n_cigar; o.cigar_off = jb.cig_off;
+		o.mte = ez.mte; o.mte_q = ez.mte_q; o.score = ez.score; o.reach_end = ez.reach_end; o.n_cigar = n_cigar;
+		s_dst = (long long)atomicAdd(dense_ctr, (unsigned long long)n_cigar);   // dense CIGAR arena: only real ops travel to the host
+		s_nc = n_cigar;
+		o.cigar_off = s_dst;
 		res[jid] = o;
 		if (cells) atomicAdd(cells_ctr, cells);
 	}
+	__syncthreads();
+	for (int i = lane; i < s_nc; i += WAVE) dense[s_dst + i] = cigar[i];
 }
 
 // gather kernel: materialise query / target code strings of each job (optionally reversed) from the read batch and
@@ -351,11 +357,11 @@ DpConst mm355_dp_const(const mm355_mapopt_t *mo)
 
 // runs jobs whose code strings are already on the device (qbuf/tbuf); fills res[] and the cigar arena (host copies)
 int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
-                 std::vector<mm355_dpres_t> &res, std::vector<uint32_t> &cigar)
+                 const mm355_dpres_t **res_out, const uint32_t **cigar_out)
 {
 	const size_t n = jobs.size();
-	res.resize(n);
-	if (n == 0) { cigar.clear(); return 0; }
+	*res_out = 0; *cigar_out = 0;
+	if (n == 0) return 0;
 	DpConst dc = mm355_dp_const(mo);
 	// lay out per-job work areas
 	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
@@ -378,13 +384,15 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 		} else ids[0].push_back((int32_t)i);
 	}
 	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64) ||
-	    c->dp_work.ensure((off_tot + 16) * 4 + (n + 16) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_H.ensure((st_tot + 16) * 12)) return MM355_ENOMEM;
+	    c->dp_work.ensure((off_tot + 16) * 4 + (n + 16) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_dense.ensure((cig_tot + 16) * 4) ||
+	    c->dp_H.ensure((st_tot + 16) * 12)) return MM355_ENOMEM;
 	HIPCHK(hipMemcpyAsync(c->dp_jobs.p, jobs.data(), n * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
 	int32_t *d_off = c->dp_work.as<int32_t>();
 	int32_t *d_ids = d_off + off_tot + 16;
 	uint64_t *d_S = c->dp_H.as<uint64_t>();
 	int32_t *d_H = (int32_t*)(d_S + st_tot + 8);
-	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4;
+	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4, *d_dense = c->counters.as<unsigned long long>() + 5;
+	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
 		size_t done = 0;
@@ -395,32 +403,34 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 			size_t lds = (size_t)cap * 12;
 			hipLaunchKernelGGL(k_ksw_extd2, dim3((unsigned)ids[cls].size()), dim3(WAVE), lds, c->st, dc, c->dp_jobs.as<DpJobDev>(), d_ids + done,
 			                   (int)ids[cls].size(), d_q, d_t, c->dp_bt.as<uint8_t>(), d_off, c->dp_cig.as<uint32_t>(), d_S, d_H,
-			                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells);
+			                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
 			done += ids[cls].size();
 		}
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipMemcpyAsync(res.data(), c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
-	cigar.resize(cig_tot + 1);
-	if (cig_tot) HIPCHK(hipMemcpyAsync(cigar.data(), c->dp_cig.p, cig_tot * 4, hipMemcpyDeviceToHost, c->st));
-	unsigned long long cells = 0;
-	HIPCHK(hipMemcpyAsync(&cells, d_cells, 8, hipMemcpyDeviceToHost, c->st));
+	unsigned long long ctr[2] = {0, 0};
+	HIPCHK(hipMemcpyAsync(ctr, d_cells, 16, hipMemcpyDeviceToHost, c->st));
+	if (c->h_res.ensure(n * sizeof(mm355_dpres_t))) return MM355_ENOMEM;
+	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
-	c->stats.dp_cells = (int64_t)cells; c->stats.n_dp_jobs += (int64_t)n;
+	const size_t n_dense = (size_t)ctr[1];
+	if (c->h_cig.ensure((n_dense + 16) * 4)) return MM355_ENOMEM;
+	if (n_dense) HIPCHK(hipMemcpyAsync(c->h_cig.p, c->dp_dense.p, n_dense * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipStreamSynchronize(c->st));
+	c->stats.dp_cells = (int64_t)ctr[0]; c->stats.n_dp_jobs += (int64_t)n;
+	*res_out = (const mm355_dpres_t*)c->h_res.p; *cigar_out = (const uint32_t*)c->h_cig.p;
 	return 0;
 }
 
 int mm355_dp_gather(mm355_ctx *c, const std::vector<DpGather> &g, size_t q_tot, size_t t_tot)
 {
 	if (g.empty()) return 0;
-	if (c->dp_q.ensure(q_tot + 64) || c->dp_t.ensure(t_tot + 64) || c->dp_jobs.ensure(g.size() * sizeof(DpGather))) return MM355_ENOMEM;
-	// reuse dp_res as the staging area for the gather descriptors
-	if (c->dp_res.ensure(g.size() * sizeof(DpGather))) return MM355_ENOMEM;
-	HIPCHK(hipMemcpyAsync(c->dp_res.p, g.data(), g.size() * sizeof(DpGather), hipMemcpyHostToDevice, c->st));
-	hipLaunchKernelGGL(k_dp_gather, dim3((unsigned)g.size()), dim3(256), 0, c->st, c->dix, c->dp_res.as<DpGather>(), (int)g.size(),
+	if (c->dp_q.ensure(q_tot + 64) || c->dp_t.ensure(t_tot + 64) || c->dp_gather.ensure(g.size() * sizeof(DpGather))) return MM355_ENOMEM;
+	HIPCHK(hipMemcpyAsync(c->dp_gather.p, g.data(), g.size() * sizeof(DpGather), hipMemcpyHostToDevice, c->st));
+	hipLaunchKernelGGL(k_dp_gather, dim3((unsigned)g.size()), dim3(256), 0, c->st, c->dix, c->dp_gather.as<DpGather>(), (int)g.size(),
 	                   c->rq.as<uint8_t>(), c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>());
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipStreamSynchronize(c->st));   // dp_res is reused by mm355_dp_run
+	HIPCHK(hipStreamSynchronize(c->st));   // g (pageable) may go out of scope at the caller
 	return 0;
 }
 
@@ -452,14 +462,14 @@ extern "C" int mm355_stage_dp(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t 
 		dj[i].qlen = jobs[i].qlen; dj[i].tlen = jobs[i].tlen; dj[i].qoff = jobs[i].qoff; dj[i].toff = jobs[i].toff;
 		dj[i].w = jobs[i].w; dj[i].zdrop = jobs[i].zdrop; dj[i].end_bonus = jobs[i].end_bonus; dj[i].flag = jobs[i].flag;
 	}
-	std::vector<mm355_dpres_t> r; std::vector<uint32_t> cg;
-	int rc = mm355_dp_run(c, mo, dj, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), r, cg);
+	const mm355_dpres_t *r = 0; const uint32_t *cg = 0;
+	int rc = mm355_dp_run(c, mo, dj, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), &r, &cg);
 	if (rc) return rc;
 	int64_t tot = 0;
 	for (int64_t i = 0; i < n_jobs; ++i) {
 		res[i] = r[i];
 		if (tot + r[i].n_cigar > cigar_cap) return MM355_ENOMEM;
-		memcpy(cigar + tot, cg.data() + r[i].cigar_off, (size_t)r[i].n_cigar * 4);
+		if (r[i].n_cigar) memcpy(cigar + tot, cg + r[i].cigar_off, (size_t)r[i].n_cigar * 4);
 		res[i].cigar_off = tot; tot += r[i].n_cigar;
 	}
 	return 0;

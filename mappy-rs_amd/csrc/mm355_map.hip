@@ -47,10 +47,11 @@ static int host_threads()
 	const char *e = getenv("MM355_HOST_THREADS");
 	int n = e? atoi(e) : (int)std::thread::hardware_concurrency();
 	if (n < 1) n = 1;
-	if (n > 32) n = 32;
+	if (n > 16) n = 16;   // the GPU box gives one GPU a 16-core CPU share
 	return n;
 }
 
+static int host_threads();
 static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<ReadState> &rs, const std::vector<DpReq> &reqs)
 {
 	// chunk the requests so that the direction matrices of one launch fit the HBM budget
@@ -81,21 +82,26 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 			jobs.push_back(jd);
 			q_tot += (size_t)gg.qlen + 16; t_tot += (size_t)gg.tlen + 16; p_tot += pb;
 		}
+		const double tg0 = now_ms();
 		int rc = mm355_dp_gather(c, g, q_tot, t_tot);
 		if (rc) return rc;
-		std::vector<mm355_dpres_t> res; std::vector<uint32_t> cig;
-		rc = mm355_dp_run(c, mo, jobs, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), res, cig);
+		const double tg1 = now_ms();
+		const mm355_dpres_t *res = 0; const uint32_t *cig = 0;
+		rc = mm355_dp_run(c, mo, jobs, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), &res, &cig);
 		if (rc) return rc;
-		for (size_t k = i; k < j; ++k) {
+		const double tr1 = now_ms();
+		parallel_for((int64_t)(j - i), host_threads(), [&](int64_t kk, int) {   // distinct (read, task, slot) per request: no sharing
+			const size_t k = i + (size_t)kk;
 			const DpReq &q = reqs[k];
 			const mm355_dpres_t &r = res[k - i];
 			AlnTask &T = rs[q.read].tasks[q.task];
 			EzRes &e = q.slot >= 0? T.res[q.slot] : T.inv_res;
 			e.max = r.max; e.zdropped = r.zdropped; e.max_q = r.max_q; e.max_t = r.max_t; e.mqe = r.mqe; e.mqe_t = r.mqe_t;
 			e.mte = r.mte; e.mte_q = r.mte_q; e.score = r.score; e.reach_end = r.reach_end;
-			e.cigar.assign(cig.begin() + r.cigar_off, cig.begin() + r.cigar_off + r.n_cigar);
+			e.cigar.assign(cig + r.cigar_off, cig + r.cigar_off + r.n_cigar);
 			e.state = 2;
-		}
+		});
+		if (getenv("MM355_VERBOSE")) fprintf(stderr, "[mm355]     dp chunk: %zu jobs, gather %.1f ms, run %.1f ms, distribute %.1f ms\n", j - i, tg1 - tg0, tr1 - tg1, now_ms() - tr1);
 		i = j;
 	}
 	return 0;
@@ -142,6 +148,8 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	for (int64_t i = 0; i < n_reads; ++i) if (mo->max_qlen > 0 && dl[i] > mo->max_qlen) dl[i] = 0;
 	std::vector<const char*> seqs(n_reads);
 	for (int64_t i = 0; i < n_reads; ++i) seqs[i] = (const char*)&c->hb.seq[c->hb.roff[i]];
+	const bool verbose = getenv("MM355_VERBOSE") != 0;
+	double tv0 = now_ms(), tv_front, tv_pack, tv_pre, tv_steps = 0, tv_dp = 0, tv_fin, tv_asm;
 	if ((rc = mm355_run_sketch(c))) return rc;
 	if ((rc = mm355_run_seeds(c, pr))) return rc;
 	if ((rc = mm355_run_expand(c, pr))) return rc;
@@ -150,17 +158,19 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	if ((rc = mm355_run_backtrack(c, pr))) return rc;
 	if ((rc = mm355_run_read_codes(c))) return rc;
 	HostBatch &hb = c->hb;
+	tv_front = now_ms() - tv0; tv0 = now_ms();
 	// pack chains / anchors / mini_pos and bring them to the host
 	std::vector<int64_t> uo(n_reads + 1), vo(n_reads + 1), mo_(n_reads + 1);
 	int64_t tu = 0, tv = 0, tm = 0;
 	for (int64_t i = 0; i < n_reads; ++i) { uo[i] = tu; vo[i] = tv; mo_[i] = tm; tu += hb.n_u[i]; tv += hb.n_v[i]; tm += hb.n_mini[i]; }
 	uo[n_reads] = tu; vo[n_reads] = tv; mo_[n_reads] = tm;
-	std::vector<uint64_t> pu(tu + 1), pm(tm + 1); std::vector<mm128> pa(tv + 1);
+	if (c->h_pu.ensure((size_t)(tu + 1) * 8) || c->h_pm.ensure((size_t)(tm + 1) * 8) || c->h_pa.ensure((size_t)(tv + 1) * 16)) return MM355_ENOMEM;
+	uint64_t *pu = (uint64_t*)c->h_pu.p, *pm = (uint64_t*)c->h_pm.p; mm128 *pa = (mm128*)c->h_pa.p;
 	if (n_reads) {
 		DBuf &scr = c->b;   // b[] (compact_a scratch) is free again: reuse it for the packed copies
 		const size_t nr2 = ((size_t)n_reads + 2) & ~(size_t)1, tu2 = ((size_t)tu + 1) & ~(size_t)1;   // keep every sub-array 16-B aligned
 		size_t need = nr2 * 8 * 3 + tu2 * 8 + (size_t)tv * 16 + (size_t)tm * 8 + 256;
-		DBuf pack; if (pack.ensure(need)) return MM355_ENOMEM;
+		DBuf &pack = c->pack; if (pack.ensure(need)) return MM355_ENOMEM;
 		(void)scr;
 		int64_t *d_uo = pack.as<int64_t>(), *d_vo = d_uo + nr2, *d_mo = d_vo + nr2;
 		uint64_t *d_pu = (uint64_t*)(d_mo + nr2); mm128 *d_pa = (mm128*)(d_pu + tu2); uint64_t *d_pm = (uint64_t*)(d_pa + tv);
@@ -171,24 +181,26 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		                   c->n_u.as<int32_t>(), c->n_v.as<int32_t>(), c->n_mini.as<int32_t>(), d_uo, d_vo, d_mo, c->u.as<uint64_t>(), c->a.as<mm128>(),
 		                   c->mini_pos.as<uint64_t>(), d_pu, d_pa, d_pm);
 		HIPCHK(hipGetLastError());
-		if (tu) HIPCHK(hipMemcpyAsync(pu.data(), d_pu, (size_t)tu * 8, hipMemcpyDeviceToHost, c->st));
-		if (tv) HIPCHK(hipMemcpyAsync(pa.data(), d_pa, (size_t)tv * 16, hipMemcpyDeviceToHost, c->st));
-		if (tm) HIPCHK(hipMemcpyAsync(pm.data(), d_pm, (size_t)tm * 8, hipMemcpyDeviceToHost, c->st));
+		if (tu) HIPCHK(hipMemcpyAsync(pu, d_pu, (size_t)tu * 8, hipMemcpyDeviceToHost, c->st));
+		if (tv) HIPCHK(hipMemcpyAsync(pa, d_pa, (size_t)tv * 16, hipMemcpyDeviceToHost, c->st));
+		if (tm) HIPCHK(hipMemcpyAsync(pm, d_pm, (size_t)tm * 8, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));
-		pack.release();
 	}
+	tv_pack = now_ms() - tv0; tv0 = now_ms();
 	const double t_host0 = now_ms();
 	const int nt = host_threads();
 	std::vector<ReadState> rs(n_reads);
 	parallel_for(n_reads, nt, [&](int64_t i, int) {
 		ReadState &r = rs[i];
 		r.qlen = dl[i]; r.seq = seqs[i]; r.rep_len = hb.rep_len[i];
-		r.u.assign(pu.begin() + uo[i], pu.begin() + uo[i + 1]);
-		r.a.assign(pa.begin() + vo[i], pa.begin() + vo[i + 1]);
-		r.mini_pos.assign(pm.begin() + mo_[i], pm.begin() + mo_[i + 1]);
+		r.u.assign(pu + uo[i], pu + uo[i + 1]);
+		r.a.assign(pa + vo[i], pa + vo[i + 1]);
+		r.mini_pos.assign(pm + mo_[i], pm + mo_[i + 1]);
 		if (r.qlen > 0) mm355_glue_pre_align(mi, mo, r); else r.aligned = true;
 	});
 	double ms_host = now_ms() - t_host0;
+	tv_pre = now_ms() - tv0;
+	int n_rounds = 0;
 	// extension rounds: every pending problem of every read goes into the same launches
 	for (int round = 0; round < 64; ++round) {
 		const double th0 = now_ms();
@@ -200,9 +212,13 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		std::vector<DpReq> reqs;
 		for (auto &v : treq) reqs.insert(reqs.end(), v.begin(), v.end());
 		ms_host += now_ms() - th0;
+		tv_steps += now_ms() - th0;
 		if (n_open.load() == 0) break;
 		if (reqs.empty()) return MM355_EINVAL;   // a read is waiting for a result nobody requested: logic error
+		const double td0 = now_ms();
 		if ((rc = run_dp_round(c, mo, rs, reqs))) return rc;
+		tv_dp += now_ms() - td0; ++n_rounds;
+		if (verbose) fprintf(stderr, "[mm355]   round %d: %zu jobs, %lld reads open\n", round, reqs.size(), (long long)n_open.load());
 	}
 	const double th1 = now_ms();
 	std::vector<std::vector<mm355_hit_t>> rh(n_reads);
@@ -212,6 +228,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		if (rs[i].qlen > 0) mm355_glue_finish(mi, mo, rs[i], flags, rh[i], rc_[i], rstr[i]);
 		mm355_glue_release(rs[i]);
 	});
+	tv_fin = now_ms() - th1; tv0 = now_ms();
 	mm355_hits_t *H = (mm355_hits_t*)calloc(1, sizeof(mm355_hits_t));
 	H->n_reads = n_reads;
 	H->hit_off = (int64_t*)malloc((n_reads + 1) * 8);
@@ -235,6 +252,9 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		nc += (int64_t)rc_[i].size(); ns += (int64_t)rstr[i].size();
 	}
 	ms_host += now_ms() - th1;
+	tv_asm = now_ms() - tv0;
+	if (verbose) fprintf(stderr, "[mm355] map_resident: front %.1f ms | pack+d2h %.1f | pre_align %.1f | align_steps %.1f | dp rounds(%d) %.1f (kernel %.1f) | finish %.1f | assemble %.1f | total %.1f\n",
+	                     tv_front, tv_pack, tv_pre, tv_steps, n_rounds, tv_dp, c->stats.ms_dp, tv_fin, tv_asm, now_ms() - t_start);
 	c->stats.ms_host = ms_host;
 	c->stats.ms_total = now_ms() - t_start;
 	*out = H;

@@ -18,6 +18,18 @@ struct DBuf {
 	template <typename T> T *as() const { return (T*)p; }
 };
 
+struct HBuf {                 // pinned host staging buffer (grow-only)
+	void *p = 0; size_t cap = 0;
+	int ensure(size_t bytes) {
+		if (bytes <= cap) return 0;
+		if (p) (void)hipHostFree(p);
+		size_t want = bytes + bytes / 4 + 4096;
+		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = 0; cap = 0; return -1; }
+		cap = want; return 0;
+	}
+	void release() { if (p) (void)hipHostFree(p); p = 0; cap = 0; }
+};
+
 struct HostBatch {            // packed reads of one sub-batch
 	int64_t n_reads = 0, n_bytes = 0, n_bases = 0;
 	std::vector<uint8_t> seq; std::vector<int64_t> roff; std::vector<int32_t> rlen, order;
@@ -38,7 +50,8 @@ struct mm355_ctx {
 	DBuf mz, mz_tmp, n_mz, sn, sv, sflt, hl, soff, n_a, rep_len, n_mini, mini_pos, counters, err;
 	DBuf aoff, a, f, p, v, z, t8, vi, b, wk, u, u2, n_u, n_v;
 	// dp buffers
-	DBuf dp_jobs, dp_res, dp_q, dp_t, dp_bt, dp_cig, dp_work, dp_H;
+	DBuf dp_jobs, dp_res, dp_q, dp_t, dp_bt, dp_cig, dp_work, dp_H, dp_dense, dp_gather, pack;
+	HBuf h_res, h_cig, h_pu, h_pa, h_pm, h_seq;
 	DBuf rq;       // per-read query codes fwd|rev
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
