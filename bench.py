@@ -40,11 +40,29 @@ def make_workload(name, n_reads, rank):
     if name == "ecoli":
         t0 = time.time()
         g = S.make_genome(1, [4641652], gc=0.508, repeats=((5000, 7, 0.01), (1300, 20, 0.01)))
-        reads, _ = S.make_reads(2 + 1000 * rank, g, n_reads, n50=8000, sigma=0.75, lo=500, hi=100000)
+        reads, _ = S.make_reads(rank_read_seed(rank), g, n_reads, n50=8000, sigma=0.75, lo=500, hi=100000)
         log("[bench] synthetic E. coli-like genome + %d reads in %.1fs" % (n_reads, time.time() - t0))
         return g, ["chrE"], reads, dict(workload="configs[1]: synthetic 4.64 Mbp E. coli-like genome (seed 1), map-ont k15 w10, "
                                                  "synthetic ONT reads N50~8kb 6% error (seed 2)", preset="map-ont")
     raise SystemExit("unknown workload " + name)
+
+
+def aggregate(dist, dt, aligned, bases):
+    """max-over-ranks time and whole-job sums; the only communication of the benchmark (never on the data path)"""
+    if dist is None:
+        return dt, float(aligned), float(bases)
+    import torch
+    dev = "cuda" if (torch.cuda.is_available() and dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    a = torch.tensor([aligned, bases], dtype=torch.float64, device=dev)
+    dist.all_reduce(a, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(a[0].item()), float(a[1].item())
+
+
+def rank_read_seed(rank):
+    """every rank maps its own reads (weak scaling): seed 2 for rank 0, disjoint streams for the others"""
+    return 2 + 1000 * rank
 
 
 def cpu_baseline(fa, preset, reads, budget_s, threads):
@@ -160,17 +178,7 @@ def main():
             agg[k] = agg.get(k, 0) + getattr(st, k)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        dev = "cuda" if torch.cuda.is_available() else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        a = torch.tensor([aligned_tot, n_bases * args.steps], dtype=torch.float64, device=dev)
-        dist.all_reduce(a, op=dist.ReduceOp.SUM)
-        aligned_all, bases_all = float(a[0].item()), float(a[1].item())
-    else:
-        aligned_all, bases_all = float(aligned_tot), float(n_bases * args.steps)
+    dt, aligned_all, bases_all = aggregate(dist, dt, aligned_tot, n_bases * args.steps)
 
     # PCIe-inclusive variant (never `value`): upload + map of the same batch
     t0 = time.perf_counter()

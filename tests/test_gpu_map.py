@@ -179,3 +179,24 @@ def test_stats_counters(ont):
         for k in tot: tot[k] += getattr(s, k)
     assert (st.n_mz, st.n_hit, st.n_a, st.n_a_multi) == (tot["n_mz"], tot["n_hit"], tot["n_a"], tot["n_a_multi"])
     assert st.dp_cells > 0 and st.n_dp_jobs > 0 and st.ms_seed_lookup > 0
+
+
+def test_committed_golden_vectors_on_gpu(built, golden_dir):
+    """the HIP path reproduces the committed golden hits (tests/golden/oracle_ont_small.json) without running the oracle"""
+    import json
+    import mappy_rs
+    want = json.load(open(os.path.join(golden_dir, "oracle_ont_small.json")))
+    g = S.make_genome(101, [60000, 40000], repeats=((1500, 5, 0.01), (400, 20, 0.03)), n_runs=1)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "g.fa")
+        S.write_fasta(fa, g, ["gA", "gB"])
+        al = mappy_rs.Aligner(fa, preset="map-ont")
+        res = al._map_many([r["seq"] for r in want["reads"]], 3)
+        for got, w in zip(res, want["reads"]):
+            assert len(got) == len(w["hits"])
+            for m, h in zip(got, w["hits"]):
+                assert (m.target_name, m.target_start, m.target_end, m.query_start, m.query_end, m.strand, m.mapq, m.is_primary, m.NM,
+                        m.cigar_str, m.cs, m.MD, m.match_len, m.block_len) == tuple(h[k] for k in (
+                            "target_name", "target_start", "target_end", "query_start", "query_end", "strand", "mapq", "is_primary", "NM",
+                            "cigar_str", "cs", "MD", "match_len", "block_len"))

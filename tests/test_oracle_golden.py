@@ -149,3 +149,18 @@ def test_region_hash_salt():
         k ^= k >> 16
         return k
     assert wang((wang(400) + wang(11)) & 0xffffffff) == 0x734db24f
+
+
+def test_committed_stage_vectors(golden_dir):
+    """G3: the oracle reproduces its committed per-stage dumps (regression pin; generator: tests/golden/make_golden.py)"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(golden_dir, "oracle_ont_small.json")))
+    got = mg.build()
+    assert got["genome_sha"] == want["genome_sha"] and got["mid_occ"] == want["mid_occ"]
+    assert len(got["reads"]) == len(want["reads"])
+    for g, w in zip(got["reads"], want["reads"]):
+        assert g == w
