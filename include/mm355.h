@@ -99,6 +99,10 @@ int mm355_mapopt_update(mm355_mapopt_t *mo, const mm355_index_t *idx);
 int mm355_index_load(const char *path, const mm355_idxopt_t *io, int n_threads, mm355_index_t **out);
 int mm355_index_build(const mm355_idxopt_t *io, int n_seq, const char *const *seqs, const int64_t *lens,
                       const char *const *names, int n_threads, mm355_index_t **out);
+/* same index, built on GPU `device` (sketch + radix sort + table fill in HBM; replaces the FASTA branch of
+ * mm_idx_reader_read for large references).  The table stays resident on that device: contexts must use the same one. */
+int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, const uint8_t *const *seqs, const int64_t *lens,
+                             const char *const *names, int device, mm355_index_t **out);
 void mm355_index_free(mm355_index_t *idx);
 /* header fields read at lib.rs:655-670 (k, w, n_seq) */
 int mm355_index_info(const mm355_index_t *idx, int32_t *k, int32_t *w, int32_t *b, int32_t *flag, uint32_t *n_seq);

@@ -19,6 +19,10 @@ struct mm355_index {
 	std::vector<uint64_t> pos;          // positions of multi-occurrence minimizers
 	int64_t n_minimizers, n_distinct;
 	std::unordered_map<std::string, int> name2id;
+	// device-built index (mm355_index_build_device): table and positions live only in HBM of device `dev_id`
+	bool dev_resident = false; int dev_id = -1;
+	void *d_slots = 0, *d_pos = 0, *d_S = 0; uint64_t n_pos = 0;
+	std::vector<uint32_t> top_counts;   // largest occurrence counts, descending (for mm_idx_cal_max_occ)
 };
 
 // lookup on the host image of the flat table (used by tests of the table itself; the product looks up on the device)

@@ -88,6 +88,13 @@ int32_t mm355_index_cal_max_occ(const mm355_index *mi, float f)
 	if (f <= 0.) return INT32_MAX;
 	size_t n = (size_t)mi->n_distinct;
 	if (n == 0) return INT32_MAX;
+	if (mi->dev_resident) {   // k-th smallest == (n-1-k)-th largest of the saved descending tail
+		size_t kk = (uint32_t)((1. - f) * n);
+		if (kk >= n) kk = n - 1;
+		size_t from_top = n - 1 - kk;
+		if (from_top >= mi->top_counts.size()) return mi->top_counts.empty()? INT32_MAX : (int32_t)(mi->top_counts.back() + 1);
+		return (int32_t)(mi->top_counts[from_top] + 1);
+	}
 	std::vector<uint32_t> a; a.reserve(n);
 	for (const mm355_slot &s : mi->slots)
 		if (s.key != UINT64_MAX) a.push_back(s.key & 1? 1u : (uint32_t)s.val);
@@ -315,7 +322,8 @@ extern "C" int mm355_index_build(const mm355_idxopt_t *io, int n_seq, const char
 	return 0;
 }
 
-extern "C" void mm355_index_free(mm355_index_t *mi) { delete mi; }
+void mm355_index_free_device(mm355_index *mi);
+extern "C" void mm355_index_free(mm355_index_t *mi) { if (mi && mi->dev_resident) mm355_index_free_device(mi); delete mi; }
 
 extern "C" int mm355_index_info(const mm355_index_t *mi, int32_t *k, int32_t *w, int32_t *b, int32_t *flag, uint32_t *n_seq)
 {
@@ -346,8 +354,8 @@ extern "C" int mm355_index_stat(const mm355_index_t *mi, int64_t *n_minimizers, 
 	if (mi == 0) return MM355_ENOIDX;
 	if (n_minimizers) *n_minimizers = mi->n_minimizers;
 	if (n_distinct) *n_distinct = mi->n_distinct;
-	if (table_bytes) *table_bytes = (int64_t)mi->slots.size() * 16;
-	if (pos_bytes) *pos_bytes = (int64_t)mi->pos.size() * 8;
+	if (table_bytes) *table_bytes = (int64_t)(mi->dev_resident? mi->n_lines * MM355_SLOTS_PER_LINE : mi->slots.size()) * 16;
+	if (pos_bytes) *pos_bytes = (int64_t)(mi->dev_resident? mi->n_pos : mi->pos.size()) * 8;
 	return 0;
 }
 
@@ -355,6 +363,7 @@ extern "C" int mm355_index_stat(const mm355_index_t *mi, int64_t *n_minimizers, 
 extern "C" int mm355_index_get(const mm355_index_t *mi, uint64_t minier, uint64_t *vals, int cap)
 {
 	if (mi == 0) return MM355_ENOIDX;
+	if (mi->dev_resident) return MM355_EUNSUP;   // the table of a device-built index exists only in HBM
 	uint64_t v = 0;
 	uint32_t n = mm355_host_get(mi, minier, &v);
 	if (n == 1) { if (cap > 0) vals[0] = v; }

@@ -55,6 +55,20 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	c->mi = mi; c->dev = device_id;
 	HIPCHK(hipStreamCreate(&c->st));
 	HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+	if (mi->dev_resident) {   // built on this device: the table is already in HBM
+		if (mi->dev_id != device_id) { delete c; return MM355_EINVAL; }
+		if (c->ix_off.ensure(mi->n_seq * 8) || c->ix_len.ensure(mi->n_seq * 4)) { delete c; return MM355_ENOMEM; }
+		HIPCHK(hipMemcpy(c->ix_off.p, mi->seq_off.data(), mi->n_seq * 8, hipMemcpyHostToDevice));
+		HIPCHK(hipMemcpy(c->ix_len.p, mi->seq_len.data(), mi->n_seq * 4, hipMemcpyHostToDevice));
+		c->dix.slots = (const mm355_slot*)mi->d_slots; c->dix.line_mask = mi->n_lines - 1;
+		c->dix.pos = (const uint64_t*)mi->d_pos; c->dix.S = (const uint32_t*)mi->d_S;
+		c->dix.seq_off = c->ix_off.as<uint64_t>(); c->dix.seq_len = c->ix_len.as<uint32_t>();
+		c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
+		if (c->counters.ensure(64) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
+		memset(&c->stats, 0, sizeof(c->stats));
+		*out = c;
+		return 0;
+	}
 	// index -> HBM (replicated per GPU; no collective is ever needed)
 	size_t sb = mi->slots.size() * sizeof(mm355_slot), pb = std::max<size_t>(mi->pos.size(), 1) * 8, Sb = std::max<size_t>(mi->S.size(), 1) * 4;
 	if (c->ix_slots.ensure(sb) || c->ix_pos.ensure(pb) || c->ix_S.ensure(Sb + 16) || c->ix_off.ensure(mi->n_seq * 8) || c->ix_len.ensure(mi->n_seq * 4)) { delete c; return MM355_ENOMEM; }

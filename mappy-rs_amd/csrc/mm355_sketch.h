@@ -1,0 +1,87 @@
+// mm355_sketch.h -- the chunked (w,k)-minimizer machine shared by the read sketch kernel (k_sketch) and the device
+// index builder (k_sketch_contig).  See the comment above k_sketch in mm355_kernels.hip for the exactness argument.
+#pragma once
+#include "mm355_core.h"
+#define SK_CHUNK 384
+struct BaseReader {
+	const uint8_t *s; uint64_t wd; int wi;
+	__device__ int operator()(int i) {
+		int q = i >> 3;
+		if (q != wi) { wd = ((const uint64_t*)s)[q]; wi = q; }   // reads start 16-B aligned and are padded
+		return mm_nt4((uint8_t)(wd >> ((i & 7) * 8)));
+	}
+};
+
+__device__ int sketch_chunk(const uint8_t *seq, int len, int w, int k, int cs, int ce, mm128 *out, mm128 *buf, int bstride)
+{
+	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
+#define BUF(j) buf[(j) * bstride]
+	int warm = 2 * (w + k) + 2 * w + 24;
+	for (;;) {
+		int s0 = cs - warm;
+		if (s0 < 0) s0 = 0;
+		const bool from_start = s0 == 0;
+		BaseReader get = { seq, 0, -1 };
+		uint64_t kmer[2] = {0, 0};
+		int i, j, l = 0, buf_pos = 0, min_pos = 0, kmer_span = 0, n = 0;
+		mm128 min = { UINT64_MAX, UINT64_MAX };
+		for (j = 0; j < w; ++j) BUF(j).x = BUF(j).y = UINT64_MAX;
+		// proof state
+		int n_real = 0, cnt_c = 0, writes_ok = 0, writes_after = 0;
+		bool jstar = from_start, seen_n = false, ok = from_start, trust = from_start, retry = false;
+#define MM_EMIT(v) do { uint32_t pp_ = (uint32_t)(v).y >> 1; if ((int)pp_ >= cs && (int)pp_ < ce) out[n++] = (v); } while (0)
+		for (i = s0; i < len; ++i) {
+			if (i == cs && !trust) { retry = true; break; }
+			int c = get(i);
+			mm128 info = { UINT64_MAX, UINT64_MAX };
+			if (c < 4) {
+				int z;
+				if (!jstar && ++n_real >= k) jstar = true;
+				kmer_span = l + 1 < k? l + 1 : k;
+				kmer[0] = (kmer[0] << 2 | c) & mask;
+				kmer[1] = (kmer[1] >> 2) | (3ULL^c) << shift1;
+				if (kmer[0] == kmer[1]) continue;
+				z = kmer[0] < kmer[1]? 0 : 1;
+				++l;
+				if (jstar) ++cnt_c;
+				if (l >= k && kmer_span < 256) {
+					info.x = mm_hash64(kmer[z], mask) << 8 | kmer_span;
+					info.y = (uint64_t)(uint32_t)i << 1 | z;
+				}
+			} else { l = 0, kmer_span = 0; if (jstar) seen_n = true; }
+			if (!ok) ok = jstar && (seen_n || cnt_c >= w + k);
+			if (ok && !trust) { if (++writes_ok > w) trust = true; }   // this write and w earlier ones are exact
+			BUF(buf_pos) = info;
+			if (l == w + k - 1 && min.x != UINT64_MAX) {
+				for (j = buf_pos + 1; j < w; ++j)
+					if (min.x == BUF(j).x && BUF(j).y != min.y) MM_EMIT(BUF(j));
+				for (j = 0; j < buf_pos; ++j)
+					if (min.x == BUF(j).x && BUF(j).y != min.y) MM_EMIT(BUF(j));
+			}
+			if (info.x <= min.x) {
+				if (l >= w + k && min.x != UINT64_MAX) MM_EMIT(min);
+				min = info, min_pos = buf_pos;
+			} else if (buf_pos == min_pos) {
+				if (l >= w + k - 1 && min.x != UINT64_MAX) MM_EMIT(min);
+				for (j = buf_pos + 1, min.x = UINT64_MAX; j < w; ++j)
+					if (min.x >= BUF(j).x) min = BUF(j), min_pos = j;
+				for (j = 0; j <= buf_pos; ++j)
+					if (min.x >= BUF(j).x) min = BUF(j), min_pos = j;
+				if (l >= w + k - 1 && min.x != UINT64_MAX) {
+					for (j = buf_pos + 1; j < w; ++j)
+						if (min.x == BUF(j).x && min.y != BUF(j).y) MM_EMIT(BUF(j));
+					for (j = 0; j <= buf_pos; ++j)
+						if (min.x == BUF(j).x && min.y != BUF(j).y) MM_EMIT(BUF(j));
+				}
+			}
+			if (++buf_pos == w) buf_pos = 0;
+			if (i >= ce && ++writes_after >= w) break;   // every ring record now lies beyond the chunk
+		}
+		if (retry) { warm = from_start? warm : warm * 4; continue; }
+		if (i >= len && min.x != UINT64_MAX) MM_EMIT(min);   // the sequential final flush
+#undef MM_EMIT
+#undef BUF
+		return n;
+	}
+}
+

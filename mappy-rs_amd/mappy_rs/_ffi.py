@@ -78,7 +78,7 @@ class DpRes(C.Structure):
 
 
 EXPORTS = [
-    "mm355_set_opt", "mm355_mapopt_update", "mm355_index_load", "mm355_index_build", "mm355_index_free",
+    "mm355_set_opt", "mm355_mapopt_update", "mm355_index_load", "mm355_index_build", "mm355_index_build_device", "mm355_index_free",
     "mm355_index_info", "mm355_index_seq_name", "mm355_index_seq_len", "mm355_index_name2id", "mm355_index_getseq",
     "mm355_index_get", "mm355_index_stat", "mm355_ctx_create", "mm355_ctx_destroy", "mm355_map_batch",
     "mm355_free_hits", "mm355_batch_upload", "mm355_map_resident", "mm355_stage_sketch", "mm355_stage_anchors", "mm355_stage_chain", "mm355_stage_chains",
@@ -102,6 +102,7 @@ def lib():
     L.mm355_mapopt_update.argtypes = [C.POINTER(MapOpt), vp]
     L.mm355_index_load.argtypes = [C.c_char_p, C.POINTER(IdxOpt), C.c_int, C.POINTER(vp)]
     L.mm355_index_build.argtypes = [C.POINTER(IdxOpt), C.c_int, C.POINTER(C.c_char_p), i64p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp)]
+    L.mm355_index_build_device.argtypes = [C.POINTER(IdxOpt), C.c_int, C.POINTER(C.c_char_p), i64p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp)]
     L.mm355_index_free.argtypes = [vp]
     L.mm355_index_info.argtypes = [vp, i32p, i32p, i32p, i32p, C.POINTER(C.c_uint32)]
     L.mm355_index_seq_name.restype = C.c_char_p

@@ -140,3 +140,45 @@ def test_chunked_sketch_adversarial(built, tmp_path):
             exp = orc.sketch(rd)
             assert got[i].shape == exp.shape and np.array_equal(got[i], exp), (k, w, i)
         sr.close()
+
+
+def test_device_index_builder_equals_host_builder(built, tmp_path):
+    """the index built on the GPU (sketch + radix sort + CAS table fill) gives the same mid_occ, the same
+    anchors and the same final hits as the host-built one"""
+    import ctypes as C
+    import mappy_rs
+    from mappy_rs import _ffi
+    L = _ffi.lib()
+    g = S.make_genome(91, [300000, 1000, 170000, 37], repeats=((3000, 6, 0.0), (700, 40, 0.01), (200, 300, 0.02)), n_runs=3)
+    names = ["c0", "c1", "c2", "c3"]
+    fa = str(tmp_path / "d.fa")
+    S.write_fasta(fa, g, names)
+    al = mappy_rs.Aligner(fa, preset="map-ont")           # host builder
+    io, mo = _ffi.IdxOpt(), _ffi.MapOpt()
+    L.mm355_set_opt(None, C.byref(io), C.byref(mo))
+    mo.flag |= 4
+    seqs = [bytes(bytearray(c.tolist())) for c in g]      # raw codes 0..4 are accepted like ASCII
+    arr = (C.c_char_p * len(seqs))(*seqs)
+    lens = (C.c_int64 * len(seqs))(*[len(s) for s in seqs])
+    nm = (C.c_char_p * len(seqs))(*[n.encode() for n in names])
+    h = C.c_void_p()
+    _ffi.check(L.mm355_index_build_device(C.byref(io), len(seqs), arr, lens, nm, 0, C.byref(h)))
+    L.mm355_mapopt_update(C.byref(mo), h)
+    assert mo.mid_occ == al._mo.mid_occ
+    nmz, nd, nmz2, nd2 = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    L.mm355_index_stat(h, C.byref(nmz), C.byref(nd), None, None)
+    L.mm355_index_stat(al._idx, C.byref(nmz2), C.byref(nd2), None, None)
+    assert (nmz.value, nd.value) == (nmz2.value, nd2.value)
+    out = (C.c_uint8 * 500)()
+    assert L.mm355_index_getseq(h, 2, 100, 600, out) == 500 and bytes(out) == bytes(int(c) for c in g[2][100:600])
+    reads, _ = S.make_reads(92, g, 60, n50=3000, lo=200)
+    sr_h = al._stage_runner()
+    sr_d = _ffi.StageRunner(h, mo, 0)
+    a_h, rep_h, _ = sr_h.anchors(reads, sorted_=True)
+    a_d, rep_d, _ = sr_d.anchors(reads, sorted_=True)
+    n_multi = 0
+    for x, y in zip(a_h, a_d):
+        assert np.array_equal(x, y)
+    assert np.array_equal(rep_h, rep_d)
+    sr_h.close(); sr_d.close()
+    L.mm355_index_free(h)
