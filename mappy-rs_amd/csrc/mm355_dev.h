@@ -69,6 +69,6 @@ void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &
 void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
 void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st);
 void mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st);
-void mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, hipStream_t st);
+int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr, hipStream_t st);
 void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st);
 #endif

@@ -410,13 +410,116 @@ __device__ inline int32_t wave_excl_prefix_max(int32_t v, int lane)   // exclusi
 	return lane == 0? INT32_MIN : e;
 }
 
-__global__ __launch_bounds__(WAVE) void k_chain(DevParams pr, DevBatch bt, DevAnchors an, unsigned long long *pairs_ctr)
+// Chaining is independent between "segments": maximal runs of the sorted anchor array with the same strand|rid whose
+// consecutive x differ by at most max_dist_x.  For the first anchor of a segment the window start `st` reaches the anchor
+// itself (every earlier anchor is on another strand/rid or farther than max_dist_x), so no score, no t[] mark and no
+// max_ii of an earlier segment can influence it.  k_chain_segments cuts the reads into segments; 1-anchor segments are
+// finished on the spot, short ones go to one lane each (k_chain_small), long ones to one wave each (k_chain_big).
+struct ChainSeg { int32_t read, i0, len, pad; };
+
+__device__ inline void chain_dist(const DevParams &pr, int qlen, int32_t &max_dist_x, int32_t &max_dist_y)
 {
-	__shared__ int32_t tw[TW_SIZE];   // t[] marks of the active window, circular by anchor index
-	const int r = blockIdx.x, lane = threadIdx.x;
+	max_dist_y = pr.max_gap;
+	if (pr.max_gap_ref > 0) max_dist_x = pr.max_gap_ref;
+	else if (pr.max_frag_len > 0) { max_dist_x = pr.max_frag_len - qlen; if (max_dist_x < pr.max_gap) max_dist_x = pr.max_gap; }
+	else max_dist_x = pr.max_gap;
+	if (max_dist_x < pr.bw) max_dist_x = pr.bw;
+	if (max_dist_y < pr.bw) max_dist_y = pr.bw;
+}
+
+__global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch bt, DevAnchors an, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
+{
+	const int r = blockIdx.x;
 	const int64_t o = an.aoff[r];
 	const int n = (int)(an.aoff[r+1] - o);
 	if (n == 0) return;
+	const mm128 *a = an.a + o;
+	int32_t mdx, mdy;
+	chain_dist(pr, bt.rlen[r], mdx, mdy);
+	for (int i = threadIdx.x; i < n; i += 256) {
+		const uint64_t xi = a[i].x;
+		bool start = i == 0;
+		if (!start) { const uint64_t xp = a[i-1].x; start = (xi >> 32 != xp >> 32) || xi > xp + (uint64_t)(int64_t)mdx; }
+		if (!start) continue;
+		int e = i + 1;
+		uint64_t xp = xi;
+		while (e < n) { const uint64_t xe = a[e].x; if ((xe >> 32 != xp >> 32) || xe > xp + (uint64_t)(int64_t)mdx) break; xp = xe; ++e; }
+		const int len = e - i;
+		if (len == 1) {
+			const int32_t sp = (int32_t)(a[i].y >> 32 & 0xff);
+			an.f[o + i] = sp; an.p[o + i] = -1; an.v[o + i] = sp;
+		} else {
+			ChainSeg sg; sg.read = r; sg.i0 = i; sg.len = len; sg.pad = 0;
+			if (len <= small_max) small[atomicAdd(&ctr[0], 1u)] = sg;
+			else big[atomicAdd(&ctr[1], 1u)] = sg;
+		}
+	}
+}
+
+#define CHAIN_SMALL 32
+// one lane per short segment: the literal sequential recurrence (U:lchain.c::mg_lchain_dp)
+__global__ __launch_bounds__(256) void k_chain_small(DevParams pr, DevBatch bt, DevAnchors an, const ChainSeg *segs, unsigned int n_segs, unsigned long long *pairs_ctr)
+{
+	__shared__ int32_t tl[CHAIN_SMALL][256];
+	const unsigned int sidx = blockIdx.x * 256 + threadIdx.x;
+	unsigned long long pairs = 0;
+	if (sidx < n_segs) {
+		const ChainSeg sg = segs[sidx];
+		const int64_t o = an.aoff[sg.read];
+		const mm128 *a = an.a + o;
+		int32_t *f = an.f + o, *p = an.p + o, *v = an.v + o;
+		int32_t mdx, mdy;
+		chain_dist(pr, bt.rlen[sg.read], mdx, mdy);
+		const int i0 = sg.i0, i1 = sg.i0 + sg.len, bw = pr.bw, max_skip = pr.max_chain_skip, max_iter = pr.max_chain_iter;
+		for (int k = 0; k < sg.len; ++k) tl[k][threadIdx.x] = -1;
+		int st = i0, max_ii = -1;
+		for (int i = i0; i < i1; ++i) {
+			const mm128 ai = a[i];
+			int max_j = -1, j, end_j;
+			int32_t max_f = (int32_t)(ai.y >> 32 & 0xff), n_skip = 0;
+			while (st < i && (ai.x >> 32 != a[st].x >> 32 || ai.x > a[st].x + (uint64_t)(int64_t)mdx)) ++st;
+			if (i - st > max_iter) st = i - max_iter;
+			for (j = i - 1; j >= st; --j) {
+				const mm128 aj = a[j];
+				int32_t sc = mm_comput_sc(ai.x, ai.y, aj.x, aj.y, mdx, mdy, bw, pr.pen_gap, pr.pen_skip);
+				++pairs;
+				if (sc == MM355_SC_NONE) continue;
+				sc += f[j];
+				if (sc > max_f) { max_f = sc, max_j = j; if (n_skip > 0) --n_skip; }
+				else if (tl[j - i0][threadIdx.x] == i) { if (++n_skip > max_skip) break; }
+				const int32_t pj = p[j];
+				if (pj >= 0) tl[pj - i0][threadIdx.x] = i;
+			}
+			end_j = j;
+			if (max_ii < 0 || ai.x - a[max_ii].x > (uint64_t)(int64_t)mdx) {
+				int32_t mx = INT32_MIN;
+				max_ii = -1;
+				for (j = i - 1; j >= st; --j) if (mx < f[j]) mx = f[j], max_ii = j;
+			}
+			if (max_ii >= 0 && max_ii < end_j) {
+				const mm128 am = a[max_ii];
+				int32_t tmp = mm_comput_sc(ai.x, ai.y, am.x, am.y, mdx, mdy, bw, pr.pen_gap, pr.pen_skip);
+				if (tmp != MM355_SC_NONE && max_f < tmp + f[max_ii]) max_f = tmp + f[max_ii], max_j = max_ii;
+			}
+			f[i] = max_f; p[i] = max_j;
+			v[i] = max_j >= 0 && v[max_j] > max_f? v[max_j] : max_f;
+			if (max_ii < 0 || (ai.x - a[max_ii].x <= (uint64_t)(int64_t)mdx && f[max_ii] < f[i])) max_ii = i;
+		}
+	}
+	for (int o2 = 32; o2 > 0; o2 >>= 1) pairs += __shfl_down(pairs, o2);
+	if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(pairs_ctr, pairs);
+}
+
+// one wave per long segment
+__global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, DevAnchors an, const ChainSeg *segs, unsigned int n_segs, unsigned long long *pairs_ctr)
+{
+	__shared__ int32_t tw[TW_SIZE];   // t[] marks of the active window, circular by anchor index
+	const int lane = threadIdx.x;
+	if (blockIdx.x >= n_segs) return;
+	const ChainSeg sg = segs[blockIdx.x];
+	const int r = sg.read;
+	const int64_t o = an.aoff[r];
+	const int i_begin = sg.i0, n = sg.i0 + sg.len;
 	const mm128 *a = an.a + o;
 	int32_t *f = an.f + o, *p = an.p + o, *v = an.v + o;
 	const int qlen = bt.rlen[r];
@@ -430,9 +533,9 @@ __global__ __launch_bounds__(WAVE) void k_chain(DevParams pr, DevBatch bt, DevAn
 	const float pen_gap = pr.pen_gap, pen_skip = pr.pen_skip;
 	for (int i = lane; i < TW_SIZE; i += WAVE) tw[i] = -1;
 	__syncthreads();
-	int st = 0, max_ii = -1;
+	int st = i_begin, max_ii = -1;
 	unsigned long long pairs = 0;
-	for (int i = 0; i < n; ++i) {
+	for (int i = i_begin; i < n; ++i) {
 		const mm128 ai = a[i];
 		// advance st (U: while (st < i && (other rid/strand || too far)) ++st)
 		for (;;) {
@@ -661,10 +764,18 @@ void mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, hipStream_t
 	if (bt.n_reads == 0) return;
 	hipLaunchKernelGGL(k_sort_anchors, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, an, err);
 }
-void mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, hipStream_t st)
+// seg_small / seg_big: scratch lists of at least tot_a/2 + 1 entries each; ctr: 2 zeroed u32 on the device
+int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr, hipStream_t st)
 {
-	if (bt.n_reads == 0) return;
-	hipLaunchKernelGGL(k_chain, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, an, pairs);
+	if (bt.n_reads == 0) return 0;
+	if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return -1;
+	hipLaunchKernelGGL(k_chain_segments, dim3(bt.n_reads), dim3(256), 0, st, pr, bt, an, (ChainSeg*)seg_small, (ChainSeg*)seg_big, ctr, CHAIN_SMALL);
+	unsigned int h[2] = {0, 0};
+	if (hipMemcpyAsync(h, ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+	if (hipStreamSynchronize(st) != hipSuccess) return -1;
+	if (h[1]) hipLaunchKernelGGL(k_chain_big, dim3(h[1]), dim3(WAVE), 0, st, pr, bt, an, (const ChainSeg*)seg_big, h[1], pairs);
+	if (h[0]) hipLaunchKernelGGL(k_chain_small, dim3((h[0] + 255) / 256), dim3(256), 0, st, pr, bt, an, (const ChainSeg*)seg_small, h[0], pairs);
+	return 0;
 }
 void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st)
 {

@@ -245,7 +245,8 @@ int mm355_run_sort(mm355_ctx *c)
 int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
-	{ EvTimer t(c, &c->stats.ms_chain); mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + 3, c->st); }
+	// segment lists live in scratch that is free at this point: z (8 B/anchor) and wk (16 B/anchor) hold >= tot_a/2 16-byte entries each
+	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + 3, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->st)) return MM355_EHIP; }
 	HIPCHK(hipGetLastError());
 	unsigned long long pairs = 0;
 	HIPCHK(hipMemcpyAsync(&pairs, c->counters.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, c->st));

@@ -129,3 +129,106 @@ def write_fasta(path, contigs, names=None, width=80):
 # canned configs (BASELINE.json configs[1] at reduced and full size)
 def ecoli_like(seed=1, size=4641652):
     return make_genome(seed, [size], gc=0.508)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GRCh38-scale synthetic genome (BASELINE.json configs[2]/[3]): 24 contigs with the hg38 primary-assembly
+# lengths, i.i.d. background at GC 41 %, three injected repeat families and an N-run at every contig centre.
+HG38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+             135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+             46709983, 50818468, 156040895, 57227415]
+HG38_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+
+
+def _revcomp_rows(a):
+    return (3 - a)[:, ::-1]
+
+
+def _inject_family(rng, flat, starts, lens, consensus, n_copies, div, piece_len):
+    """scatter n_copies diverged copies of the 3' `piece_len` bases of `consensus` at random places (vectorised)"""
+    if n_copies <= 0:
+        return
+    total = int(flat.size)
+    piece = consensus[-piece_len:]
+    step = max(1000, 50_000_000 // piece_len)   # bounds the (m x piece_len) index array
+    for lo in range(0, n_copies, step):
+        m = min(step, n_copies - lo)
+        pos = rng.integers(0, total - piece_len, m)
+        # keep copies inside one contig
+        ci = np.searchsorted(starts, pos, side="right") - 1
+        ok = pos + piece_len <= starts[ci] + lens[ci]
+        pos = pos[ok]
+        m = len(pos)
+        if m == 0:
+            continue
+        cp = np.broadcast_to(piece, (m, piece_len)).copy()
+        mut = rng.random((m, piece_len), dtype=np.float32) < div
+        cp[mut] = (cp[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) & 3
+        flip = rng.random(m) < 0.5
+        cp[flip] = _revcomp_rows(cp[flip])
+        idx = pos[:, None] + np.arange(piece_len)[None, :]
+        flat[idx.ravel()] = cp.ravel()
+
+
+def make_human_like(seed=3, scale=1.0, log=None):
+    """returns (list of contig code arrays [views of one flat array], names).  scale < 1 shrinks every contig."""
+    rng = _rng(seed)
+    lens = np.array([max(100000, int(l * scale)) for l in HG38_LENS], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    total = int(lens.sum())
+    lut = np.empty(256, np.uint8)
+    n_gc = int(round(256 * 0.41))
+    lut[:n_gc] = np.where(np.arange(n_gc) % 2 == 0, 1, 2)             # C / G
+    lut[n_gc:] = np.where(np.arange(256 - n_gc) % 2 == 0, 0, 3)       # A / T
+    flat = np.empty(total, np.uint8)
+    step = 1 << 28
+    for lo in range(0, total, step):
+        hi = min(total, lo + step)
+        flat[lo:hi] = lut[rng.integers(0, 256, hi - lo, dtype=np.uint8)]
+    if log: log("[synth] background %d bases" % total)
+    sine = random_codes(rng, 300, 0.55)
+    line = random_codes(rng, 6000, 0.40)
+    sat = random_codes(rng, 171, 0.35)
+    _inject_family(rng, flat, starts, lens, sine, int(1.1e6 * scale), 0.12, 300)
+    for plen, frac in ((6000, 0.04), (3000, 0.08), (1500, 0.20), (900, 0.68)):
+        _inject_family(rng, flat, starts, lens, line, int(0.5e6 * scale * frac), 0.08, plen)
+    n_arr = max(1, int(total * 0.03 / 50000))
+    for _ in range(n_arr):
+        alen = 50000
+        pos = int(rng.integers(0, total - alen))
+        ci = int(np.searchsorted(starts, pos, side="right") - 1)
+        if pos + alen > starts[ci] + lens[ci]:
+            continue
+        arr = np.tile(sat, alen // 171 + 1)[:alen].copy()
+        mut = rng.random(alen, dtype=np.float32) < 0.02
+        arr[mut] = (arr[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) & 3
+        flat[pos:pos + alen] = arr
+    for s, l in zip(starts, lens):                                    # centromere-like N-run
+        nl = int(min(500000, l // 50))
+        c = int(s + l // 2)
+        flat[c:c + nl] = 4
+    if log: log("[synth] repeats injected")
+    contigs = [flat[int(s):int(s + l)] for s, l in zip(starts, lens)]
+    return contigs, list(HG38_NAMES)
+
+
+def make_reads_codes(seed, contigs, n_reads, n50=10000, sigma=0.75, lo=500, hi=100000, sub=0.024, ins=0.016, dele=0.020):
+    """like make_reads but returns raw code bytes (0..4), which the C-ABI accepts like ASCII; avoids string conversion"""
+    rng = _rng(seed)
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    lengths = read_lengths(rng, n_reads, n50, sigma, lo, hi)
+    p = lens / lens.sum()
+    cis = rng.choice(len(contigs), size=n_reads, p=p)
+    out, truth = [], []
+    for i in range(n_reads):
+        ci = int(cis[i])
+        L = int(min(lengths[i], lens[ci]))
+        st = int(rng.integers(0, lens[ci] - L + 1))
+        seg = contigs[ci][st:st + L]
+        strand = 1
+        if rng.random() < 0.5:
+            strand = -1
+            seg = np.where(seg < 4, 3 - seg, 4).astype(np.uint8)[::-1]
+        out.append(mutate(seg, rng, sub, ins, dele).tobytes())
+        truth.append((ci, st, st + L, strand))
+    return out, truth
