@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ecoli")
     ap.add_argument("--reads", type=int, default=8192, help="reads per step per GPU")
+    ap.add_argument("--streams", type=int, default=2, help="concurrent contexts (HIP streams) per GPU")
     ap.add_argument("--scale", type=float, default=1.0, help="genome scale of the human workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -152,21 +153,31 @@ def main():
         arr = (C.c_char_p * len(seqs))(*seqs)
         _ffi.check(L.mm355_index_build(C.byref(io), len(seqs), arr, lens, nm, min(16, os.cpu_count() or 1), C.byref(idx)))
     L.mm355_mapopt_update(C.byref(mo), idx)
-    ctx = C.c_void_p()
-    _ffi.check(L.mm355_ctx_create(idx, local_rank, C.byref(ctx)))
+    # `--streams S`: S contexts (own HIP stream + buffers) on this GPU, each with 1/S of the step's reads resident in HBM;
+    # a step maps all of them concurrently from S host threads, so the host tail of one sub-batch overlaps kernels of another.
+    n_str = max(1, args.streams)
+    os.environ.setdefault("MM355_HOST_THREADS", str(max(2, 16 // n_str)))
+    ctxs, parts = [], []
+    for si in range(n_str):
+        ctx = C.c_void_p()
+        _ffi.check(L.mm355_ctx_create(idx, local_rank, C.byref(ctx)))
+        ctxs.append(ctx)
+        parts.append(reads[si::n_str])
     log("[bench] index built + uploaded in %.1fs (mid_occ=%d)" % (time.time() - t0, mo.mid_occ))
 
-    rarr, rlens, keep = _ffi.pack_reads(reads)
-    n_bases = sum(len(b) for b in keep)
+    packed = [_ffi.pack_reads(p) for p in parts]
+    n_bases = sum(len(b) for pk in packed for b in pk[2])
     t0 = time.time()
-    _ffi.check(L.mm355_batch_upload(ctx, len(reads), rarr, rlens))
+    for ctx, (rarr, rlens, keep) in zip(ctxs, packed):
+        _ffi.check(L.mm355_batch_upload(ctx, len(keep), rarr, rlens))
     t_upload = time.time() - t0
 
-    def step():
+    def step_one(si):
+        ctx, (rarr, rlens, keep) = ctxs[si], packed[si]
         hp = C.POINTER(_ffi.Hits)()
         _ffi.check(L.mm355_map_resident(ctx, C.byref(mo), _ffi.OUT_CS, C.byref(hp)))
         h = hp.contents
-        off = np.ctypeslib.as_array(h.hit_off, shape=(len(reads) + 1,))
+        off = np.ctypeslib.as_array(h.hit_off, shape=(len(keep) + 1,))
         mapped = np.diff(off) > 0
         aligned = int(np.asarray(rlens)[mapped].sum())
         n_hits = int(h.n_hits)
@@ -174,6 +185,17 @@ def main():
         st = _ffi.Stats()
         L.mm355_get_stats(ctx, C.byref(st))
         return aligned, n_hits, st
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(n_str)
+
+    def step():
+        res = list(pool.map(step_one, range(n_str)))
+        agg_st = _ffi.Stats()
+        for _a, _h, st in res:
+            for k, _t in _ffi.Stats._fields_:
+                setattr(agg_st, k, getattr(agg_st, k) + getattr(st, k))
+        return sum(r[0] for r in res), sum(r[1] for r in res), agg_st
 
     def barrier():
         if dist is not None:
@@ -194,11 +216,14 @@ def main():
     dt = time.perf_counter() - t0
     dt, aligned_all, bases_all = aggregate(dist, dt, aligned_tot, n_bases * args.steps)
 
-    # PCIe-inclusive variant (never `value`): upload + map of the same batch
+    # PCIe-inclusive variant (never `value`): upload + map of the same reads
+    def pcie_one(si):
+        ctx, (rarr, rlens, keep) = ctxs[si], packed[si]
+        hp = C.POINTER(_ffi.Hits)()
+        _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(keep), rarr, rlens, _ffi.OUT_CS, C.byref(hp)))
+        L.mm355_free_hits(hp)
     t0 = time.perf_counter()
-    hp = C.POINTER(_ffi.Hits)()
-    _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(reads), rarr, rlens, _ffi.OUT_CS, C.byref(hp)))
-    L.mm355_free_hits(hp)
+    list(pool.map(pcie_one, range(n_str)))
     dt_pcie = time.perf_counter() - t0
 
     if rank == 0:
@@ -229,7 +254,7 @@ def main():
             "value": round(aligned_all / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (+f32 chaining gap cost)", "data": "synthetic",
-            "config": dict(workload=wl["workload"], reads_per_step_per_gpu=len(reads), mbases_per_step_per_gpu=round(n_bases / 1e6, 3),
+            "config": dict(workload=wl["workload"], reads_per_step_per_gpu=len(reads), streams_per_gpu=n_str, mbases_per_step_per_gpu=round(n_bases / 1e6, 3),
                            preset=wl["preset"], parallelism="reads sharded over %d GPU(s), index replicated, no collective" % world),
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
             "pcie_inclusive_mbases_per_s": round(n_bases / dt_pcie / 1e6, 3),
@@ -249,7 +274,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(fa, wl["preset"], reads, args.cpu_seconds, min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
     barrier()
-    L.mm355_ctx_destroy(ctx)
+    for ctx in ctxs:
+        L.mm355_ctx_destroy(ctx)
     L.mm355_index_free(idx)
     if dist is not None:
         dist.destroy_process_group()

@@ -55,13 +55,17 @@ __device__ inline uint32_t *push_cigar(uint32_t *cigar, int &n, uint32_t op, int
 // state word: byte0 u, 1 v, 2 x, 3 y, 4 x2, 5 y2, 6 s
 __device__ inline int8_t SB(uint64_t w, int i) { return (int8_t)(w >> (8 * i)); }
 
+// A workgroup is ONE wave: LDS traffic of a wave is executed in order, so lanes only need their own LDS operations to have
+// completed (lgkmcnt) -- __syncthreads() would also wait for every outstanding global store (vmcnt(0)), i.e. for the
+// direction-matrix bytes of the current anti-diagonal to reach HBM, which serialises the sweep on store latency.
+#define DP_SYNC() do { if (state_in_lds) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); } while (0)
 __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
                                                     const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, int32_t *offbase,
                                                     uint32_t *cigbase, uint64_t *stbase, int32_t *Hbase, mm355_dpres_t *res,
                                                     int lds_cap, unsigned long long *cells_ctr, uint32_t *dense, unsigned long long *dense_ctr)
 {
 	extern __shared__ uint64_t lds[];
-	__shared__ long long s_dst; __shared__ int s_nc;   // [lds_cap] state words, then [lds_cap] int32 H
+	// [lds_cap] state words, then [lds_cap] int32 H
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_jobs) return;
 	const int jid = job_ids[blockIdx.x];
@@ -70,12 +74,11 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 	EzState ez;
 	ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
 	ez.max = 0; ez.score = ez.mqe = ez.mte = KSW_NEG_INF; ez.zdropped = 0; ez.reach_end = 0;
-	int n_cigar = 0;
-	uint32_t *cigar = cigbase + jb.cig_off;
+	(void)cigbase; (void)dense; (void)dense_ctr;
 	if (qlen <= 0 || tlen <= 0 || jb.skip) {   // skip: tlen*qlen > max_sw_mat => treated as z-dropped by mm_align_pair
 		if (lane == 0) {
 			mm355_dpres_t o; o.max = 0; o.zdropped = jb.skip? 1 : 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1;
-			o.mqe = o.mte = o.score = KSW_NEG_INF; o.reach_end = 0; o.n_cigar = 0; o.cigar_off = 0;
+			o.mqe = o.mte = o.score = KSW_NEG_INF; o.reach_end = 0; o.n_cigar = -1; o.cigar_off = -1;
 			res[jid] = o;
 		}
 		return;
@@ -92,16 +95,17 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 	n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
 	const int n_col = n_col_ * 16;
 	uint64_t *S; int32_t *H;
-	if (T <= lds_cap) { S = lds; H = (int32_t*)(lds + lds_cap); }
+	const bool state_in_lds = T <= lds_cap;
+	if (state_in_lds) { S = lds; H = (int32_t*)(lds + lds_cap); }
 	else { S = stbase + jb.st_off; H = Hbase + jb.st_off; }
 	uint8_t *p = pbase + jb.p_off;
-	int32_t *off = offbase + jb.off_off, *off_end = off + (qlen + tlen - 1);
+	(void)offbase;
 	{   // memset(u,v,x,y = -q-e; x2,y2 = -q2-e2); s = 0; H = NEG_INF
 		const uint8_t a = (uint8_t)I8(-q - e), b = (uint8_t)I8(-q2 - e2);
 		const uint64_t init = (uint64_t)a | (uint64_t)a << 8 | (uint64_t)a << 16 | (uint64_t)a << 24 | (uint64_t)b << 32 | (uint64_t)b << 40;
 		for (int t = lane; t < T; t += WAVE) { S[t] = init; if (!approx_max) H[t] = KSW_NEG_INF; }
 	}
-	__syncthreads();
+	DP_SYNC();
 	int last_st = -1, last_en = -1;
 	int32_t H0 = 0, last_H0_t = 0;
 	unsigned long long cells = 0;
@@ -129,7 +133,6 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 		const int sc_end = st0 + ((en0 - st0) / 16 + 1) * 16;   // scores are (re)written for t in [st0, sc_end)
 		int8_t cx = x1, cv = v1, cx2 = x21;
 		uint8_t *pr = p + (size_t)r * n_col - st;
-		if (lane == 0) { off[r] = st; off_end[r] = en; }
 		for (int c0 = st; c0 <= en; c0 += WAVE) {
 			const int t = c0 + lane;
 			const bool act = t <= en;
@@ -199,13 +202,13 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 			}
 		}
 		cells += (unsigned long long)(en0 - st0 + 1);
-		__syncthreads();
+		DP_SYNC();
 		if (!approx_max) {
 			int32_t max_H, max_t;
 			if (r > 0) {
 				const int en1 = st0 + (en0 - st0) / 4 * 4;
 				int32_t hen = en0 > 0? H[en0 - 1] + SB(S[en0], 0) : H[en0] + SB(S[en0], 1);
-				__syncthreads();
+				DP_SYNC();
 				max_H = hen; max_t = en0;
 				// 4-lane strided maxima over [st0,en1): class = (t - st0) & 3, strict > keeps the first t of a class
 				int32_t bh = INT32_MIN, bt = 0x7fffffff;
@@ -225,16 +228,16 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 				if (lane == 0) H[en0] = hen;
 				for (int t = en1; t < en0; ++t) {    // scalar tail (at most 3 cells), strict >
 					int32_t h = H[t] + (int32_t)SB(S[t], 1);
-					__syncthreads();
+					DP_SYNC();
 					if (lane == 0) H[t] = h;
 					if (h > max_H) max_H = h, max_t = t;
 				}
-				__syncthreads();
+				DP_SYNC();
 			} else {
 				int32_t h0 = (int32_t)SB(S[0], 1) - qe;
 				if (lane == 0) H[0] = h0;
 				max_H = h0; max_t = 0;
-				__syncthreads();
+				DP_SYNC();
 			}
 			const int32_t Hen0 = H[en0], Hst0 = H[st0];
 			if (en0 == tlen - 1 && Hen0 > ez.mte) ez.mte = Hen0, ez.mte_q = r - en;
@@ -258,48 +261,75 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 			if (r == qlen + tlen - 2 && en0 == tlen - 1) ez.score = H0;
 		}
 		last_st = st, last_en = en;
-		__syncthreads();
+		DP_SYNC();
 	}
-	__syncthreads();
-	// backtrack (U:ksw2.h::ksw_backtrack, is_rot=1): one lane walks the direction matrix
+	// the sweep only records where the backtrack starts; k_ksw_backtrack walks the direction matrix (one LANE per alignment)
 	if (lane == 0) {
 		int i0 = -1, j0 = -1;
-		const bool rev_cigar = flag & EZ_REV_CIGAR;
 		if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) { i0 = tlen - 1; j0 = qlen - 1; }
 		else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + end_bonus > ez.max) { ez.reach_end = 1; i0 = ez.mqe_t; j0 = qlen - 1; }
 		else if (ez.max_t >= 0 && ez.max_q >= 0) { i0 = ez.max_t; j0 = ez.max_q; }
-		if (i0 >= 0 || j0 >= 0) {
-			int i = i0, j = j0, state = 0;
-			while (i >= 0 && j >= 0) {
-				int force_state = -1, rr = i + j;
-				uint32_t tmp;
-				if (i < off[rr]) force_state = 2;
-				if (i > off_end[rr]) force_state = 1;
-				tmp = force_state < 0? p[(size_t)rr * n_col + i - off[rr]] : 0;
-				if (state == 0) state = tmp & 7;
-				else if (!(tmp >> (state + 2) & 1)) state = 0;
-				if (state == 0) state = tmp & 7;
-				if (force_state >= 0) state = force_state;
-				if (state == 0) push_cigar(cigar, n_cigar, 0, 1), --i, --j;
-				else if (state == 1 || state == 3) push_cigar(cigar, n_cigar, 2, 1), --i;
-				else push_cigar(cigar, n_cigar, 1, 1), --j;
-			}
-			if (i >= 0) push_cigar(cigar, n_cigar, 2, i + 1);
-			if (j >= 0) push_cigar(cigar, n_cigar, 1, j + 1);
-			if (!rev_cigar)
-				for (i = 0; i < n_cigar >> 1; ++i) { uint32_t t2 = cigar[i]; cigar[i] = cigar[n_cigar - 1 - i]; cigar[n_cigar - 1 - i] = t2; }
-		}
 		mm355_dpres_t o;
 		o.max = ez.max; o.zdropped = ez.zdropped; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe = ez.mqe; o.mqe_t = ez.mqe_t;
-		o.mte = ez.mte; o.mte_q = ez.mte_q; o.score = ez.score; o.reach_end = ez.reach_end; o.n_cigar = n_cigar;
-		s_dst = (long long)atomicAdd(dense_ctr, (unsigned long long)n_cigar);   // dense CIGAR arena: only real ops travel to the host
-		s_nc = n_cigar;
-		o.cigar_off = s_dst;
+		o.mte = ez.mte; o.mte_q = ez.mte_q; o.score = ez.score; o.reach_end = ez.reach_end;
+		o.n_cigar = i0;            // start cell, replaced by the CIGAR length / offset in k_ksw_backtrack
+		o.cigar_off = j0;
 		res[jid] = o;
 		if (cells) atomicAdd(cells_ctr, cells);
 	}
-	__syncthreads();
-	for (int i = lane; i < s_nc; i += WAVE) dense[s_dst + i] = cigar[i];
+}
+
+// U:ksw2.h::ksw_backtrack (is_rot = 1).  The walk is a chain of dependent 1-byte loads (one per CIGAR column), i.e. pure
+// latency: with one lane per alignment a wave keeps 64 independent chains in flight instead of one.  off[]/off_end[] of
+// the reference are pure functions of (r, qlen, tlen, w) and are recomputed instead of being stored and re-loaded.
+__global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, const int32_t *job_ids, int n_jobs, const uint8_t *pbase, uint32_t *cigbase,
+                                                        mm355_dpres_t *res, uint32_t *dense, unsigned long long *dense_ctr)
+{
+	const int t = blockIdx.x * WAVE + threadIdx.x;
+	if (t >= n_jobs) return;
+	const int jid = job_ids[t];
+	const DpJobDev jb = jobs[jid];
+	mm355_dpres_t o = res[jid];
+	const int i0 = o.n_cigar, j0 = (int)o.cigar_off;
+	int n_cigar = 0;
+	uint32_t *cigar = cigbase + jb.cig_off;
+	const int qlen = jb.qlen, tlen = jb.tlen;
+	if (qlen > 0 && tlen > 0 && !jb.skip && (i0 >= 0 || j0 >= 0)) {
+		int w = jb.w;
+		if (w < 0) w = tlen > qlen? tlen : qlen;
+		int n_col_ = qlen < tlen? qlen : tlen;
+		n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
+		const int n_col = n_col_ * 16;
+		const uint8_t *p = pbase + jb.p_off;
+		int i = i0, j = j0, state = 0;
+		while (i >= 0 && j >= 0) {
+			int force_state = -1, rr = i + j;
+			int st = 0, en = tlen - 1;
+			if (st < rr - qlen + 1) st = rr - qlen + 1;
+			if (en > rr) en = rr;
+			if (st < (rr - w + 1) >> 1) st = (rr - w + 1) >> 1;
+			if (en > (rr + w) >> 1) en = (rr + w) >> 1;
+			st = st / 16 * 16, en = (en + 16) / 16 * 16 - 1;   // off[rr], off_end[rr]
+			uint32_t tmp;
+			if (i < st) force_state = 2;
+			if (i > en) force_state = 1;
+			tmp = force_state < 0? p[(size_t)rr * n_col + i - st] : 0;
+			if (state == 0) state = tmp & 7;
+			else if (!(tmp >> (state + 2) & 1)) state = 0;
+			if (state == 0) state = tmp & 7;
+			if (force_state >= 0) state = force_state;
+			if (state == 0) push_cigar(cigar, n_cigar, 0, 1), --i, --j;
+			else if (state == 1 || state == 3) push_cigar(cigar, n_cigar, 2, 1), --i;
+			else push_cigar(cigar, n_cigar, 1, 1), --j;
+		}
+		if (i >= 0) push_cigar(cigar, n_cigar, 2, i + 1);
+		if (j >= 0) push_cigar(cigar, n_cigar, 1, j + 1);
+	}
+	const long long dst = (long long)atomicAdd(dense_ctr, (unsigned long long)n_cigar);   // dense arena: only real ops travel to the host
+	if (jb.flag & EZ_REV_CIGAR) for (int k = 0; k < n_cigar; ++k) dense[dst + k] = cigar[k];
+	else for (int k = 0; k < n_cigar; ++k) dense[dst + k] = cigar[n_cigar - 1 - k];
+	o.n_cigar = n_cigar; o.cigar_off = dst;
+	res[jid] = o;
 }
 
 // gather kernel: materialise query / target code strings of each job (optionally reversed) from the read batch and
@@ -406,6 +436,14 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 			                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
 			done += ids[cls].size();
 		}
+		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
+		std::vector<int32_t> order(n);
+		for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
+		std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return jobs[x].qlen + jobs[x].tlen > jobs[y].qlen + jobs[y].tlen; });
+		HIPCHK(hipMemcpyAsync(d_ids, order.data(), n * 4, hipMemcpyHostToDevice, c->st));
+		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids, (int)n,
+		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
+		HIPCHK(hipStreamSynchronize(c->st));   // `order` is pageable
 	}
 	HIPCHK(hipGetLastError());
 	unsigned long long ctr[2] = {0, 0};

@@ -76,9 +76,88 @@ __global__ __launch_bounds__(WAVE) void k_sketch_compact(DevBatch bt, DevSeeds s
 #define RS_STK 1024
 struct SortLds {
 	uint32_t cnt[256], bb[256], be[256];
+	uint32_t cur[256], fend[256], arr[256], abef[256], fst[256];   // label-walk state (wave_rs_level_walk)
 	uint32_t stk_beg[RS_STK], stk_end[RS_STK];
 	uint32_t stk_n, overflow;
 };
+
+// per-read HBM scratch of the parallel permutation (all indexed like the array being sorted)
+struct WalkScratch { void *out; uint32_t *fpos; uint32_t *rank; uint8_t *flab; };
+
+// One level of the in-place cycle-leader permutation of rs_sort, reproduced WITHOUT moving elements one by one.
+// The permutation only depends on the byte labels: inside the region R_k of bucket k an element is "home" (label k) or
+// "foreign".  Foreign elements leave their region in position order; an element arriving at bucket l before l's own
+// turn is inserted at l's cursor and pushes the following run of home elements right by one, an element arriving during
+// l's turn fills the next foreign slot.  So the final position of every element follows from (a) the order in which
+// foreign elements arrive at each bucket and (b) how many arrive before the bucket's turn.  (a)/(b) are produced by a
+// sequential walk over the 1-byte label queues only (lane 0, labels in LDS); everything else -- histogram, compaction
+// of foreign elements, the final scatter -- is done by all 64 lanes with coalesced traffic.  Exhaustively checked
+// against the literal permutation on the host (tests) and bit-compared through the anchor parity tests.
+template <typename T, typename Key>
+__device__ void wave_rs_level_walk(T *a, uint32_t beg, uint32_t end, int s, Key key, SortLds *L, const WalkScratch &ws, uint8_t *lds_lab, uint32_t lds_cap)
+{
+	const uint32_t lane = threadIdx.x & 63, tot = end - beg;
+	if (lane == 0) { uint32_t acc = 0; for (int k = 0; k < 256; ++k) { L->bb[k] = acc; acc += L->cnt[k]; L->be[k] = acc; } }
+	__syncthreads();
+	T *out = (T*)ws.out + beg;
+	uint32_t *fpos = ws.fpos + beg, *rank = ws.rank + beg;
+	uint8_t *flab = ws.flab + beg;
+	uint32_t nfor = 0;
+	for (uint32_t base = 0; base < tot; base += WAVE) {
+		const uint32_t rel = base + lane;
+		uint32_t g = 0; bool foreign = false;
+		if (rel < tot) { g = (uint32_t)(key(a[beg + rel]) >> s) & 255u; foreign = !(rel >= L->bb[g] && rel < L->be[g]); }
+		const unsigned long long mask = __ballot(foreign);
+		if (foreign) { const uint32_t e = nfor + __popcll(mask & LANE_LT_MASK(lane)); fpos[e] = rel; flab[e] = (uint8_t)g; if (e < lds_cap) lds_lab[e] = (uint8_t)g; }
+		nfor += __popcll(mask);
+	}
+	__syncthreads();
+	for (uint32_t k = lane; k < 256; k += WAVE) {   // first foreign slot at or after the start of region k
+		uint32_t lo = 0, hi = nfor; const uint32_t target = L->bb[k];
+		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (fpos[mid] < target) lo = mid + 1; else hi = mid; }
+		L->cur[k] = lo; L->fst[k] = lo; L->arr[k] = 0;
+	}
+	__syncthreads();
+	for (uint32_t k = lane; k < 256; k += WAVE) L->fend[k] = k < 255? L->fst[k + 1] : nfor;
+	__syncthreads();
+	if (lane == 0) {   // the only sequential part: one step per foreign element, on 1-byte labels
+		const bool in_lds = nfor <= lds_cap;
+		for (uint32_t k = 0; k < 256; ++k) {
+			L->abef[k] = L->arr[k];
+			while (L->cur[k] < L->fend[k]) {
+				uint32_t c = k;
+				do {
+					const uint32_t e = L->cur[c]++;
+					const uint32_t g = in_lds? lds_lab[e] : flab[e];
+					rank[e] = L->arr[g]++;
+					c = g;
+				} while (c != k);
+			}
+		}
+	}
+	__syncthreads();
+	uint32_t nfb = 0;
+	for (uint32_t base = 0; base < tot; base += WAVE) {
+		const uint32_t rel = base + lane;
+		uint32_t g = 0; bool foreign = false; T el;
+		if (rel < tot) { el = a[beg + rel]; g = (uint32_t)(key(el) >> s) & 255u; foreign = !(rel >= L->bb[g] && rel < L->be[g]); }
+		const unsigned long long mask = __ballot(foreign);
+		const uint32_t pre = nfb + __popcll(mask & LANE_LT_MASK(lane));
+		if (rel < tot) {
+			uint32_t dest;
+			const uint32_t al = L->abef[g], f0 = L->fst[g];
+			if (foreign) {
+				const uint32_t r = rank[pre];
+				dest = r < al? (r == 0? L->bb[g] : fpos[f0 + r - 1] + 1) : fpos[f0 + r];
+			} else dest = rel + ((pre - f0) < al? 1u : 0u);
+			out[dest] = el;
+		}
+		nfb += __popcll(mask);
+	}
+	__syncthreads();
+	for (uint32_t i = lane; i < tot; i += WAVE) a[beg + i] = out[i];
+	__syncthreads();
+}
 
 template <typename T, typename Key>
 __device__ void wave_rank_sort_small(T *a, uint32_t n, Key key)   // n <= 64: stable == rs_insertsort's result
@@ -98,7 +177,7 @@ __device__ void wave_rank_sort_small(T *a, uint32_t n, Key key)   // n <= 64: st
 
 // sort a[0..n0) starting at byte shift s0, exactly as rs_sort_128x(beg,end,8,s0) would.
 template <bool STAGE, typename T, typename Key>
-__device__ void wave_rs_core(T *a, uint32_t n0, int s0, Key key, SortLds *L, T *stage, uint32_t stage_cap)
+__device__ void wave_rs_core(T *a, uint32_t n0, int s0, Key key, SortLds *L, T *stage, uint32_t stage_cap, const WalkScratch *ws = 0)
 {
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t base = L->stk_n;
@@ -137,7 +216,8 @@ __device__ void wave_rs_core(T *a, uint32_t n0, int s0, Key key, SortLds *L, T *
 			__syncthreads();
 			continue;
 		}
-		if (lane == 0) mm_rs_permute(a + beg, (int64_t)tot, s, L->cnt, L->bb, L->be, key);
+		if (STAGE && ws) wave_rs_level_walk(a, beg, end, s, key, L, *ws, (uint8_t*)stage, (uint32_t)(stage_cap * sizeof(T)));
+		else if (lane == 0) mm_rs_permute(a + beg, (int64_t)tot, s, L->cnt, L->bb, L->be, key);
 		__syncthreads();
 		if (s > 0) {
 			uint32_t s2 = (uint32_t)((s - 8) >> 3);
@@ -157,13 +237,13 @@ __device__ void wave_rs_core(T *a, uint32_t n0, int s0, Key key, SortLds *L, T *
 }
 
 template <typename T, typename Key>
-__device__ void wave_radix_sort(T *a, uint32_t n, Key key, SortLds *L, T *stage, uint32_t stage_cap)
+__device__ void wave_radix_sort(T *a, uint32_t n, Key key, SortLds *L, T *stage, uint32_t stage_cap, const WalkScratch *ws = 0)
 {
 	if (n <= 1) return;
 	if (n <= MM355_RS_MIN_SIZE) { wave_rank_sort_small(a, n, key); return; }
 	if ((threadIdx.x & 63) == 0) { L->stk_n = 0; L->overflow = 0; }
 	__syncthreads();
-	wave_rs_core<true>(a, n, 56, key, L, stage, stage_cap);
+	wave_rs_core<true>(a, n, 56, key, L, stage, stage_cap, ws);
 }
 
 struct key_hi32 { __host__ __device__ uint64_t operator()(const uint64_t &v) const { return v >> 32; } };
@@ -180,6 +260,19 @@ __global__ __launch_bounds__(WAVE) void k_mzflt(DevParams pr, DevBatch bt, DevSe
 	if (n <= q_occ_max || pr.q_occ_frac <= 0.0f || q_occ_max <= 0) return;
 	const int64_t off = bt.roff[r];
 	mm128 *mz = sd.mz + off, *tmp = sd.mz_tmp + off;
+	{   // cheap proof that nothing can be filtered: a count-sketch bucket holds at least every occurrence of a value,
+		// so if no bucket exceeds q_occ_max no minimizer does (the common case: the exact sort below is skipped)
+		uint32_t *cs = (uint32_t*)stage;   // 8192 counters
+		for (int i = lane; i < 8192; i += WAVE) cs[i] = 0;
+		__syncthreads();
+		for (int i = lane; i < n; i += WAVE) atomicAdd(&cs[(uint32_t)(mm_table_hash(mz[i].x) >> 20) & 8191u], 1u);
+		__syncthreads();
+		uint32_t mx = 0;
+		for (int i = lane; i < 8192; i += WAVE) mx = mx > cs[i]? mx : cs[i];
+		for (int o2 = 32; o2 > 0; o2 >>= 1) { uint32_t y2 = __shfl_xor(mx, o2); mx = mx > y2? mx : y2; }
+		__syncthreads();
+		if (mx <= (uint32_t)q_occ_max) return;
+	}
 	for (int i = lane; i < n; i += WAVE) { tmp[i].x = mz[i].x; tmp[i].y = (uint64_t)i; }
 	__syncthreads();
 	wave_radix_sort(tmp, (uint32_t)n, mm_key_x(), &L, stage, (uint32_t)MZ_STAGE);
@@ -384,14 +477,15 @@ __global__ __launch_bounds__(256) void k_seed_expand(DevIndex ix, DevParams pr, 
 
 // ------------------------------------------------------------------ a6: radix_sort_128x on the anchors
 #define A_STAGE 2048
-__global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors an, int *err)
+__global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors an, int *err, const int32_t *heavy_first)
 {
 	__shared__ SortLds L;
 	__shared__ mm128 stage[A_STAGE];
-	const int r = blockIdx.x;
+	const int r = heavy_first[blockIdx.x];
 	const int64_t o = an.aoff[r];
 	const uint32_t n = (uint32_t)(an.aoff[r+1] - o);
-	wave_radix_sort(an.a + o, n, mm_key_x(), &L, stage, (uint32_t)A_STAGE);
+	WalkScratch ws; ws.out = an.b + o; ws.fpos = (uint32_t*)an.f + o; ws.rank = (uint32_t*)an.p + o; ws.flab = an.t8 + o;   // all free before chaining
+	wave_radix_sort(an.a + o, n, mm_key_x(), &L, stage, (uint32_t)A_STAGE, &ws);
 	if (threadIdx.x == 0 && n > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
 }
 
@@ -622,11 +716,11 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 
 // ------------------------------------------------------------------ a8: mg_chain_backtrack + compact_a
 #define Z_STAGE 4096
-__global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, DevAnchors an, int *err)
+__global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, DevAnchors an, int *err, const int32_t *heavy_first)
 {
 	__shared__ SortLds L;
 	__shared__ uint64_t zstage[Z_STAGE];
-	const int r = blockIdx.x, lane = threadIdx.x;
+	const int r = heavy_first[blockIdx.x], lane = threadIdx.x;
 	const int64_t o = an.aoff[r];
 	const int n = (int)(an.aoff[r+1] - o);
 	if (lane == 0) { an.n_u[r] = 0; an.n_v[r] = 0; }
@@ -648,13 +742,15 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 		bool keep = i < n && fi >= min_sc;
 		unsigned long long mask = __ballot(keep);
 		if (keep) z[n_z + __popcll(mask & LANE_LT_MASK(lane))] = (uint64_t)(uint32_t)fi << 32 | (uint32_t)i;
-		if (i < n) t8[i] = 0;
 		n_z += __popcll(mask);
 	}
 	__syncthreads();
 	if (n_z == 0) return;
-	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE);
+	WalkScratch ws; ws.out = u2; ws.fpos = (uint32_t*)vi; ws.rank = (uint32_t*)(an.v + o); ws.flab = t8;   // v[] is dead after the DP fill
+	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws);
 	if (lane == 0 && n_z > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
+	__syncthreads();
+	for (int i = lane; i < n; i += WAVE) t8[i] = 0;
 	__syncthreads();
 	__shared__ int s_nu, s_nv;
 	if (lane == 0) {
@@ -759,10 +855,10 @@ void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const Dev
 	if (bt.n_reads == 0) return;
 	hipLaunchKernelGGL(k_seed_expand, dim3(bt.n_reads), dim3(256), 0, st, ix, pr, bt, sd, an);
 }
-void mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st)
+void mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st)
 {
 	if (bt.n_reads == 0) return;
-	hipLaunchKernelGGL(k_sort_anchors, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, an, err);
+	hipLaunchKernelGGL(k_sort_anchors, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, an, err, heavy_first);
 }
 // seg_small / seg_big: scratch lists of at least tot_a/2 + 1 entries each; ctr: 2 zeroed u32 on the device
 int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr, hipStream_t st)
@@ -777,8 +873,8 @@ int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, 
 	if (h[0]) hipLaunchKernelGGL(k_chain_small, dim3((h[0] + 255) / 256), dim3(256), 0, st, pr, bt, an, (const ChainSeg*)seg_small, h[0], pairs);
 	return 0;
 }
-void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, hipStream_t st)
+void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st)
 {
 	if (bt.n_reads == 0) return;
-	hipLaunchKernelGGL(k_backtrack, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, an, err);
+	hipLaunchKernelGGL(k_backtrack, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, an, err, heavy_first);
 }

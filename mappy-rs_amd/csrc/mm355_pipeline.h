@@ -45,7 +45,7 @@ struct mm355_ctx {
 	DevIndex dix;
 	DBuf ix_slots, ix_pos, ix_S, ix_off, ix_len;
 	// per-batch device buffers
-	DBuf seq, roff, rlen, order, ck_read, ck_start, ck_n, ck_r0;
+	DBuf heavy, seq, roff, rlen, order, ck_read, ck_start, ck_n, ck_r0;
 	int64_t n_chunks = 0;
 	DBuf mz, mz_tmp, n_mz, sn, sv, sflt, hl, soff, n_a, rep_len, n_mini, mini_pos, counters, err;
 	DBuf aoff, a, f, p, v, z, t8, vi, b, wk, u, u2, n_u, n_v;

@@ -91,7 +91,7 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 {
 	if (c == 0) return;
 	(void)hipSetDevice(c->dev);
-	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
+	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
 		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
@@ -215,6 +215,14 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 	    c->z.ensure(na * 8) || c->t8.ensure(na) || c->vi.ensure(na * 4) || c->b.ensure(na * 16) || c->wk.ensure(na * 16) ||
 	    c->u.ensure(na * 8) || c->u2.ensure(na * 8)) return MM355_ENOMEM;
 	HIPCHK(hipMemcpyAsync(c->aoff.p, hb.aoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->st));
+	{   // per-read kernels take the reads with the most anchors first: the slowest block starts at t=0 instead of last
+		std::vector<int32_t> hv(n);
+		std::iota(hv.begin(), hv.end(), 0);
+		std::stable_sort(hv.begin(), hv.end(), [&](int32_t x, int32_t y) { return hb.n_a[x] > hb.n_a[y]; });
+		if (c->heavy.ensure((size_t)(n + 1) * 4)) return MM355_ENOMEM;
+		if (n) HIPCHK(hipMemcpyAsync(c->heavy.p, hv.data(), n * 4, hipMemcpyHostToDevice, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));
+	}
 	return 0;
 }
 
@@ -237,7 +245,7 @@ static int check_err(mm355_ctx *c)
 int mm355_run_sort(mm355_ctx *c)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
-	{ EvTimer t(c, &c->stats.ms_sort); mm355_launch_sort(b, a, c->err.as<int>(), c->st); }
+	{ EvTimer t(c, &c->stats.ms_sort); mm355_launch_sort(b, a, c->err.as<int>(), c->heavy.as<int32_t>(), c->st); }
 	HIPCHK(hipGetLastError());
 	return check_err(c);
 }
@@ -259,7 +267,7 @@ int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
 	HostBatch &hb = c->hb;
-	{ EvTimer t(c, &c->stats.ms_backtrack); mm355_launch_backtrack(pr, b, a, c->err.as<int>(), c->st); }
+	{ EvTimer t(c, &c->stats.ms_backtrack); mm355_launch_backtrack(pr, b, a, c->err.as<int>(), c->heavy.as<int32_t>(), c->st); }
 	HIPCHK(hipGetLastError());
 	int64_t n = hb.n_reads;
 	hb.n_u.resize(n); hb.n_v.resize(n);
