@@ -382,8 +382,10 @@ DpConst mm355_dp_const(const mm355_mapopt_t *mo)
 	return c;
 }
 
-#define DP_LDS_SMALL 1024
-#define DP_LDS_MED   4096
+// LDS size classes of the per-target state (12 B per target position): small alignments get small footprints so that
+// up to 32 of them are resident per CU and hide each other's LDS round trips
+static const int DP_CLASS_CAP[] = { 256, 512, 1024, 4096, 0 };
+#define DP_N_CLASS 5
 
 // runs jobs whose code strings are already on the device (qbuf/tbuf); fills res[] and the cigar arena (host copies)
 int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
@@ -395,7 +397,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 	DpConst dc = mm355_dp_const(mo);
 	// lay out per-job work areas
 	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
-	std::vector<int32_t> ids[3];
+	std::vector<int32_t> ids[DP_N_CLASS];
 	for (size_t i = 0; i < n; ++i) {
 		DpJobDev &j = jobs[i];
 		j.skip = (mo->max_sw_mat > 0 && (int64_t)j.tlen * j.qlen > mo->max_sw_mat) || !dc.valid;
@@ -408,8 +410,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 			p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
 			off_tot += (size_t)(j.qlen + j.tlen - 1) * 2;
 			cig_tot += (size_t)j.qlen + j.tlen + 2;
-			int cls = T <= DP_LDS_SMALL? 0 : T <= DP_LDS_MED? 1 : 2;
-			if (cls == 2) { j.st_off = (int64_t)st_tot; st_tot += T; }
+			int cls = 0;
+			while (cls < DP_N_CLASS - 1 && T > DP_CLASS_CAP[cls]) ++cls;
+			if (cls == DP_N_CLASS - 1) { j.st_off = (int64_t)st_tot; st_tot += T; }
 			ids[cls].push_back((int32_t)i);
 		} else ids[0].push_back((int32_t)i);
 	}
@@ -426,10 +429,10 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
 		size_t done = 0;
-		for (int cls = 0; cls < 3; ++cls) {
+		for (int cls = DP_N_CLASS - 1; cls >= 0; --cls) {   // big problems first
 			if (ids[cls].empty()) continue;
 			HIPCHK(hipMemcpyAsync(d_ids + done, ids[cls].data(), ids[cls].size() * 4, hipMemcpyHostToDevice, c->st));
-			int cap = cls == 0? DP_LDS_SMALL : cls == 1? DP_LDS_MED : 0;
+			int cap = DP_CLASS_CAP[cls];
 			size_t lds = (size_t)cap * 12;
 			hipLaunchKernelGGL(k_ksw_extd2, dim3((unsigned)ids[cls].size()), dim3(WAVE), lds, c->st, dc, c->dp_jobs.as<DpJobDev>(), d_ids + done,
 			                   (int)ids[cls].size(), d_q, d_t, c->dp_bt.as<uint8_t>(), d_off, c->dp_cig.as<uint32_t>(), d_S, d_H,

@@ -607,7 +607,16 @@ __global__ __launch_bounds__(256) void k_chain_small(DevParams pr, DevBatch bt, 
 // one wave per long segment
 __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, DevAnchors an, const ChainSeg *segs, unsigned int n_segs, unsigned long long *pairs_ctr)
 {
-	__shared__ int32_t tw[TW_SIZE];   // t[] marks of the active window, circular by anchor index
+	// t[] marks of the active window, circular by anchor index: 15 bits of the marking anchor + a valid bit (a stale mark
+	// would need an index distance that is a multiple of 32768, larger than window + ring size)
+	__shared__ uint16_t tw[TW_SIZE];
+	// f/p/v of the last 64 anchors: the next anchors read them from LDS, so the loop-carried dependence never waits for a
+	// global store -> load round trip; older entries come from HBM (their stores were issued >= 64 anchors ago)
+	__shared__ int32_t rf[WAVE], rp[WAVE], rv[WAVE];
+#define CH_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define GETF(j) ((i - (j)) <= WAVE? rf[(j) & 63] : f[j])
+#define GETP(j) ((i - (j)) <= WAVE? rp[(j) & 63] : p[j])
+#define GETV(j) ((i - (j)) <= WAVE? rv[(j) & 63] : v[j])
 	const int lane = threadIdx.x;
 	if (blockIdx.x >= n_segs) return;
 	const ChainSeg sg = segs[blockIdx.x];
@@ -625,7 +634,7 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 	if (max_dist_x < bw) max_dist_x = bw;
 	if (max_dist_y < bw) max_dist_y = bw;
 	const float pen_gap = pr.pen_gap, pen_skip = pr.pen_skip;
-	for (int i = lane; i < TW_SIZE; i += WAVE) tw[i] = -1;
+	for (int i = lane; i < TW_SIZE; i += WAVE) tw[i] = 0;
 	__syncthreads();
 	int st = i_begin, max_ii = -1;
 	unsigned long long pairs = 0;
@@ -644,20 +653,22 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 		if (i - st > max_iter) st = i - max_iter;
 		int32_t max_f = (int32_t)(ai.y >> 32 & 0xff), max_j = -1, n_skip = 0;
 		int end_j = st - 1;
+		const uint16_t mark = (uint16_t)((i & 0x7fff) | 0x8000);
 		for (int jb = i - 1; jb >= st; jb -= WAVE) {
 			const int j = jb - lane;
 			const bool active = j >= st;
 			int32_t sc = MM355_SC_NONE, pj = -1;
+			if (jb != i - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // older f/p come from HBM: their stores have landed
 			if (active) {
 				const mm128 aj = a[j];
 				sc = mm_comput_sc(ai.x, ai.y, aj.x, aj.y, max_dist_x, max_dist_y, bw, pen_gap, pen_skip);
-				if (sc != MM355_SC_NONE) { sc += f[j]; pj = p[j]; }
+				if (sc != MM355_SC_NONE) { sc += GETF(j); pj = GETP(j); }
 			}
 			const bool valid = sc != MM355_SC_NONE;
 			pairs += __popcll(__ballot(active));
-			if (valid && pj >= st) tw[pj & TW_MASK] = i;   // t[p[j]] = i; marks below st are never tested
-			__syncthreads();
-			const bool marked = valid && tw[j & TW_MASK] == i;
+			if (valid && pj >= st) tw[pj & TW_MASK] = mark;   // t[p[j]] = i; marks below st are never tested
+			CH_SYNC();
+			const bool marked = valid && tw[j & TW_MASK] == mark;
 			const int32_t scv = valid? sc : INT32_MIN;
 			int32_t pm = wave_excl_prefix_max(scv, lane);
 			pm = pm > max_f? pm : max_f;
@@ -680,7 +691,7 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 				int wl = __builtin_ctzll(w);   // lowest lane = highest j = first met by the sequential scan
 				max_f = cmax; max_j = jb - wl;
 			}
-			__syncthreads();
+			CH_SYNC();
 			if (brk >= 0) { end_j = jb - brk; break; }
 		}
 		// max_ii rescue
@@ -688,7 +699,8 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 		if (!need) need = ai.x - a[max_ii].x > (uint64_t)(int64_t)max_dist_x;
 		if (need) {
 			int32_t bf = INT32_MIN, bj = -1;
-			for (int j = i - 1 - lane; j >= st; j -= WAVE) { int32_t fj = f[j]; if (bf < fj) bf = fj, bj = j; }
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			for (int j = i - 1 - lane; j >= st; j -= WAVE) { int32_t fj = GETF(j); if (bf < fj) bf = fj, bj = j; }
 			for (int of = 32; of > 0; of >>= 1) {
 				int32_t of_f = __shfl_xor(bf, of), of_j = __shfl_xor(bj, of);
 				if (of_f > bf || (of_f == bf && of_j > bj)) bf = of_f, bj = of_j;
@@ -698,19 +710,25 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 		if (max_ii >= 0 && max_ii < end_j) {
 			const mm128 am = a[max_ii];
 			int32_t tmp = mm_comput_sc(ai.x, ai.y, am.x, am.y, max_dist_x, max_dist_y, bw, pen_gap, pen_skip);
-			if (tmp != MM355_SC_NONE) { int32_t fm = f[max_ii]; if (max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii; }
+			if (tmp != MM355_SC_NONE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); int32_t fm = GETF(max_ii); if (max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii; }
 		}
 		int32_t vi = max_f;
-		if (max_j >= 0) { int32_t vm = v[max_j]; if (vm > max_f) vi = vm; }
-		if (lane == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; }
+		if (max_j >= 0) { if (i - max_j > WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); int32_t vm = GETV(max_j); if (vm > max_f) vi = vm; }
 		if (max_ii < 0) max_ii = i;
 		else {
 			uint64_t d = ai.x - a[max_ii].x;
-			int32_t fm = (max_ii == i)? max_f : f[max_ii];
+			if (i - max_ii > WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			int32_t fm = GETF(max_ii);
 			if (d <= (uint64_t)(int64_t)max_dist_x && fm < max_f) max_ii = i;
 		}
-		__syncthreads();   // f/p/v[i] visible to the whole wave before the next anchor reads them
+		CH_SYNC();   // every lane has finished reading ring slot (i & 63) (it held anchor i-64)
+		if (lane == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; rf[i & 63] = max_f; rp[i & 63] = max_j; rv[i & 63] = vi; }
+		CH_SYNC();
 	}
+#undef GETF
+#undef GETP
+#undef GETV
+#undef CH_SYNC
 	if (lane == 0 && pairs) atomicAdd(pairs_ctr, pairs);
 }
 
