@@ -878,11 +878,11 @@ static inline void update_max_zdrop(int32_t score, int i, int j, int32_t *max, i
 	} else *max = score, *max_i = i, *max_j = j;
 }
 
-static int test_zdrop(const mm355_mapopt_t *opt, const uint8_t *qseq, const uint8_t *tseq, const std::vector<uint32_t> &cigar, const int8_t *mat)
+static int test_zdrop(const mm355_mapopt_t *opt, const uint8_t *qseq, const uint8_t *tseq, const uint32_t *cigar, int n_cigar, const int8_t *mat)
 {
 	int32_t score = 0, max = INT32_MIN, max_i = -1, max_j = -1, i = 0, j = 0, max_zdrop = 0;
 	int pos[2][2] = {{-1, -1}, {-1, -1}}, q_len, t_len;
-	for (size_t k = 0; k < cigar.size(); ++k) {
+	for (int k = 0; k < n_cigar; ++k) {
 		uint32_t l, op = cigar[k] & 0xf, len = cigar[k] >> 4;
 		if (op == 0) {
 			for (l = 0; l < len; ++l) {
@@ -907,15 +907,15 @@ static int test_zdrop(const mm355_mapopt_t *opt, const uint8_t *qseq, const uint
 	return max_zdrop > opt->zdrop? 1 : 0;
 }
 
-static void append_cigar(Reg *r, const std::vector<uint32_t> &cigar)
+static void append_cigar(Reg *r, const uint32_t *cigar, int n)
 {
-	if (cigar.empty()) return;
+	if (n <= 0) return;
 	if (r->p == 0) r->p = new Extra();
 	std::vector<uint32_t> &c = r->p->cigar;
 	if (!c.empty() && (c.back() & 0xf) == (cigar[0] & 0xf)) {
 		c.back() += (cigar[0] >> 4) << 4;
-		c.insert(c.end(), cigar.begin() + 1, cigar.end());
-	} else c.insert(c.end(), cigar.begin(), cigar.end());
+		c.insert(c.end(), cigar + 1, cigar + n);
+	} else c.insert(c.end(), cigar, cigar + n);
 }
 
 static void fix_cigar(Reg *r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
@@ -1197,17 +1197,19 @@ static void task_prepare(const mm355_index *mi, const mm355_mapopt_t *opt, ReadS
 	} else re0 = re_, qe0 = qe_;
 	T.rs = rs_, T.qs = qs_, T.re = re_, T.qe = qe_;
 	T.rs0 = rs0, T.qs0 = qs0, T.re0 = re0, T.qe0 = qe0;
-	T.res.assign(2 + 2 * (size_t)T.cnt1, EzRes());
+	T.res.clear(); T.res.reserve(40);
+	T.slot_of.assign(2 + 2 * (size_t)T.cnt1, -1);
 	T.prepared = true;
 }
 
 static bool want(AlnTask &T, int slot, int read_id, int task_id, std::vector<DpReq> &reqs, int32_t qlen, int32_t tlen, int32_t q_st, int rev_strand,
                  uint32_t rid, int32_t t_st, int reversed, int32_t w, int32_t zdrop, int32_t end_bonus, int32_t flag)
 {
-	EzRes &e = T.res[slot];
+	if (T.slot_of[slot] < 0) { T.slot_of[slot] = (int32_t)T.res.size(); T.res.emplace_back(); }
+	EzRes &e = T.res[T.slot_of[slot]];
 	if (e.state == 2) return true;
 	if (e.state == 0) {
-		DpReq q; q.read = read_id; q.task = task_id; q.slot = slot; q.qlen = qlen; q.tlen = tlen; q.q_st = q_st; q.rev_strand = rev_strand;
+		DpReq q; q.read = read_id; q.task = task_id; q.slot = T.slot_of[slot]; q.qlen = qlen; q.tlen = tlen; q.q_st = q_st; q.rev_strand = rev_strand;
 		q.rid = rid; q.t_st = t_st; q.reversed = reversed; q.w = w; q.zdrop = zdrop; q.end_bonus = end_bonus; q.flag = flag;
 		reqs.push_back(q);
 		e.state = 1;
@@ -1233,7 +1235,8 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 	gen_simple_mat(mat, opt->a, opt->b, opt->sc_ambi);
 	Extra tmp;        // alignment under construction; committed only when every needed DP result is present
 	bool have_p = false;
-	auto add_cigar = [&](const std::vector<uint32_t> &cg) { if (cg.empty()) return; Reg t2; t2.p = &tmp; append_cigar(&t2, cg); have_p = true; };
+	auto add_cigar = [&](const uint32_t *cg, int ncg) { if (ncg <= 0) return; Reg t2; t2.p = &tmp; append_cigar(&t2, cg, ncg); have_p = true; };
+	auto RES = [&](int slot) -> EzRes& { return T.res[T.slot_of[slot]]; };
 	std::vector<uint8_t> tseq;
 	r2->cnt = 0;
 	if (r->cnt == 0) return true;
@@ -1241,9 +1244,9 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 	// left extension (requested by request_left(), which runs before every task_run)
 	rs1 = rs_, qs1 = qs_;
 	if (qs_ > 0 && rs_ > 0) {
-		EzRes &e = T.res[0];
-		if (e.state == 2) {
-			if (!e.cigar.empty()) { add_cigar(e.cigar); tmp.dp_score += e.max; }
+		if (T.slot_of[0] >= 0 && RES(0).state == 2) {
+			EzRes &e = RES(0);
+			if (e.n_cigar > 0) { add_cigar(e.cigar, e.n_cigar); tmp.dp_score += e.max; }
 			rs1 = rs_ - (e.reach_end? e.mqe_t + 1 : e.max_t + 1);
 			qs1 = qs_ - (e.reach_end? qs_ - qs0 : e.max_q + 1);
 		} else complete = false;
@@ -1260,18 +1263,18 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 			const int sa = 2 + 2 * i, se = 3 + 2 * i;
 			bool ok = want(T, sa, read_id, task_id, reqs, qe_run - qs_run, re_run - rs_run, qs_run, rev, (uint32_t)rid, rs_run, 0, bw1, opt->zdrop, -1, EZ_APPROX_MAX);
 			if (!ok) { complete = false; rs_run = re_run, qs_run = qe_run; continue; }   // speculate: not dropped
-			EzRes *e = &T.res[sa];
+			EzRes *e = &RES(sa);
 			tseq.resize((size_t)(re_run - rs_run) + 1);
 			getseq(mi, (uint32_t)rid, rs_run, re_run, tseq.data());
 			const uint8_t *qseq = rs.qc[rev].data() + qs_run;
-			zdrop_code = test_zdrop(opt, qseq, tseq.data(), e->cigar, mat);
+			zdrop_code = test_zdrop(opt, qseq, tseq.data(), e->cigar, e->n_cigar, mat);
 			if (zdrop_code != 0) {
 				ok = want(T, se, read_id, task_id, reqs, qe_run - qs_run, re_run - rs_run, qs_run, rev, (uint32_t)rid, rs_run, 0, bw1,
 				          zdrop_code == 2? opt->zdrop_inv : opt->zdrop, -1, 0);
 				if (!ok) { complete = false; rs_run = re_run, qs_run = qe_run; continue; }
-				e = &T.res[se];
+				e = &RES(se);
 			}
-			if (!e->cigar.empty()) add_cigar(e->cigar);
+			if (e->n_cigar > 0) add_cigar(e->cigar, e->n_cigar);
 			if (e->zdropped) {
 				int32_t j;
 				have_p = true;
@@ -1291,8 +1294,8 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 	if (!dropped && qe_ < qe0 && re_ < re0) {   // right extension
 		bool ok = want(T, 1, read_id, task_id, reqs, qe0 - qe_, re0 - re_, qe_, rev, (uint32_t)rid, re_, 0, T.bw, opt->zdrop, opt->end_bonus, EZ_EXTZ_ONLY);
 		if (ok) {
-			EzRes &e = T.res[1];
-			if (!e.cigar.empty()) { add_cigar(e.cigar); tmp.dp_score += e.max; }
+			EzRes &e = RES(1);
+			if (e.n_cigar > 0) { add_cigar(e.cigar, e.n_cigar); tmp.dp_score += e.max; }
 			re1 = re_ + (e.reach_end? e.mqe_t + 1 : e.max_t + 1);
 			qe1 = qe_ + (e.reach_end? qe0 - qe_ : e.max_q + 1);
 		} else complete = false;
@@ -1364,8 +1367,8 @@ static int align1_inv(const mm355_index *mi, const mm355_mapopt_t *opt, int read
 		return 0;
 	}
 	const EzRes &ez = T.inv_res;
-	if (ez.cigar.empty()) return 0;
-	append_cigar(r_inv, ez.cigar);
+	if (ez.n_cigar <= 0) return 0;
+	append_cigar(r_inv, ez.cigar, ez.n_cigar);
 	r_inv->p->dp_score = ez.max;
 	r_inv->id = -1;
 	r_inv->parent = PARENT_UNSET;
@@ -1458,6 +1461,7 @@ static void gen_cs(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::
 {
 	int q_off = 0, t_off = 0;
 	char buf[16];
+	s.reserve(s.size() + (size_t)(r->qe - r->qs) / 2 + 64);
 	for (size_t i = 0; i < r->p->cigar.size(); ++i) {
 		int op = r->p->cigar[i] & 0xf, len = r->p->cigar[i] >> 4;
 		if (op == 0 || op == 7 || op == 8) {

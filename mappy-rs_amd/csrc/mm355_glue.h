@@ -26,7 +26,7 @@ struct Reg {                // U:minimap.h::mm_reg1_t
 
 struct EzRes {              // U:ksw2.h::ksw_extz_t as returned by the DP kernel
 	int32_t max = 0, zdropped = 0, max_q = -1, max_t = -1, mqe = 0, mqe_t = -1, mte = 0, mte_q = -1, score = 0, reach_end = 0;
-	std::vector<uint32_t> cigar;
+	const uint32_t *cigar = 0; int32_t n_cigar = 0;   // points into the per-round CIGAR arena kept alive by the batch
 	int state = 0;          // 0 none, 1 requested, 2 done
 };
 
@@ -48,7 +48,8 @@ struct AlnTask {            // U:align.c::mm_align1 split into a one-off preambl
 	int32_t bw, bw_long;
 	int split_inv;
 	bool prepared = false, done = false;
-	std::vector<EzRes> res;            // slot 0 left, 1 right, 2+2*i approx fill at seed i, 3+2*i exact fill at seed i
+	std::vector<EzRes> res;            // compact: only the extension problems that are actually requested
+	std::vector<int32_t> slot_of;      // logical slot (0 left, 1 right, 2+2*i approx fill at seed i, 3+2*i exact fill) -> index into res, -1 = none
 	// inversion attempt (U:align.c::mm_align1_inv)
 	EzRes inv_res; int inv_state = 0;  // 0 not tried, 1 waiting for DP, 2 finished
 };

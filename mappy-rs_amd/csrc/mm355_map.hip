@@ -52,7 +52,7 @@ static int host_threads()
 }
 
 static int host_threads();
-static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<ReadState> &rs, const std::vector<DpReq> &reqs)
+static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<ReadState> &rs, const std::vector<DpReq> &reqs, std::vector<std::vector<uint32_t>> &arenas)
 {
 	// chunk the requests so that the direction matrices of one launch fit the HBM budget
 	size_t free_b = 0, total_b = 0;
@@ -90,16 +90,24 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 		rc = mm355_dp_run(c, mo, jobs, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), &res, &cig);
 		if (rc) return rc;
 		const double tr1 = now_ms();
-		parallel_for((int64_t)(j - i), host_threads(), [&](int64_t kk, int) {   // distinct (read, task, slot) per request: no sharing
-			const size_t k = i + (size_t)kk;
-			const DpReq &q = reqs[k];
-			const mm355_dpres_t &r = res[k - i];
-			AlnTask &T = rs[q.read].tasks[q.task];
-			EzRes &e = q.slot >= 0? T.res[q.slot] : T.inv_res;
-			e.max = r.max; e.zdropped = r.zdropped; e.max_q = r.max_q; e.max_t = r.max_t; e.mqe = r.mqe; e.mqe_t = r.mqe_t;
-			e.mte = r.mte; e.mte_q = r.mte_q; e.score = r.score; e.reach_end = r.reach_end;
-			e.cigar.assign(cig + r.cigar_off, cig + r.cigar_off + r.n_cigar);
-			e.state = 2;
+		// one bulk copy of the dense CIGAR arena of this launch; results point into it (kept alive until the batch is finished)
+		size_t n_cg = 0;
+		for (size_t k = i; k < j; ++k) n_cg = std::max(n_cg, (size_t)(res[k - i].cigar_off + res[k - i].n_cigar));
+		arenas.emplace_back(cig, cig + n_cg);
+		const uint32_t *arena = arenas.back().data();
+		const int nt_d = host_threads();
+		parallel_for(nt_d, nt_d, [&](int64_t part, int) {   // static partition; every request owns a distinct (read, task, slot)
+			const size_t lo = i + (j - i) * (size_t)part / nt_d, hi = i + (j - i) * (size_t)(part + 1) / nt_d;
+			for (size_t k = lo; k < hi; ++k) {
+				const DpReq &q = reqs[k];
+				const mm355_dpres_t &r = res[k - i];
+				AlnTask &T = rs[q.read].tasks[q.task];
+				EzRes &e = q.slot >= 0? T.res[q.slot] : T.inv_res;
+				e.max = r.max; e.zdropped = r.zdropped; e.max_q = r.max_q; e.max_t = r.max_t; e.mqe = r.mqe; e.mqe_t = r.mqe_t;
+				e.mte = r.mte; e.mte_q = r.mte_q; e.score = r.score; e.reach_end = r.reach_end;
+				e.cigar = arena + r.cigar_off; e.n_cigar = r.n_cigar;
+				e.state = 2;
+			}
 		});
 		if (getenv("MM355_VERBOSE")) fprintf(stderr, "[mm355]     dp chunk: %zu jobs, gather %.1f ms, run %.1f ms, distribute %.1f ms\n", j - i, tg1 - tg0, tr1 - tg1, now_ms() - tr1);
 		i = j;
@@ -201,6 +209,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	double ms_host = now_ms() - t_host0;
 	tv_pre = now_ms() - tv0;
 	int n_rounds = 0;
+	std::vector<std::vector<uint32_t>> arenas;   // CIGAR arenas of all extension launches of this batch
 	// extension rounds: every pending problem of every read goes into the same launches
 	for (int round = 0; round < 64; ++round) {
 		const double th0 = now_ms();
@@ -216,7 +225,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		if (n_open.load() == 0) break;
 		if (reqs.empty()) return MM355_EINVAL;   // a read is waiting for a result nobody requested: logic error
 		const double td0 = now_ms();
-		if ((rc = run_dp_round(c, mo, rs, reqs))) return rc;
+		if ((rc = run_dp_round(c, mo, rs, reqs, arenas))) return rc;
 		tv_dp += now_ms() - td0; ++n_rounds;
 		if (verbose) fprintf(stderr, "[mm355]   round %d: %zu jobs, %lld reads open\n", round, reqs.size(), (long long)n_open.load());
 	}
