@@ -58,14 +58,20 @@ __device__ inline int8_t SB(uint64_t w, int i) { return (int8_t)(w >> (8 * i)); 
 // A workgroup is ONE wave: LDS traffic of a wave is executed in order, so lanes only need their own LDS operations to have
 // completed (lgkmcnt) -- __syncthreads() would also wait for every outstanding global store (vmcnt(0)), i.e. for the
 // direction-matrix bytes of the current anti-diagonal to reach HBM, which serialises the sweep on store latency.
-#define DP_SYNC() do { if (state_in_lds) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); } while (0)
-__global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+#define DP_SYNC() do { if (NT == WAVE && state_in_lds) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); } while (0)
+// NT = threads per alignment: 64 (one wave; x[t-1]/v[t-1] by a lane shuffle) for the short problems, 512 (eight waves share
+// one anti-diagonal; neighbours are re-read from LDS between two barriers) for long ones, whose single-wave sweep would
+// otherwise be the tail of the whole launch.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
                                                     const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, int32_t *offbase,
                                                     uint32_t *cigbase, uint64_t *stbase, int32_t *Hbase, mm355_dpres_t *res,
                                                     int lds_cap, unsigned long long *cells_ctr, uint32_t *dense, unsigned long long *dense_ctr)
 {
 	extern __shared__ uint64_t lds[];
 	// [lds_cap] state words, then [lds_cap] int32 H
+	__shared__ uint64_t s_carry[2];
+	__shared__ int32_t s_rh[NT / WAVE][4], s_rt[NT / WAVE][4];
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_jobs) return;
 	const int jid = job_ids[blockIdx.x];
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 	{   // memset(u,v,x,y = -q-e; x2,y2 = -q2-e2); s = 0; H = NEG_INF
 		const uint8_t a = (uint8_t)I8(-q - e), b = (uint8_t)I8(-q2 - e2);
 		const uint64_t init = (uint64_t)a | (uint64_t)a << 8 | (uint64_t)a << 16 | (uint64_t)a << 24 | (uint64_t)b << 32 | (uint64_t)b << 40;
-		for (int t = lane; t < T; t += WAVE) { S[t] = init; if (!approx_max) H[t] = KSW_NEG_INF; }
+		for (int t = lane; t < T; t += NT) { S[t] = init; if (!approx_max) H[t] = KSW_NEG_INF; }
 	}
 	DP_SYNC();
 	int last_st = -1, last_en = -1;
@@ -133,19 +139,32 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 		const int sc_end = st0 + ((en0 - st0) / 16 + 1) * 16;   // scores are (re)written for t in [st0, sc_end)
 		int8_t cx = x1, cv = v1, cx2 = x21;
 		uint8_t *pr = p + (size_t)r * n_col - st;
-		for (int c0 = st; c0 <= en; c0 += WAVE) {
+		int rnd = 0;
+		for (int c0 = st; c0 <= en; c0 += NT, ++rnd) {
 			const int t = c0 + lane;
 			const bool act = t <= en;
 			uint64_t old = act? S[t] : 0;
+			uint64_t oldm = 0;
+			if (NT > WAVE) {   // previous diagonal's cell t-1: LDS (or the word the previous round saved before overwriting it)
+				if (act && t > st) oldm = (lane == 0)? s_carry[(rnd + 1) & 1] : S[t - 1];
+				__syncthreads();
+				if (act && lane == NT - 1) s_carry[rnd & 1] = old;
+			}
 			int8_t ou = SB(old, 0), ov = SB(old, 1), ox = SB(old, 2), oy = SB(old, 3), ox2 = SB(old, 4), oy2 = SB(old, 5), os = SB(old, 6);
 			if (edge && t == r) { oy = I8(-q - e); oy2 = I8(-q2 - e2); ou = edge_u; }
 			// x[t-1], v[t-1], x2[t-1] of the previous diagonal: neighbour lane, or the carry from the previous chunk
-			int pk = (uint8_t)ox | (uint8_t)ov << 8 | (uint8_t)ox2 << 16;
-			int nb = __shfl_up(pk, 1);
-			int8_t xt1 = (int8_t)nb, vt1 = (int8_t)(nb >> 8), x2t1 = (int8_t)(nb >> 16);
-			if (lane == 0) { xt1 = cx; vt1 = cv; x2t1 = cx2; }
-			int last = __shfl(pk, 63);
-			cx = (int8_t)last; cv = (int8_t)(last >> 8); cx2 = (int8_t)(last >> 16);
+			int8_t xt1, vt1, x2t1;
+			if (NT == WAVE) {
+				int pk = (uint8_t)ox | (uint8_t)ov << 8 | (uint8_t)ox2 << 16;
+				int nb = __shfl_up(pk, 1);
+				xt1 = (int8_t)nb, vt1 = (int8_t)(nb >> 8), x2t1 = (int8_t)(nb >> 16);
+				if (lane == 0) { xt1 = cx; vt1 = cv; x2t1 = cx2; }
+				int last = __shfl(pk, 63);
+				cx = (int8_t)last; cv = (int8_t)(last >> 8); cx2 = (int8_t)(last >> 16);
+			} else {
+				xt1 = SB(oldm, 2), vt1 = SB(oldm, 1), x2t1 = SB(oldm, 4);
+				if (t == st) { xt1 = x1; vt1 = v1; x2t1 = x21; }
+			}
 			int8_t z;
 			if (t >= st0 && t < sc_end) {
 				const uint8_t sq = t < tlen? target[t] : 0;
@@ -189,6 +208,7 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 				       (uint64_t)(uint8_t)nx2 << 32 | (uint64_t)(uint8_t)ny2 << 40 | (uint64_t)(uint8_t)sc << 48;
 				pr[t] = d;
 			}
+			if (NT > WAVE) __syncthreads();
 		}
 		{   // the last unaligned 16-byte score store may reach past `en`: those s[] bytes persist for later diagonals
 			const int t = en + 1 + lane;
@@ -212,7 +232,7 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 				max_H = hen; max_t = en0;
 				// 4-lane strided maxima over [st0,en1): class = (t - st0) & 3, strict > keeps the first t of a class
 				int32_t bh = INT32_MIN, bt = 0x7fffffff;
-				for (int t = st0 + lane; t < en1; t += WAVE) {
+				for (int t = st0 + lane; t < en1; t += NT) {
 					int32_t h = H[t] + (int32_t)SB(S[t], 1);
 					H[t] = h;
 					if (h > bh) bh = h, bt = t;
@@ -221,8 +241,16 @@ __global__ __launch_bounds__(WAVE) void k_ksw_extd2(DpConst dc, const DpJobDev *
 					int32_t oh = __shfl_xor(bh, o), ot = __shfl_xor(bt, o);
 					if (oh > bh || (oh == bh && ot < bt)) bh = oh, bt = ot;
 				}
+				if (NT > WAVE) {   // combine the waves (same class = same lane & 3, NT is a multiple of 4)
+					if ((lane & 63) < 4) { s_rh[lane >> 6][lane & 3] = bh; s_rt[lane >> 6][lane & 3] = bt; }
+					__syncthreads();
+					bh = INT32_MIN, bt = 0x7fffffff;
+					const int cl = lane & 3;
+					for (int wv = 0; wv < NT / WAVE; ++wv) { int32_t oh = s_rh[wv][cl], ot = s_rt[wv][cl]; if (oh > bh || (oh == bh && ot < bt)) bh = oh, bt = ot; }
+					__syncthreads();
+				}
 				for (int i = 0; i < 4; ++i) {        // HH[i] starts at H[en0]; combine in class order with strict <
-					int32_t hh = __shfl(bh, i), tt = __shfl(bt, i);
+					int32_t hh = __shfl(bh, i), tt = __shfl(bt, i);   // lanes 0..3 of every wave hold the class results
 					if (hh > hen) { if (max_H < hh) max_H = hh, max_t = tt; }
 				}
 				if (lane == 0) H[en0] = hen;
@@ -384,8 +412,9 @@ DpConst mm355_dp_const(const mm355_mapopt_t *mo)
 
 // LDS size classes of the per-target state (12 B per target position): small alignments get small footprints so that
 // up to 32 of them are resident per CU and hide each other's LDS round trips
-static const int DP_CLASS_CAP[] = { 256, 512, 1024, 4096, 0 };
-#define DP_N_CLASS 5
+static const int DP_CLASS_CAP[] = { 256, 512, 1024, 4096, 12288, 0 };
+static const int DP_CLASS_NT[]  = { 64, 64, 64, 512, 512, 512 };
+#define DP_N_CLASS 6
 
 // runs jobs whose code strings are already on the device (qbuf/tbuf); fills res[] and the cigar arena (host copies)
 int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
@@ -408,7 +437,6 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 		j.p_off = (int64_t)p_tot; j.off_off = (int64_t)off_tot; j.cig_off = (int64_t)cig_tot; j.st_off = 0;
 		if (j.qlen > 0 && j.tlen > 0 && !j.skip) {
 			p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
-			off_tot += (size_t)(j.qlen + j.tlen - 1) * 2;
 			cig_tot += (size_t)j.qlen + j.tlen + 2;
 			int cls = 0;
 			while (cls < DP_N_CLASS - 1 && T > DP_CLASS_CAP[cls]) ++cls;
@@ -417,7 +445,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 		} else ids[0].push_back((int32_t)i);
 	}
 	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64) ||
-	    c->dp_work.ensure((off_tot + 16) * 4 + (n + 16) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_dense.ensure((cig_tot + 16) * 4) ||
+	    c->dp_work.ensure((off_tot + 16) * 4 + (2 * n + 32) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_dense.ensure((cig_tot + 16) * 4) ||
 	    c->dp_H.ensure((st_tot + 16) * 12)) return MM355_ENOMEM;
 	HIPCHK(hipMemcpyAsync(c->dp_jobs.p, jobs.data(), n * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
 	int32_t *d_off = c->dp_work.as<int32_t>();
@@ -428,23 +456,39 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
-		size_t done = 0;
+		// every size class gets its own HIP stream: the few long alignments of the big classes run concurrently with the
+		// thousands of short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
+		std::vector<int32_t> all_ids; all_ids.reserve(n);
+		size_t cls_off[DP_N_CLASS];
+		for (int cls = 0; cls < DP_N_CLASS; ++cls) { cls_off[cls] = all_ids.size(); all_ids.insert(all_ids.end(), ids[cls].begin(), ids[cls].end()); }
+		HIPCHK(hipMemcpyAsync(d_ids, all_ids.data(), all_ids.size() * 4, hipMemcpyHostToDevice, c->st));
+		HIPCHK(hipStreamSynchronize(c->st));   // all_ids is pageable; also orders the class streams after the uploads
 		for (int cls = DP_N_CLASS - 1; cls >= 0; --cls) {   // big problems first
 			if (ids[cls].empty()) continue;
-			HIPCHK(hipMemcpyAsync(d_ids + done, ids[cls].data(), ids[cls].size() * 4, hipMemcpyHostToDevice, c->st));
+			if (c->dp_st[cls] == 0) { HIPCHK(hipStreamCreateWithFlags(&c->dp_st[cls], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->dp_ev[cls], hipEventDisableTiming)); }
 			int cap = DP_CLASS_CAP[cls];
 			size_t lds = (size_t)cap * 12;
-			hipLaunchKernelGGL(k_ksw_extd2, dim3((unsigned)ids[cls].size()), dim3(WAVE), lds, c->st, dc, c->dp_jobs.as<DpJobDev>(), d_ids + done,
-			                   (int)ids[cls].size(), d_q, d_t, c->dp_bt.as<uint8_t>(), d_off, c->dp_cig.as<uint32_t>(), d_S, d_H,
-			                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
-			done += ids[cls].size();
+			if (DP_CLASS_NT[cls] == 64)
+				hipLaunchKernelGGL(k_ksw_extd2<64>, dim3((unsigned)ids[cls].size()), dim3(64), lds, c->dp_st[cls], dc, c->dp_jobs.as<DpJobDev>(), d_ids + cls_off[cls],
+				                   (int)ids[cls].size(), d_q, d_t, c->dp_bt.as<uint8_t>(), d_off, c->dp_cig.as<uint32_t>(), d_S, d_H,
+				                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
+			else {
+				static bool attr_set = false;
+				if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12); attr_set = true; }
+				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3((unsigned)ids[cls].size()), dim3(512), lds, c->dp_st[cls], dc, c->dp_jobs.as<DpJobDev>(), d_ids + cls_off[cls],
+				                   (int)ids[cls].size(), d_q, d_t, c->dp_bt.as<uint8_t>(), d_off, c->dp_cig.as<uint32_t>(), d_S, d_H,
+				                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
+			}
+			HIPCHK(hipEventRecord(c->dp_ev[cls], c->dp_st[cls]));
+			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[cls], 0));
 		}
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		std::vector<int32_t> order(n);
 		for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
 		std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return jobs[x].qlen + jobs[x].tlen > jobs[y].qlen + jobs[y].tlen; });
-		HIPCHK(hipMemcpyAsync(d_ids, order.data(), n * 4, hipMemcpyHostToDevice, c->st));
-		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids, (int)n,
+		int32_t *d_ord = d_ids + n + 8;
+		HIPCHK(hipMemcpyAsync(d_ord, order.data(), n * 4, hipMemcpyHostToDevice, c->st));
+		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ord, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
 		HIPCHK(hipStreamSynchronize(c->st));   // `order` is pageable
 	}

@@ -112,6 +112,9 @@ void mm355_index_free_device(mm355_index *mi)
 }
 
 #define GRID(n, b) dim3((unsigned)(((n) + (b) - 1) / (b)))
+#include <chrono>
+static double ib_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define IB_LOG(what) do { if (getenv("MM355_VERBOSE")) { (void)hipStreamSynchronize(st); fprintf(stderr, "[mm355] index build: %-28s %.2f s\n", what, ib_now() - t_ib); t_ib = ib_now(); } } while (0)
 
 extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, const uint8_t *const *seqs, const int64_t *lens, const char *const *names,
                                         int device, mm355_index_t **out)
@@ -123,6 +126,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) return MM355_ENODEV;
 	HIPCHK(hipSetDevice(device));
 	hipStream_t st; HIPCHK(hipStreamCreate(&st));
+	double t_ib = ib_now();
 	mm355_index *mi = new mm355_index();
 	mi->w = io->w < 1? 1 : io->w; mi->k = io->k; mi->b = io->bucket_bits; mi->flag = io->flag; mi->n_seq = n_seq;
 	if (mi->k * 2 < mi->b) mi->b = mi->k * 2;
@@ -147,6 +151,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 	if (d_seq.ensure((size_t)max_len + 64) || d_slots16.ensure(((size_t)max_len + 64) * 16) || d_cn.ensure((max_chunks + 1) * 4) || d_co.ensure((max_chunks + 1) * 4) ||
 	    d_keys.ensure(cap * 8) || d_vals.ensure(cap * 8) || d_err.ensure(16)) FAIL(MM355_ENOMEM);
 	(void)hipMemsetAsync(d_err.p, 0, 16, st);
+	IB_LOG("alloc");
 	for (int i = 0; i < n_seq; ++i) {
 		const int64_t len = lens[i];
 		if (len <= 0) continue;
@@ -174,6 +179,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		(void)hipMemcpy(&e, d_err.p, 4, hipMemcpyDeviceToHost);
 		if (e) FAIL(MM355_ENOMEM);
 	}
+	IB_LOG("sketch contigs");
 	d_seq.release(); d_slots16.release();
 	mi->n_minimizers = (int64_t)n;
 	if (n == 0) FAIL(MM355_EIO);
@@ -185,6 +191,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		if (d_tmp.ensure(tb + 256)) FAIL(MM355_ENOMEM);
 		if (rocprim::radix_sort_pairs(d_tmp.p, tb, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_vals.as<uint64_t>(), d_vals2.as<uint64_t>(), (size_t)n, 0u, (unsigned)(2 * mi->k), st) != hipSuccess) FAIL(MM355_EHIP);
 		if (hipStreamSynchronize(st) != hipSuccess) FAIL(MM355_EHIP);
+		IB_LOG("radix sort");
 		d_keys.release(); d_vals.release();
 		uint64_t *keys = d_keys2.as<uint64_t>(), *vals = d_vals2.as<uint64_t>();
 		// runs
@@ -213,6 +220,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		if (hipStreamSynchronize(st) != hipSuccess) FAIL(MM355_EHIP);
 		if (n_pos >= (1ULL << 32)) FAIL(MM355_EUNSUP);   // offset<<32|count packing
 		mi->n_pos = n_pos;
+		IB_LOG("runs + scans");
 		// table
 		uint64_t want = (uint64_t)(n_runs / 0.55) + MM355_SLOTS_PER_LINE, n_lines = 1;
 		while (n_lines * MM355_SLOTS_PER_LINE < want) n_lines <<= 1;
@@ -224,6 +232,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		                   (mm355_slot*)mi->d_slots, n_lines - 1);
 		hipLaunchKernelGGL(k_fill_pos, GRID(n, 256), dim3(256), 0, st, vals, d_rid.as<uint32_t>(), d_starts.as<uint64_t>(), d_len.as<uint32_t>(), d_moff.as<uint64_t>(), n,
 		                   (uint64_t*)mi->d_pos);
+		IB_LOG("table insert + pos fill");
 		// occurrence-count tail for mm_idx_cal_max_occ: sort counts descending, keep the top 2M
 		DBuf d_len2;
 		if (d_len2.ensure((n_runs + 1) * 4)) FAIL(MM355_ENOMEM);
@@ -238,8 +247,10 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		if (hipGetLastError() != hipSuccess) FAIL(MM355_EHIP);
 		d_flag.release(); d_rid.release(); d_starts.release(); d_len.release(); d_multi.release(); d_moff.release(); d_len2.release();
 	}
+	IB_LOG("count tail");
 	mi->S.resize(Sw);
 	if (hipMemcpy(mi->S.data(), dS, Sw * 4, hipMemcpyDeviceToHost) != hipSuccess) FAIL(MM355_EHIP);
+	IB_LOG("S to host");
 	mi->d_S = dS; dS = 0;
 	mi->dev_resident = true; mi->dev_id = device;
 done:

@@ -28,7 +28,8 @@ __device__ int sketch_chunk(const uint8_t *seq, int len, int w, int k, int cs, i
 		for (j = 0; j < w; ++j) BUF(j).x = BUF(j).y = UINT64_MAX;
 		// proof state
 		int n_real = 0, cnt_c = 0, writes_ok = 0, writes_after = 0;
-		bool jstar = from_start, seen_n = false, ok = from_start, trust = from_start, retry = false;
+		// odd k: a k-mer never equals its reverse complement, so no skip decision depends on bases before the warm-up
+		bool jstar = from_start || (k & 1), seen_n = false, ok = from_start, trust = from_start, retry = false;
 #define MM_EMIT(v) do { uint32_t pp_ = (uint32_t)(v).y >> 1; if ((int)pp_ >= cs && (int)pp_ < ce) out[n++] = (v); } while (0)
 		for (i = s0; i < len; ++i) {
 			if (i == cs && !trust) { retry = true; break; }
