@@ -106,8 +106,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ecoli")
-    ap.add_argument("--reads", type=int, default=8192, help="reads per step per GPU")
-    ap.add_argument("--streams", type=int, default=2, help="concurrent contexts (HIP streams) per GPU")
+    ap.add_argument("--reads", type=int, default=16384, help="reads per step per GPU")
+    ap.add_argument("--streams", type=int, default=4, help="concurrent contexts (HIP streams) per GPU")
     ap.add_argument("--scale", type=float, default=1.0, help="genome scale of the human workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
