@@ -810,10 +810,15 @@ void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, Read
 	n = filter_strand_retained(n, rs.regs.data());
 	rs.regs.resize(n);
 	// U:align.c::mm_align_skeleton prologue: query codes and anchor squeeze
-	rs.qc[0].resize(qlen); rs.qc[1].resize(qlen);
-	for (int i = 0; i < qlen; ++i) {
-		uint8_t c = (uint8_t)mm_nt4((uint8_t)rs.seq[i]);
-		rs.qc[0][i] = c; rs.qc[1][qlen - 1 - i] = c < 4? 3 - c : 4;
+	static const struct Nt4Lut { uint8_t t[256]; Nt4Lut() { for (int c = 0; c < 256; ++c) t[c] = (uint8_t)mm_nt4((uint8_t)c); } } lut;
+	rs.qc[0].resize(qlen);
+	for (int i = 0; i < qlen; ++i) rs.qc[0][i] = lut.t[(uint8_t)rs.seq[i]];
+	bool any_rev = false;
+	for (int i = 0; i < n; ++i) any_rev |= rs.regs[i].rev != 0;
+	rs.qc[1].clear();
+	if (any_rev || n == 0) {   // the reverse-complement code string is only read by reverse-strand regions (and inversions, see ensure_rev)
+		rs.qc[1].resize(qlen);
+		for (int i = 0; i < qlen; ++i) { uint8_t c = rs.qc[0][i]; rs.qc[1][qlen - 1 - i] = c < 4? 3 - c : 4; }
 	}
 	rs.n_a = squeeze_a(n, rs.regs.data(), rs.a.data());
 	rs.cursor = 0; rs.aligned = n == 0;
@@ -832,8 +837,15 @@ static void getseq(const mm355_index *mi, uint32_t rid, int32_t st, int32_t en, 
 {
 	if (rid >= mi->n_seq || (uint32_t)st >= mi->seq_len[rid]) return;
 	if ((uint32_t)en > mi->seq_len[rid]) en = (int32_t)mi->seq_len[rid];
-	uint64_t b = mi->seq_off[rid];
-	for (int32_t i = st; i < en; ++i) { uint64_t o = b + (uint64_t)i; out[i - st] = (uint8_t)(mi->S[o >> 3] >> ((o & 7) << 2) & 0xf); }
+	uint64_t o = mi->seq_off[rid] + (uint64_t)st, e = mi->seq_off[rid] + (uint64_t)en;
+	const uint32_t *S = mi->S.data();
+	for (; o < e && (o & 7); ++o) *out++ = (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
+	for (; o + 8 <= e; o += 8, out += 8) {   // one packed word = 8 bases
+		uint32_t w = S[o >> 3];
+		out[0] = w & 0xf; out[1] = w >> 4 & 0xf; out[2] = w >> 8 & 0xf; out[3] = w >> 12 & 0xf;
+		out[4] = w >> 16 & 0xf; out[5] = w >> 20 & 0xf; out[6] = w >> 24 & 0xf; out[7] = w >> 28;
+	}
+	for (; o < e; ++o) *out++ = (uint8_t)(S[o >> 3] >> ((o & 7) << 2) & 0xf);
 }
 
 // local Smith-Waterman score/end as U:ksw2_ll_sse.c::ksw_ll_i16 reports them (query padded to a multiple of 8 with
@@ -976,7 +988,10 @@ static void fix_cigar(Reg *r, const uint8_t *qseq, const uint8_t *tseq, int *qsh
 	cg.resize(n_cigar);
 }
 
-static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e)
+static void gen_cs(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::string &s);
+static void gen_md(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::string &s);
+
+static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int out_flags = 0)
 {
 	int32_t qshift, tshift, toff = 0, qoff = 0;
 	double s = 0.0, max = 0.0;
@@ -1015,6 +1030,8 @@ static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const
 		} else if (op == 3) toff += len;
 	}
 	p->dp_max = (int32_t)(max + .499);
+	if (out_flags & MM355_OUT_CS) { p->cs.clear(); gen_cs(r, qseq, tseq, p->cs); }
+	if (out_flags & MM355_OUT_MD) { p->md.clear(); gen_md(r, qseq, tseq, p->md); }
 }
 
 static int *collect_long_gaps(int as1, int cnt1, const mm128 *a, int min_gap, int *n_, std::vector<int> &K)
@@ -1228,7 +1245,7 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 	const int qlen = rs.qlen, kh = mi->k >> 1;
 	const int32_t rid = T.rid, rev = T.rev, as1 = T.as1, cnt1 = T.cnt1;
 	int32_t rs_ = T.rs, qs_ = T.qs, re_ = T.re, qe_ = T.qe;
-	const int32_t rs0 = T.rs0, qs0 = T.qs0, re0 = T.re0, qe0 = T.qe0;
+	const int32_t qs0 = T.qs0, re0 = T.re0, qe0 = T.qe0;
 	int32_t rs1, qs1, re1, qe1, dropped = 0;
 	bool complete = true;
 	int8_t mat[25];
@@ -1313,7 +1330,7 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 		r->p = new Extra(tmp);
 		tseq.resize((size_t)(re1 - rs1) + 1);
 		getseq(mi, (uint32_t)rid, rs1, re1, tseq.data());
-		update_extra(r, rs.qc[r->rev].data() + qs1, tseq.data(), mat, (int8_t)opt->q, (int8_t)opt->e);
+		update_extra(r, rs.qc[r->rev].data() + qs1, tseq.data(), mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags);
 	}
 	return true;
 }
@@ -1327,8 +1344,16 @@ static void request_left(const mm355_mapopt_t *opt, int read_id, int task_id, Al
 }
 
 // U:align.c::mm_align1_inv; uses slot machinery of the *second* region's task (inv_res)
+static void ensure_rev(ReadState &rs)
+{
+	if ((int)rs.qc[1].size() == rs.qlen) return;
+	rs.qc[1].resize(rs.qlen);
+	for (int i = 0; i < rs.qlen; ++i) { uint8_t c = rs.qc[0][i]; rs.qc[1][rs.qlen - 1 - i] = c < 4? 3 - c : 4; }
+}
+
 static int align1_inv(const mm355_index *mi, const mm355_mapopt_t *opt, int read_id, ReadState &rs, int i, int task_id, Reg *r_inv, std::vector<DpReq> &reqs, bool *pending)
 {
+	ensure_rev(rs);
 	const Reg *r1 = &rs.regs[i - 1], *r2 = &rs.regs[i];
 	AlnTask &T = rs.tasks[task_id];
 	const int qlen = rs.qlen;
@@ -1380,7 +1405,7 @@ static int align1_inv(const mm355_index *mi, const mm355_mapopt_t *opt, int read
 	else { r_inv->qe = r2->qs - q_off; r_inv->qs = r_inv->qe - (ez.max_q + 1); }
 	r_inv->rs = r1->re + t_off;
 	r_inv->re = r_inv->rs + ez.max_t + 1;
-	update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, (int8_t)opt->q, (int8_t)opt->e);
+	update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags);
 	return 1;
 }
 
@@ -1397,8 +1422,9 @@ static int ensure_task(const mm355_index *mi, const mm355_mapopt_t *opt, ReadSta
 	return r.task;
 }
 
-bool mm355_glue_align_step(const mm355_index *mi, const mm355_mapopt_t *opt, int read_id, ReadState &rs, std::vector<DpReq> &reqs)
+bool mm355_glue_align_step(const mm355_index *mi, const mm355_mapopt_t *opt, int read_id, ReadState &rs, std::vector<DpReq> &reqs, int flags)
 {
+	rs.out_flags = flags;
 	if (rs.aligned) return true;
 	// commit in skeleton order
 	while (rs.cursor < (int)rs.regs.size()) {
@@ -1532,11 +1558,8 @@ void mm355_glue_finish(const mm355_index *mi, const mm355_mapopt_t *opt, ReadSta
 			h.n_cigar = (int32_t)r->p->cigar.size(); h.cigar_off = (int64_t)cigar.size();
 			cigar.insert(cigar.end(), r->p->cigar.begin(), r->p->cigar.end());
 			h.dp_max = r->p->dp_max; h.dp_max2 = r->p->dp_max2; h.dp_score = r->p->dp_score;
-			if (flags & (MM355_OUT_CS | MM355_OUT_MD)) {
-				get_aln_seqs(mi, rs, r, q, t);
-				if (flags & MM355_OUT_CS) { std::string s; gen_cs(r, q.data(), t.data(), s); h.cs_off = (int64_t)str.size(); h.cs_len = (int64_t)s.size(); str += s; str += '\0'; }
-				if (flags & MM355_OUT_MD) { std::string s; gen_md(r, q.data(), t.data(), s); h.md_off = (int64_t)str.size(); h.md_len = (int64_t)s.size(); str += s; str += '\0'; }
-			}
+			if (flags & MM355_OUT_CS) { h.cs_off = (int64_t)str.size(); h.cs_len = (int64_t)r->p->cs.size(); str += r->p->cs; str += '\0'; }
+			if (flags & MM355_OUT_MD) { h.md_off = (int64_t)str.size(); h.md_len = (int64_t)r->p->md.size(); str += r->p->md; str += '\0'; }
 		}
 		hits.push_back(h);
 	}

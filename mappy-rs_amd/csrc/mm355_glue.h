@@ -11,6 +11,7 @@ struct Extra {
 	int32_t dp_score = 0, dp_max = 0, dp_max2 = 0;
 	uint32_t n_ambi = 0;
 	std::vector<uint32_t> cigar;
+	std::string cs, md;     // written when the region is committed (the code strings are at hand there)
 };
 
 struct Reg {                // U:minimap.h::mm_reg1_t
@@ -55,6 +56,7 @@ struct AlnTask {            // U:align.c::mm_align1 split into a one-off preambl
 };
 
 struct ReadState {
+	int out_flags = 0;                 // MM355_OUT_CS / MM355_OUT_MD requested for this batch
 	int32_t qlen = 0;
 	const char *seq = 0;
 	std::vector<uint8_t> qc[2];        // query codes forward / reverse-complement
@@ -75,7 +77,7 @@ struct GlueStats { int64_t n_rmq = 0, n_rounds = 0, n_jobs = 0; };
 void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs);
 // stage 2: advance the skeleton of one read as far as cached DP results allow; appends missing DP problems to `reqs`.
 // returns true when the read needs no more DP.
-bool mm355_glue_align_step(const mm355_index *mi, const mm355_mapopt_t *opt, int read_id, ReadState &rs, std::vector<DpReq> &reqs);
+bool mm355_glue_align_step(const mm355_index *mi, const mm355_mapopt_t *opt, int read_id, ReadState &rs, std::vector<DpReq> &reqs, int flags);
 // stage 3: post-DP filtering, sorting, selection and MAPQ; emits hit records
 void mm355_glue_finish(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs, int flags,
                        std::vector<mm355_hit_t> &hits, std::vector<uint32_t> &cigar, std::string &str);

@@ -216,7 +216,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		std::vector<std::vector<DpReq>> treq(nt);
 		std::atomic<int64_t> n_open(0);
 		parallel_for(n_reads, nt, [&](int64_t i, int tid) {
-			if (!mm355_glue_align_step(mi, mo, (int)i, rs[i], treq[tid])) n_open.fetch_add(1);
+			if (!mm355_glue_align_step(mi, mo, (int)i, rs[i], treq[tid], flags)) n_open.fetch_add(1);
 		});
 		std::vector<DpReq> reqs;
 		for (auto &v : treq) reqs.insert(reqs.end(), v.begin(), v.end());
