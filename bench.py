@@ -156,7 +156,6 @@ def main():
     # `--streams S`: S contexts (own HIP stream + buffers) on this GPU, each with 1/S of the step's reads resident in HBM;
     # a step maps all of them concurrently from S host threads, so the host tail of one sub-batch overlaps kernels of another.
     n_str = max(1, args.streams)
-    os.environ.setdefault("MM355_HOST_THREADS", str(max(2, 16 // n_str)))
     ctxs, parts = [], []
     for si in range(n_str):
         ctx = C.c_void_p()

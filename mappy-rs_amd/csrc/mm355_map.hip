@@ -28,28 +28,64 @@ __global__ __launch_bounds__(256) void k_pack_chains(int n_reads, const int64_t 
 	for (int i = threadIdx.x; i < n_mini[r]; i += 256) pm[mo[r] + i] = mini_pos[ro + i];
 }
 
+// One process-wide pool of host threads shared by every context: while some contexts wait for their kernels the others
+// get all the cores for the host tail (a per-context pool would leave cores idle whenever contexts are out of phase).
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+struct PJob { std::atomic<int64_t> next{0}; int64_t n = 0; std::function<void(int64_t, int)> f; std::atomic<int> pending{0}; std::atomic<int> tid{1}; };
+class HostPool {
+public:
+	// intentionally leaked: destroying a condition variable with parked workers at process exit would block in pthread_cond_destroy
+	static HostPool &get() { static HostPool *p = new HostPool(); return *p; }
+	int size() const { return (int)th.size() + 1; }
+	void run(int64_t n, int want_threads, std::function<void(int64_t, int)> f) {
+		if (n <= 0) return;
+		int helpers = std::min<int64_t>((int64_t)std::min(want_threads, size()) - 1, n - 1);
+		if (helpers <= 0) { for (int64_t i = 0; i < n; ++i) f(i, 0); return; }
+		auto j = std::make_shared<PJob>();
+		j->n = n; j->f = std::move(f); j->pending = helpers;
+		{ std::lock_guard<std::mutex> lk(m); for (int h = 0; h < helpers; ++h) q.push_back(j); }
+		cv.notify_all();
+		for (;;) { int64_t i = j->next.fetch_add(1); if (i >= n) break; j->f(i, 0); }
+		{   // withdraw tickets nobody picked up, then wait for the helpers that did start
+			std::lock_guard<std::mutex> lk(m);
+			for (auto it = q.begin(); it != q.end();) { if (it->get() == j.get()) { it = q.erase(it); j->pending.fetch_sub(1); } else ++it; }
+		}
+		while (j->pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+	}
+private:
+	HostPool() {
+		const char *e = getenv("MM355_HOST_THREADS");
+		int n = e? atoi(e) : 16;   // the GPU box gives one GPU a 16-core CPU share
+		if (n < 1) n = 1;
+		if (n > 64) n = 64;
+		for (int i = 1; i < n; ++i) th.emplace_back([this]() { worker(); });
+		for (auto &t : th) t.detach();
+	}
+	void worker() {
+		for (;;) {
+			std::shared_ptr<PJob> j;
+			{ std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&]() { return !q.empty(); }); j = q.front(); q.pop_front(); }
+			const int tid = j->tid.fetch_add(1);
+			for (;;) { int64_t i = j->next.fetch_add(1); if (i >= j->n) break; j->f(i, tid); }
+			j->pending.fetch_sub(1, std::memory_order_release);
+		}
+	}
+	std::vector<std::thread> th; std::mutex m; std::condition_variable cv; std::deque<std::shared_ptr<PJob>> q;
+};
+
 template <typename F>
 static void parallel_for(int64_t n, int n_threads, F f)
 {
-	if (n_threads <= 1 || n < 2) { for (int64_t i = 0; i < n; ++i) f(i, 0); return; }
-	std::atomic<int64_t> next(0);
-	std::vector<std::thread> th;
-	auto work = [&](int tid) { for (;;) { int64_t i = next.fetch_add(1); if (i >= n) break; f(i, tid); } };
-	for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t);
-	work(0);
-	for (auto &t : th) t.join();
+	HostPool::get().run(n, n_threads, std::function<void(int64_t, int)>(f));
 }
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static int host_threads()
-{
-	const char *e = getenv("MM355_HOST_THREADS");
-	int n = e? atoi(e) : (int)std::thread::hardware_concurrency();
-	if (n < 1) n = 1;
-	if (n > 16) n = 16;   // the GPU box gives one GPU a 16-core CPU share
-	return n;
-}
+static int host_threads() { return HostPool::get().size(); }
 
 static int host_threads();
 static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<ReadState> &rs, const std::vector<DpReq> &reqs, std::vector<std::vector<uint32_t>> &arenas)
