@@ -489,6 +489,189 @@ __global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors a
 	if (threadIdx.x == 0 && n > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
 }
 
+// ---- heavy reads: the top radix levels of an array with tens/hundreds of thousands of elements are done by a whole
+// 1024-thread block (k_sort_level_mw: same label-walk level as wave_rs_level_walk, block-wide ordered prefix), which
+// emits the resulting buckets as independent tasks; tasks that are still large go through another block level, the rest
+// is finished by one wave each (k_sort_tasks).  The latency of the slowest read drops from O(n) wave-serial steps per
+// level to O(n/1024) + the 1-byte label walk.
+struct SortTask { int32_t read; uint32_t beg, end; int32_t s; };
+#define MW_NT 1024
+#define MW_LAB_CAP 122880   // 120 KB of labels in LDS
+#define MW_BIG 16384        // buckets larger than this take another block-level pass
+
+int mm355_sort_heavy_threshold(void);
+template <typename T> struct SortArr;   // per-read base pointers of the array being sorted and of its scratch
+template <> struct SortArr<mm128> {
+	__device__ static mm128 *arr(const DevAnchors &an, int64_t o) { return an.a + o; }
+	__device__ static WalkScratch ws(const DevAnchors &an, int64_t o) { WalkScratch w; w.out = an.b + o; w.fpos = (uint32_t*)an.f + o; w.rank = (uint32_t*)an.p + o; w.flab = an.t8 + o; return w; }
+};
+template <> struct SortArr<uint64_t> {   // z[] of the backtrack: v[] and vi[] are free at that point
+	__device__ static uint64_t *arr(const DevAnchors &an, int64_t o) { return an.z + o; }
+	__device__ static WalkScratch ws(const DevAnchors &an, int64_t o) { WalkScratch w; w.out = an.u2 + o; w.fpos = (uint32_t*)an.vi + o; w.rank = (uint32_t*)an.v + o; w.flab = an.t8 + o; return w; }
+};
+
+struct MwLds {
+	uint32_t cnt[256], bb[256], be[256], cur[256], fend[256], arr[256], abef[256], fst[256];
+	uint32_t wtot[MW_NT / WAVE];
+	uint32_t nfor, single;
+};
+
+// block-wide exclusive count of `flag` over the threads of this iteration, in thread order; returns the offset and adds the total to *base
+__device__ inline uint32_t block_ordered_prefix(bool flag, uint32_t &base, MwLds *L)
+{
+	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const unsigned long long mask = __ballot(flag);
+	if (lane == 0) L->wtot[wv] = (uint32_t)__popcll(mask);
+	__syncthreads();
+	uint32_t before = 0, tot = 0;
+	for (uint32_t w2 = 0; w2 < MW_NT / WAVE; ++w2) { const uint32_t c = L->wtot[w2]; if (w2 < wv) before += c; tot += c; }
+	const uint32_t off = base + before + (uint32_t)__popcll(mask & LANE_LT_MASK(lane));
+	base += tot;
+	__syncthreads();
+	return off;
+}
+
+template <typename T, typename Key>
+__global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const SortTask *tasks, int n_tasks, SortTask *out_big, SortTask *out_small, unsigned int *ctr, uint32_t big_min, int *err)
+{
+	__shared__ MwLds L;
+	extern __shared__ uint8_t lds_lab[];   // MW_LAB_CAP labels
+	if ((int)blockIdx.x >= n_tasks) return;
+	const SortTask tk = tasks[blockIdx.x];
+	const int64_t o = an.aoff[tk.read];
+	T *a = SortArr<T>::arr(an, o);
+	const WalkScratch ws = SortArr<T>::ws(an, o);
+	Key key;
+	const uint32_t tid = threadIdx.x, beg = tk.beg, end = tk.end, tot = end - beg;
+	int s = tk.s;
+	// skip the levels where every key has the same byte (identity permutation)
+	for (;;) {
+		for (uint32_t i = tid; i < 256; i += MW_NT) L.cnt[i] = 0;
+		if (tid == 0) L.single = 0;
+		__syncthreads();
+		for (uint32_t i = beg + tid; i < end; i += MW_NT) atomicAdd(&L.cnt[(uint32_t)(key(a[i]) >> s) & 255u], 1u);
+		__syncthreads();
+		if (tid < 256 && L.cnt[tid] == tot) L.single = 1;
+		__syncthreads();
+		if (!L.single) break;
+		if (s == 0) return;          // all keys equal: nothing moves
+		s -= 8;
+		__syncthreads();
+	}
+	if (tid == 0) { uint32_t acc = 0; for (int k = 0; k < 256; ++k) { L.bb[k] = acc; acc += L.cnt[k]; L.be[k] = acc; } }
+	__syncthreads();
+	T *out = (T*)ws.out + beg;
+	uint32_t *fpos = ws.fpos + beg, *rank = ws.rank + beg;
+	uint8_t *flab = ws.flab + beg;
+	uint32_t nfor = 0;
+	for (uint32_t base = 0; base < tot; base += MW_NT) {
+		const uint32_t rel = base + tid;
+		uint32_t g = 0; bool foreign = false;
+		if (rel < tot) { g = (uint32_t)(key(a[beg + rel]) >> s) & 255u; foreign = !(rel >= L.bb[g] && rel < L.be[g]); }
+		const uint32_t e = block_ordered_prefix(foreign, nfor, &L);
+		if (foreign) { fpos[e] = rel; flab[e] = (uint8_t)g; if (e < MW_LAB_CAP) lds_lab[e] = (uint8_t)g; }
+	}
+	__syncthreads();
+	if (tid < 256) {
+		uint32_t lo = 0, hi = nfor; const uint32_t target = L.bb[tid];
+		while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (fpos[mid] < target) lo = mid + 1; else hi = mid; }
+		L.cur[tid] = lo; L.fst[tid] = lo; L.arr[tid] = 0;
+	}
+	__syncthreads();
+	if (tid < 256) L.fend[tid] = tid < 255? L.fst[tid + 1] : nfor;
+	__syncthreads();
+	if (tid == 0) {
+		const bool in_lds = nfor <= MW_LAB_CAP;
+		for (uint32_t k = 0; k < 256; ++k) {
+			L.abef[k] = L.arr[k];
+			while (L.cur[k] < L.fend[k]) {
+				uint32_t c = k;
+				do {
+					const uint32_t e = L.cur[c]++;
+					const uint32_t g = in_lds? lds_lab[e] : flab[e];
+					rank[e] = L.arr[g]++;
+					c = g;
+				} while (c != k);
+			}
+		}
+	}
+	__syncthreads();
+	uint32_t nfb = 0;
+	for (uint32_t base = 0; base < tot; base += MW_NT) {
+		const uint32_t rel = base + tid;
+		uint32_t g = 0; bool foreign = false; T el;
+		if (rel < tot) { el = a[beg + rel]; g = (uint32_t)(key(el) >> s) & 255u; foreign = !(rel >= L.bb[g] && rel < L.be[g]); }
+		const uint32_t pre = block_ordered_prefix(foreign, nfb, &L);
+		if (rel < tot) {
+			uint32_t dest;
+			const uint32_t al = L.abef[g], f0 = L.fst[g];
+			if (foreign) { const uint32_t r = rank[pre]; dest = r < al? (r == 0? L.bb[g] : fpos[f0 + r - 1] + 1) : fpos[f0 + r]; }
+			else dest = rel + ((pre - f0) < al? 1u : 0u);
+			out[dest] = el;
+		}
+	}
+	__syncthreads();
+	for (uint32_t i = tid; i < tot; i += MW_NT) a[beg + i] = out[i];
+	__syncthreads();
+	if (s > 0 && tid < 256) {   // children: big -> another block level, medium -> one wave each, <= 64 -> insertion sort right here
+		const uint32_t b0 = L.bb[tid], sz = L.cnt[tid];
+		if (sz > MM355_RS_MIN_SIZE) {
+			SortTask c; c.read = tk.read; c.beg = beg + b0; c.end = beg + b0 + sz; c.s = s - 8;
+			if (sz > big_min) out_big[atomicAdd(&ctr[0], 1u)] = c;
+			else out_small[atomicAdd(&ctr[1], 1u)] = c;
+		} else if (sz > 1) mm_rs_insertsort(a + beg + b0, a + beg + b0 + sz, key);
+	}
+	(void)err;
+}
+
+// one wave per task: finishes a bucket exactly as rs_sort(beg, end, 8, s) would
+template <typename T, typename Key>
+__global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTask *tasks, int n_tasks, int *err)
+{
+	__shared__ SortLds L;
+	__shared__ mm128 stage[2048];
+	if ((int)blockIdx.x >= n_tasks) return;
+	const SortTask tk = tasks[blockIdx.x];
+	const int64_t o = an.aoff[tk.read];
+	WalkScratch ws = SortArr<T>::ws(an, o);
+	ws.out = (T*)ws.out + tk.beg; ws.fpos += tk.beg; ws.rank += tk.beg; ws.flab += tk.beg;
+	if (threadIdx.x == 0) { L.stk_n = 0; L.overflow = 0; }
+	__syncthreads();
+	wave_rs_core<true>(SortArr<T>::arr(an, o) + tk.beg, tk.end - tk.beg, tk.s, Key(), &L, (T*)stage, (uint32_t)(sizeof(stage) / sizeof(T)), &ws);
+	if (threadIdx.x == 0 && L.overflow) *err = 1;
+}
+
+// host side of the heavy path: tasks0 (n0 entries, on the device) = whole arrays of the heavy reads at level 56
+template <typename T, typename Key>
+static int sort_heavy_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_small, unsigned int *d_ctr, int n0, int *err, hipStream_t st)
+{
+	(void)hipFuncSetAttribute((const void*)k_sort_level_mw<T, Key>, hipFuncAttributeMaxDynamicSharedMemorySize, MW_LAB_CAP);
+	int n_big = n0, cur = 0;
+	unsigned int h[2] = {0, 0};
+	if (hipMemsetAsync(d_ctr, 0, 8, st) != hipSuccess) return -1;
+	for (int level = 0; level < 9 && n_big > 0; ++level) {
+		hipLaunchKernelGGL((k_sort_level_mw<T, Key>), dim3(n_big), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], n_big, d_big[cur ^ 1], d_small + h[1], d_ctr, (uint32_t)mm355_sort_heavy_threshold(), err);
+		// counters: ctr[0] = children for the next block level (restarted per level), ctr[1] = running total of wave tasks
+		unsigned int hh[2];
+		if (hipMemcpyAsync(hh, d_ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+		if (hipStreamSynchronize(st) != hipSuccess) return -1;
+		n_big = (int)hh[0]; h[1] += hh[1];
+		if (hipMemsetAsync(d_ctr, 0, 8, st) != hipSuccess) return -1;
+		cur ^= 1;
+	}
+	if (h[1]) hipLaunchKernelGGL((k_sort_tasks<T, Key>), dim3(h[1]), dim3(WAVE), 0, st, an, d_small, (int)h[1], err);
+	return 0;
+}
+
+__global__ void k_make_heavy_tasks(DevAnchors an, const int32_t *heavy_first, int n_heavy, SortTask *tasks)
+{
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n_heavy) return;
+	const int r = heavy_first[i];
+	SortTask t; t.read = r; t.beg = 0; t.end = (uint32_t)(an.aoff[r + 1] - an.aoff[r]); t.s = 56;
+	tasks[i] = t;
+}
+
 // ------------------------------------------------------------------ a7: mg_lchain_dp (fill)
 #define TW_SIZE 8192
 #define TW_MASK (TW_SIZE - 1)
@@ -873,10 +1056,25 @@ void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const Dev
 	if (bt.n_reads == 0) return;
 	hipLaunchKernelGGL(k_seed_expand, dim3(bt.n_reads), dim3(256), 0, st, ix, pr, bt, sd, an);
 }
-void mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st)
+// heavy_first[0..n_heavy) = reads with more than MW_BIG anchors (block-level path, on st_heavy); the others take one wave each.
+// task_buf: device scratch for 3 task lists of `task_cap` entries each + 2 counters
+int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, int n_heavy, void *task_buf, size_t task_cap, hipStream_t st, hipStream_t st_heavy)
 {
-	if (bt.n_reads == 0) return;
-	hipLaunchKernelGGL(k_sort_anchors, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, an, err, heavy_first);
+	if (bt.n_reads == 0) return 0;
+	if (bt.n_reads > n_heavy) hipLaunchKernelGGL(k_sort_anchors, dim3(bt.n_reads - n_heavy), dim3(WAVE), 0, st, bt, an, err, heavy_first + n_heavy);
+	if (n_heavy > 0) {
+		SortTask *big[2] = { (SortTask*)task_buf, (SortTask*)task_buf + task_cap };
+		SortTask *small = (SortTask*)task_buf + 2 * task_cap;
+		unsigned int *ctr = (unsigned int*)((SortTask*)task_buf + 3 * task_cap);
+		hipLaunchKernelGGL(k_make_heavy_tasks, dim3((n_heavy + 255) / 256), dim3(256), 0, st_heavy, an, heavy_first, n_heavy, big[0]);
+		if (sort_heavy_run<mm128, mm_key_x>(an, big, small, ctr, n_heavy, err, st_heavy)) return -1;
+	}
+	return 0;
+}
+int mm355_sort_heavy_threshold(void)   // MM355_SORT_HEAVY_MIN: test hook that pushes ordinary reads through the block-level path
+{
+	static int thr = [] { const char *e = getenv("MM355_SORT_HEAVY_MIN"); int v = e? atoi(e) : MW_BIG; return v < 65? 65 : v; }();
+	return thr;
 }
 // seg_small / seg_big: scratch lists of at least tot_a/2 + 1 entries each; ctr: 2 zeroed u32 on the device
 int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr, hipStream_t st)

@@ -91,13 +91,16 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 {
 	if (c == 0) return;
 	(void)hipSetDevice(c->dev);
-	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
+	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->sort_tasks, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
 		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
 	for (DBuf *b : bufs) b->release();
 	c->h_res.release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
 	for (int i = 0; i < 8; ++i) { if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]); if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); }
+	if (c->aux_st) (void)hipStreamDestroy(c->aux_st);
+	if (c->aux_ev) (void)hipEventDestroy(c->aux_ev);
+	if (c->aux_ev2) (void)hipEventDestroy(c->aux_ev2);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->st) (void)hipStreamDestroy(c->st);
@@ -220,6 +223,8 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 		std::vector<int32_t> hv(n);
 		std::iota(hv.begin(), hv.end(), 0);
 		std::stable_sort(hv.begin(), hv.end(), [&](int32_t x, int32_t y) { return hb.n_a[x] > hb.n_a[y]; });
+		c->n_heavy = 0;
+		for (int64_t i = 0; i < n && hb.n_a[hv[i]] > mm355_sort_heavy_threshold(); ++i) ++c->n_heavy;
 		if (c->heavy.ensure((size_t)(n + 1) * 4)) return MM355_ENOMEM;
 		if (n) HIPCHK(hipMemcpyAsync(c->heavy.p, hv.data(), n * 4, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));
@@ -246,7 +251,16 @@ static int check_err(mm355_ctx *c)
 int mm355_run_sort(mm355_ctx *c)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
-	{ EvTimer t(c, &c->stats.ms_sort); mm355_launch_sort(b, a, c->err.as<int>(), c->heavy.as<int32_t>(), c->st); }
+	if (c->aux_st == 0) { HIPCHK(hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev2, hipEventDisableTiming)); }
+	{
+		// every emitted task covers > 64 elements, so tot_a / 64 bounds each list
+		const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->n_heavy + 1024;
+		if (c->sort_tasks.ensure(task_cap * 3 * 16 + 64)) return MM355_ENOMEM;
+		EvTimer t(c, &c->stats.ms_sort);
+		HIPCHK(hipEventRecord(c->aux_ev, c->st)); HIPCHK(hipStreamWaitEvent(c->aux_st, c->aux_ev, 0));   // anchors are complete
+		if (mm355_launch_sort(b, a, c->err.as<int>(), c->heavy.as<int32_t>(), c->n_heavy, c->sort_tasks.p, task_cap, c->st, c->aux_st)) return MM355_EHIP;
+		HIPCHK(hipEventRecord(c->aux_ev2, c->aux_st)); HIPCHK(hipStreamWaitEvent(c->st, c->aux_ev2, 0));
+	}
 	HIPCHK(hipGetLastError());
 	return check_err(c);
 }

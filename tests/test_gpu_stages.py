@@ -182,3 +182,65 @@ def test_device_index_builder_equals_host_builder(built, tmp_path):
     assert np.array_equal(rep_h, rep_d)
     sr_h.close(); sr_d.close()
     L.mm355_index_free(h)
+
+
+def _repeat_world(td):
+    """genome with a 150-copy 1-kb family; reads made of several unit copies collect > 100k anchors each"""
+    rng = np.random.default_rng(77)
+    g = S.random_codes(rng, 700000)
+    unit = S.random_codes(rng, 1000)
+    for _ in range(150):
+        pos = int(rng.integers(0, len(g) - 1000))
+        g[pos:pos + 1000] = S.mutate(unit, rng, 0.01, 0.0, 0.0)[:1000]
+    fa = os.path.join(str(td), "rep.fa")
+    S.write_fasta(fa, [g], ["chrR"])
+    reads = [S.codes_to_str(S.mutate(np.tile(unit, m), rng, 0.02, 0.01, 0.01)) for m in (2, 5, 9)]
+    reads += [S.codes_to_str(g[5000:9000]), S.codes_to_str(S.mutate(np.tile(unit, 3)[::-1].copy(), rng, 0.02, 0.0, 0.0))]
+    return fa, reads
+
+
+def _check_sorted_and_chains(fa, reads, min_heavy):
+    import mappy_rs
+    al = mappy_rs.Aligner(fa, preset="map-ont")
+    orc = O.OracleAligner(fa, preset="map-ont")
+    sr = al._stage_runner()
+    try:
+        got, _, _ = sr.anchors(reads, sorted_=True)
+        ch = sr.chains(reads)
+        big = 0
+        for i, rd in enumerate(reads):
+            exp, _, _, _ = orc.anchors(rd, sorted_=True)
+            assert np.array_equal(got[i], exp), i
+            eu, eb = orc.chains(exp, len(rd))
+            assert np.array_equal(ch[i][0], eu), i
+            assert np.array_equal(ch[i][1], eb), i
+            big += len(exp) > min_heavy
+        return big
+    finally:
+        sr.close()
+
+
+def test_heavy_read_block_level_sort(built, tmp_path):
+    """reads above the heavy threshold (16384 anchors) take the 1024-thread level kernel + task lists; the permutation
+    must still be the literal radix_sort_128x one"""
+    fa, reads = _repeat_world(tmp_path)
+    assert _check_sorted_and_chains(fa, reads, 16384) >= 2
+
+
+def test_heavy_sort_path_on_ordinary_reads(built, tmp_path):
+    """MM355_SORT_HEAVY_MIN=100 sends every read with > 100 anchors through the block-level path (one child process:
+    the threshold is read once per process)"""
+    import subprocess, sys
+    code = ("import sys; sys.path[:0] = %r; import tests.test_gpu_stages as T, synthdata as S, numpy as np, os\n"
+            "td = sys.argv[1]\n"
+            "g = S.make_genome(31, [400000, 250000], repeats=((4000, 6, 0.01), (900, 40, 0.02), (300, 120, 0.05)), n_runs=3)\n"
+            "fa = os.path.join(td, 'ref.fa'); S.write_fasta(fa, g, ['chrA', 'chrB'])\n"
+            "reads, _ = S.make_reads(32, g, 120, n50=5000, lo=200)\n"
+            "n = T._check_sorted_and_chains(fa, reads, 100)\n"
+            "fa2, r2 = T._repeat_world(td)\n"
+            "n += T._check_sorted_and_chains(fa2, r2, 100)\n"
+            "assert n > 50, n\nprint('heavy-ok', n)\n") % ([os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                          os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mappy-rs_amd")],)
+    env = dict(os.environ, MM355_SORT_HEAVY_MIN="100")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "heavy-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -24,3 +24,6 @@ for k in (0, 1, 5, 20, 100, 400, 2000):
         else: sr.chains([r], cap=4_000_000)
         st = sr.stats()
         print("rank %4d n_a %7d len %6d  %s: sort %.2f ms chain %.2f ms backtrack %.2f ms" % (k, na[order[k]], len(r), stage, st.ms_sort, st.ms_chain, st.ms_backtrack))
+for rep in range(2):
+    sr.anchors(reads, sorted_=True, cap=120_000_000); st = sr.stats()
+    print("whole batch: sort %.2f ms (n_heavy>16384: %d, >65536: %d)" % (st.ms_sort, (na > 16384).sum(), (na > 65536).sum()))
