@@ -33,7 +33,7 @@ struct EzState { int32_t max, max_q, max_t, mqe, mqe_t, mte, mte_q, score, zdrop
 
 __device__ inline int8_t I8(int v) { return (int8_t)v; }
 
-__device__ inline bool apply_zdrop(EzState &ez, int32_t H, int r, int t, int zdrop, int e2)
+__device__ __forceinline__ bool apply_zdrop(EzState &ez, int32_t H, int r, int t, int zdrop, int e2)
 {
 	if (H > ez.max) {
 		ez.max = H, ez.max_t = t, ez.max_q = r - t;
@@ -307,6 +307,8 @@ __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jo
 	}
 }
 
+#include "mm355_dpreg.h"
+
 // U:ksw2.h::ksw_backtrack (is_rot = 1).  The walk is a chain of dependent 1-byte loads (one per CIGAR column), i.e. pure
 // latency: with one lane per alignment a wave keeps 64 independent chains in flight instead of one.  off[]/off_end[] of
 // the reference are pure functions of (r, qlen, tlen, w) and are recomputed instead of being stored and re-loaded.
@@ -410,11 +412,22 @@ DpConst mm355_dp_const(const mm355_mapopt_t *mo)
 	return c;
 }
 
-// LDS size classes of the per-target state (12 B per target position): small alignments get small footprints so that
-// up to 32 of them are resident per CU and hide each other's LDS round trips
-static const int DP_CLASS_CAP[] = { 256, 512, 1024, 4096, 12288, 0 };
-static const int DP_CLASS_NT[]  = { 64, 64, 64, 512, 512, 512 };
-#define DP_N_CLASS 6
+// Size classes.  Targets up to 1024 bases run register-resident (k_ksw_reg, 2 * NP cells per lane), split by score
+// tracking mode (KSW_EZ_APPROX_MAX or exact); longer ones keep their per-target state in LDS (12 B per position) or, beyond
+// 12288 positions, in HBM, with eight waves per alignment.  MM355_DP_LEGACY=1 routes everything through the LDS kernel.
+struct DpClass { int cap, kind, np; };   // kind 0: k_ksw_reg, 1: k_ksw_extd2<64> (LDS), 2: k_ksw_extd2<512>
+static const DpClass DP_CLASSES[] = { {128, 0, 1}, {256, 0, 2}, {512, 0, 4}, {1024, 0, 8}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
+static const DpClass DP_CLASSES_LEGACY[] = { {256, 1, 0}, {512, 1, 0}, {1024, 1, 0}, {1024, 1, 0}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
+#define DP_N_CLASS 7
+#define DP_N_GROUP (2 * DP_N_CLASS)      // group = class * 2 + exact
+
+template <int NP>
+static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc, const DpJobDev *jobs, const int32_t *ids, const uint8_t *d_q, const uint8_t *d_t,
+                       uint8_t *bt, mm355_dpres_t *res, unsigned long long *cells)
+{
+	if (exact) hipLaunchKernelGGL((k_ksw_reg<NP, true>), dim3(n), dim3(64), 0, st, dc, jobs, ids, (int)n, d_q, d_t, bt, res, cells);
+	else hipLaunchKernelGGL((k_ksw_reg<NP, false>), dim3(n), dim3(64), 0, st, dc, jobs, ids, (int)n, d_q, d_t, bt, res, cells);
+}
 
 // runs jobs whose code strings are already on the device (qbuf/tbuf); fills res[] and the cigar arena (host copies)
 int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
@@ -426,7 +439,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 	DpConst dc = mm355_dp_const(mo);
 	// lay out per-job work areas
 	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
-	std::vector<int32_t> ids[DP_N_CLASS];
+	static const bool legacy = [] { const char *e = getenv("MM355_DP_LEGACY"); return e && atoi(e) != 0; }();
+	const DpClass *classes = legacy? DP_CLASSES_LEGACY : DP_CLASSES;
+	std::vector<int32_t> ids[DP_N_GROUP];
 	for (size_t i = 0; i < n; ++i) {
 		DpJobDev &j = jobs[i];
 		j.skip = (mo->max_sw_mat > 0 && (int64_t)j.tlen * j.qlen > mo->max_sw_mat) || !dc.valid;
@@ -439,9 +454,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 			p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
 			cig_tot += (size_t)j.qlen + j.tlen + 2;
 			int cls = 0;
-			while (cls < DP_N_CLASS - 1 && T > DP_CLASS_CAP[cls]) ++cls;
+			while (cls < DP_N_CLASS - 1 && T > classes[cls].cap) ++cls;
 			if (cls == DP_N_CLASS - 1) { j.st_off = (int64_t)st_tot; st_tot += T; }
-			ids[cls].push_back((int32_t)i);
+			ids[cls * 2 + ((j.flag & EZ_APPROX_MAX)? 0 : 1)].push_back((int32_t)i);
 		} else ids[0].push_back((int32_t)i);
 	}
 	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64) ||
@@ -459,28 +474,33 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 		// every size class gets its own HIP stream: the few long alignments of the big classes run concurrently with the
 		// thousands of short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
 		std::vector<int32_t> all_ids; all_ids.reserve(n);
-		size_t cls_off[DP_N_CLASS];
-		for (int cls = 0; cls < DP_N_CLASS; ++cls) { cls_off[cls] = all_ids.size(); all_ids.insert(all_ids.end(), ids[cls].begin(), ids[cls].end()); }
+		size_t grp_off[DP_N_GROUP];
+		for (int g = 0; g < DP_N_GROUP; ++g) { grp_off[g] = all_ids.size(); all_ids.insert(all_ids.end(), ids[g].begin(), ids[g].end()); }
 		HIPCHK(hipMemcpyAsync(d_ids, all_ids.data(), all_ids.size() * 4, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));   // all_ids is pageable; also orders the class streams after the uploads
-		for (int cls = DP_N_CLASS - 1; cls >= 0; --cls) {   // big problems first
-			if (ids[cls].empty()) continue;
-			if (c->dp_st[cls] == 0) { HIPCHK(hipStreamCreateWithFlags(&c->dp_st[cls], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->dp_ev[cls], hipEventDisableTiming)); }
-			int cap = DP_CLASS_CAP[cls];
-			size_t lds = (size_t)cap * 12;
-			if (DP_CLASS_NT[cls] == 64)
-				hipLaunchKernelGGL(k_ksw_extd2<64>, dim3((unsigned)ids[cls].size()), dim3(64), lds, c->dp_st[cls], dc, c->dp_jobs.as<DpJobDev>(), d_ids + cls_off[cls],
-				                   (int)ids[cls].size(), d_q, d_t, c->dp_bt.as<uint8_t>(), d_off, c->dp_cig.as<uint32_t>(), d_S, d_H,
-				                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
-			else {
-				static bool attr_set = false;
-				if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12); attr_set = true; }
-				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3((unsigned)ids[cls].size()), dim3(512), lds, c->dp_st[cls], dc, c->dp_jobs.as<DpJobDev>(), d_ids + cls_off[cls],
-				                   (int)ids[cls].size(), d_q, d_t, c->dp_bt.as<uint8_t>(), d_off, c->dp_cig.as<uint32_t>(), d_S, d_H,
-				                   c->dp_res.as<mm355_dpres_t>(), cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
-			}
-			HIPCHK(hipEventRecord(c->dp_ev[cls], c->dp_st[cls]));
-			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[cls], 0));
+		(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
+		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
+			if (ids[g].empty()) continue;
+			const DpClass &k = classes[g >> 1];
+			if (c->dp_st[g] == 0) { HIPCHK(hipStreamCreateWithFlags(&c->dp_st[g], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming)); }
+			const unsigned nj = (unsigned)ids[g].size();
+			const int32_t *gid = d_ids + grp_off[g];
+			const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();
+			mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
+			if (k.kind == 0) {
+				const bool ex = g & 1;
+				if (k.np == 1) launch_reg<1>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_cells);
+				else if (k.np == 2) launch_reg<2>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_cells);
+				else if (k.np == 4) launch_reg<4>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_cells);
+				else launch_reg<8>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_cells);
+			} else if (k.kind == 1)
+				hipLaunchKernelGGL(k_ksw_extd2<64>, dim3(nj), dim3(64), (size_t)k.cap * 12, c->dp_st[g], dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
+			else
+				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3(nj), dim3(512), (size_t)k.cap * 12, c->dp_st[g], dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
+			HIPCHK(hipEventRecord(c->dp_ev[g], c->dp_st[g]));
+			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		}
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		std::vector<int32_t> order(n);

@@ -1,0 +1,367 @@
+// mm355_dpreg.h -- register-resident form of the banded extension kernel (row a12, targets up to 1024 bases).
+// Included by mm355_dp.hip; same results, bit for bit, as k_ksw_extd2 (U:ksw2_extd2_sse.c::ksw_extd2_sse).
+//
+// One wave = one alignment.  Lane l of block j OWNS the two target positions t = 128 j + 2 l, t + 1 for the whole
+// sweep: their state (u, v, x, y, x2, y2, s) sits in VGPRs as two 16-bit halves per register, each holding the int8
+// value shifted left by 8.  In that "8.8" form the packed 16-bit VALU operations (v_pk_add_u16, v_pk_max_i16, ...)
+// reproduce the int8 wrap-around of the SSE kernel exactly -- a carry out of bit 15 is the int8 wrap, signed order is
+// preserved -- so one instruction advances two cells and no value is ever unpacked.  Nothing goes through LDS:
+//   * x[t-1], v[t-1], x2[t-1] of the previous anti-diagonal come from the lower half of the own register and, for the
+//     even cell, from the upper half of lane l-1 (one DPP wave_shr:1 move + v_alignbit);
+//   * the query is a systolic register: every anti-diagonal it moves one cell to the right and query[r] enters at t = 0,
+//     so cell t always holds query[r - t];
+//   * only the blocks j that intersect the band [st, en] of the anti-diagonal are evaluated (cells outside keep their
+//     stale state, as the 16-lane SSE blocks do), so the cost follows the band width, not the target length.  The sweep
+//     is cut into segments of anti-diagonals with the same first/last active block (both only ever move up) and every
+//     (first, last) pair has its own straight-line loop: a per-block "skip" branch would make the compiler copy the six
+//     state registers of the block at the merge point, which costs more than the skipped work;
+//   * the direction bytes of an anti-diagonal leave as one 2-byte store per lane (128 B per block, coalesced).
+// The direction code is the argmax position among (s, a, b, a2, b2) -- first maximum for left-aligned gaps, last maximum
+// with KSW_EZ_RIGHT -- computed without compares: n_i = min_u16(zmax - v_i, 1) is 0 exactly where v_i attains the maximum.
+#pragma once
+
+// The packed operations are emitted as written: left to itself the optimiser turns min_u16(x, 1) and the multiplications by
+// 0/1 flags back into per-half compares and selects (SDWA v_cmp + v_cndmask + v_perm), several instructions per half.
+// v = VGPR operand, s = wave-uniform constant read straight from an SGPR (one constant-bus operand per instruction)
+#define DP_PK2(name, ins) __device__ __forceinline__ uint32_t name(uint32_t a, uint32_t b) { uint32_t r; asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; } \
+	__device__ __forceinline__ uint32_t name##_s(uint32_t a, uint32_t b) { uint32_t r; asm(ins " %0, %1, %2" : "=v"(r) : "v"(a), "s"(b)); return r; } \
+	__device__ __forceinline__ void name##_to(uint32_t &dst, uint32_t a, uint32_t b) { asm(ins " %0, %1, %2" : "+v"(dst) : "v"(a), "v"(b)); } \
+	__device__ __forceinline__ void name##_s_to(uint32_t &dst, uint32_t a, uint32_t b) { asm(ins " %0, %1, %2" : "+v"(dst) : "v"(a), "s"(b)); }
+DP_PK2(pk_add, "v_pk_add_u16")
+DP_PK2(pk_sub, "v_pk_sub_u16")
+DP_PK2(pk_max, "v_pk_max_i16")
+DP_PK2(pk_min, "v_pk_min_i16")
+DP_PK2(pk_minu, "v_pk_min_u16")
+__device__ __forceinline__ uint32_t pk_rsub_s(uint32_t c, uint32_t a) { uint32_t r; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(r) : "s"(c), "v"(a)); return r; }   // c - a
+__device__ __forceinline__ uint32_t pk_max0(uint32_t a) { uint32_t r; asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ uint32_t pk_mad_vvs(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c)); return r; }
+__device__ __forceinline__ uint32_t pk_mad_vss(uint32_t a, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %2" : "=v"(r) : "v"(a), "s"(c)); return r; }   // a * c + c
+__device__ __forceinline__ uint32_t pk_shr2(uint32_t a) { uint32_t r; asm("v_pk_lshrrev_b16 %0, 2, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ uint32_t vreg_const(uint32_t c) { uint32_t r; asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "s"(c)); return r; }   // constant pinned in a VGPR (not rematerialised)
+__device__ __forceinline__ uint32_t pk8(int v) { const uint32_t h = (uint32_t)(uint8_t)v << 8; return h | h << 16; }   // int8 -> both halves, 8.8
+__device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }           // m ? a : b (v_bfi_b32)
+// value of lane-1 (lane 0: `first`)
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t first, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+
+// Per-lane state: individually named members (arrays indexed by the unrolled block number get promoted to vector values by
+// the optimiser, and every update of one element then copies the whole tuple).
+#define DP_MEMB(k) uint32_t U##k, V##k, X##k, Y##k, X2##k, Y2##k, SC##k, TQ##k, QQ##k; int32_t Hl##k, Hh##k;
+struct DpSt { DP_MEMB(0) DP_MEMB(1) DP_MEMB(2) DP_MEMB(3) DP_MEMB(4) DP_MEMB(5) DP_MEMB(6) DP_MEMB(7) };
+struct DpK { uint32_t nqe, nq2e2, q, q2, qe, q2e2, mch, dmis_v, N, one, c256, m256, two, three, four, f8, f16, f32, f64, dx1, dx21; };
+struct DpRun {             // wave-uniform state of the sweep
+	int qlen, tlen, w, T, n_col, flag, zdrop, end_bonus, q, e, q2, e2, qe, long_thres, long_diff, r_total;
+	const uint8_t *query; uint8_t *p;
+	int r, st, en, st0, en0, last_st, last_en;
+	int32_t H0, last_H0_t;
+	unsigned long long cells;
+	uint32_t qv;
+	bool any_n;
+	EzState ez;
+};
+
+__device__ __forceinline__ bool dp_bounds(DpRun &R)   // U:ksw2_extd2_sse.c: st/en of anti-diagonal R.r; false: the band has left the matrix
+{
+	const int r = R.r;
+	int st = 0, en = R.tlen - 1;
+	if (st < r - R.qlen + 1) st = r - R.qlen + 1;
+	if (en > r) en = r;
+	if (st < (r - R.w + 1) >> 1) st = (r - R.w + 1) >> 1;
+	if (en > (r + R.w) >> 1) en = (r + R.w) >> 1;
+	if (st > en) return false;
+	R.st0 = st; R.en0 = en;
+	R.st = st / 16 * 16; R.en = (en + 16) / 16 * 16 - 1;
+	return true;
+}
+
+struct DpDiag {            // wave-uniform description of one anti-diagonal
+	int r, st, en, st0, jq, lane_st, lane_r;
+	uint32_t sclen, dv1, edge_u8, qc_hi;
+	bool use_def, edge, any_n;
+	size_t prow;           // r * n_col - st
+};
+
+__device__ __forceinline__ void dp_slide(uint32_t &QQ, const uint32_t first_hi)   // the query moves one cell to the right
+{
+	QQ = __builtin_amdgcn_alignbit(QQ, lane_shr1(first_hi, QQ), 16);
+}
+
+template <int J>
+__device__ __forceinline__ void dp_score(const DpDiag &g, const DpK &k, const int lane, uint32_t &SC, const uint32_t TQ, const uint32_t QQ)
+{
+	uint32_t s = pk_mad_vvs(pk_minu_s(TQ ^ QQ, k.one), k.dmis_v, k.mch);
+	if (g.any_n) s = pk_mad(pk_shr2(TQ | QQ), pk_rsub_s(k.N, s), s);
+	const uint32_t tl = (uint32_t)(128 * J + 2 * lane - g.st0);
+	const uint32_t m = (tl < g.sclen? 0xffffu : 0u) | (tl + 1 < g.sclen? 0xffff0000u : 0u);
+	SC = bfi(m, s, SC);
+}
+
+// one block of one anti-diagonal; pX/pV/pX2 = registers of block J-1 (previous anti-diagonal)
+template <int J, bool IS_LO, bool IS_HI, bool RIGHT>
+__device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int lane, uint8_t *p,
+                                        uint32_t &U, uint32_t &V, uint32_t &X, uint32_t &Y, uint32_t &X2, uint32_t &Y2, const uint32_t SC,
+                                        const uint32_t pX, const uint32_t pV, const uint32_t pX2)
+{
+	uint32_t fx = 0, fv = 0, fx2 = 0;
+	if (J > 0) { fx = rdlane(pX, 63); fv = rdlane(pV, 63); fx2 = rdlane(pX2, 63); }
+	uint32_t nx_ = lane_shr1(fx, X), nv_ = lane_shr1(fv, V), nx2_ = lane_shr1(fx2, X2);
+	if (IS_LO) {   // x[st-1], v[st-1], x2[st-1] are boundary values when that cell was outside the previous anti-diagonal
+		const bool at = g.use_def && lane == g.lane_st;
+		nx_ = at? k.dx1 : nx_; nv_ = at? g.dv1 : nv_; nx2_ = at? k.dx21 : nx2_;
+	}
+	const uint32_t XT = __builtin_amdgcn_alignbit(X, nx_, 16), VT = __builtin_amdgcn_alignbit(V, nv_, 16), X2T = __builtin_amdgcn_alignbit(X2, nx2_, 16);
+	uint32_t yi = Y, y2i = Y2, ui = U;
+	if (IS_HI) {   // top row (query position 0, only ever in the last active block): y, y2 and u are the boundary values
+		const uint32_t hm = (g.r & 1)? 0xffff0000u : 0xffffu, m = (g.edge && J == g.jq && lane == g.lane_r)? hm : 0u;
+		yi = bfi(m, k.nqe, yi); y2i = bfi(m, k.nq2e2, y2i); ui = bfi(m, g.edge_u8, ui);
+	}
+	// every lane computes; lanes outside [st, en] keep their state through one v_bfi per register
+	const int tl = 128 * J + 2 * lane;
+	const bool act = tl >= g.st && tl <= g.en;
+	const uint32_t am = act? 0xffffffffu : 0u;
+	const uint32_t z0 = SC;
+	uint32_t a = pk_add(XT, VT), b = pk_add(yi, ui), a2 = pk_add(X2T, VT), b2 = pk_add(y2i, ui);
+	const uint32_t zm = pk_max(pk_max(pk_max(pk_max(z0, a), b), a2), b2);
+	const uint32_t n1 = pk_minu_s(pk_sub(zm, a), k.one), n2 = pk_minu_s(pk_sub(zm, b), k.one), n3 = pk_minu_s(pk_sub(zm, a2), k.one);
+	uint32_t d;
+	if (!RIGHT) {   // first maximum
+		const uint32_t n0 = pk_minu_s(pk_sub(zm, z0), k.one);
+		d = pk_mad_vss(n3, k.one);             // 1 + n3
+		d = pk_mad_vvs(n2, d, k.one);          // 1 + n2 (1 + n3)
+		d = pk_mad_vvs(n1, d, k.one);
+		d = pk_mul(n0, d);
+	} else {        // last maximum
+		const uint32_t n4 = pk_minu_s(pk_sub(zm, b2), k.one);
+		d = pk_rsub_s(k.one, n1);                              // a attains the maximum -> 1
+		d = pk_mad_vvs(n2, pk_sub_s(d, k.two), k.two);         // b attains it -> 2, else keep
+		d = pk_mad_vvs(n3, pk_sub_s(d, k.three), k.three);
+		d = pk_mad_vvs(n4, pk_sub_s(d, k.four), k.four);
+	}
+	const uint32_t z = pk_min_s(zm, k.mch);
+	uint32_t tmp = pk_sub_s(z, k.q);
+	a = pk_sub(a, tmp); b = pk_sub(b, tmp);
+	tmp = pk_sub_s(z, k.q2);
+	a2 = pk_sub(a2, tmp); b2 = pk_sub(b2, tmp);
+	const uint32_t pa = pk_max0(a), pb = pk_max0(b), pa2 = pk_max0(a2), pb2 = pk_max0(b2);
+	uint32_t fa, fb, fa2, fb2;   // continuation flags already at their bit positions (0x08, 0x10, 0x20, 0x40)
+	if (!RIGHT) { fa = pk_minu_s(pa, k.f8); fb = pk_minu_s(pb, k.f16); fa2 = pk_minu_s(pa2, k.f32); fb2 = pk_minu_s(pb2, k.f64); }   // > 0
+	else {          // >= 0
+		fa = pk_minu_s(pk_add_s(pk_max_s(a, k.m256), k.c256), k.f8); fb = pk_minu_s(pk_add_s(pk_max_s(b, k.m256), k.c256), k.f16);
+		fa2 = pk_minu_s(pk_add_s(pk_max_s(a2, k.m256), k.c256), k.f32); fb2 = pk_minu_s(pk_add_s(pk_max_s(b2, k.m256), k.c256), k.f64);
+	}
+	d = d | fa | fb; d = d | fa2 | fb2;
+	X = bfi(am, pk_sub_s(pa, k.qe), X); Y = bfi(am, pk_sub_s(pb, k.qe), Y); X2 = bfi(am, pk_sub_s(pa2, k.q2e2), X2); Y2 = bfi(am, pk_sub_s(pb2, k.q2e2), Y2);
+	U = bfi(am, pk_sub(z, VT), U); V = bfi(am, pk_sub(z, ui), V);
+	if (act) *(uint16_t*)(p + g.prow + tl) = (uint16_t)(__builtin_amdgcn_perm(0, d, 0x0c0c0200));
+}
+
+// exact score tracking of one block: H[t] += v[t] on [st0, en0), H[en0] = hen, best (H, priority) candidate of the lane
+template <int J>
+__device__ __forceinline__ void dp_block_h(const int lane, const int st0, const int en0, const int en1, const int32_t hen, const uint32_t V, int32_t &Hl, int32_t &Hh, long long &best)
+{
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		int32_t &Hc = h? Hh : Hl;
+		const int t = 128 * J + 2 * lane + h;
+		int32_t hv = Hc + (int32_t)(int8_t)(V >> (h? 24 : 8));
+		const bool in = t >= st0 && t < en0;
+		const uint32_t prio = (uint32_t)(t < en1? (t - st0) & 3 : 4) << 16 | (uint32_t)t;
+		const long long key = in? (long long)(((unsigned long long)(uint32_t)hv << 32) | (uint32_t)~prio) : INT64_MIN;
+		best = key > best? key : best;
+		hv = in? hv : Hc;
+		Hc = t == en0? hen : hv;
+	}
+}
+
+// value of register R of block j (wave-uniform j) at lane l
+#define DP_PICK(R, j, l) ((NP <= 1 || (j) == 0)? rdlane(S.R##0, l) : (NP <= 2 || (j) == 1)? rdlane(S.R##1, l) : (NP <= 3 || (j) == 2)? rdlane(S.R##2, l) : \
+                          (NP <= 4 || (j) == 3)? rdlane(S.R##3, l) : (NP <= 5 || (j) == 4)? rdlane(S.R##4, l) : (NP <= 6 || (j) == 5)? rdlane(S.R##5, l) : \
+                          (NP <= 7 || (j) == 6)? rdlane(S.R##6, l) : rdlane(S.R##7, l))
+#define DP_CELL8(R, t) ((int)(int8_t)(DP_PICK(R, (t) >> 7, ((t) >> 1) & 63) >> (((t) & 1)? 24 : 8)))
+#define DP_HAT(t) (int32_t)(((t) & 1)? DP_PICK(Hh, (t) >> 7, ((t) >> 1) & 63) : DP_PICK(Hl, (t) >> 7, ((t) >> 1) & 63))
+#define DP_IN(k) (NP > k && k >= JLO && k <= JHI)
+
+// one anti-diagonal with active blocks JLO..JHI (a superset of the blocks that intersect [st, en] is fine: lanes outside are
+// masked); returns false when the sweep ends here (z-drop)
+template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI>
+__device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const int lane)
+{
+	const int r = R.r, st = R.st, en = R.en, st0 = R.st0, en0 = R.en0;
+	DpDiag g;
+	g.r = r; g.st = st; g.en = en; g.st0 = st0; g.any_n = R.any_n;
+	g.use_def = st == 0 || !(st - 1 >= R.last_st && st - 1 <= R.last_en);
+	const int edge_u = r == 0? -R.q - R.e : r < R.long_thres? -R.e : r == R.long_thres? R.long_diff : -R.e2;
+	g.edge_u8 = pk8(edge_u);
+	g.dv1 = st > 0? K.nqe & 0xffff0000u : g.edge_u8 & 0xffff0000u;   // v1 at st == 0 follows the same schedule as the edge u
+	g.edge = en >= r;
+	int sce = st0 + ((en0 - st0) / 16 + 1) * 16;   // scores are (re)written for t in [st0, sce), clipped to the padded target
+	if (sce > R.T) sce = R.T;
+	g.sclen = (uint32_t)(sce - st0);
+	if ((r & 63) == 0) R.qv = r + lane < R.qlen? R.query[r + lane] : 0;   // query[r] enters at t = 0
+	g.qc_hi = rdlane(R.qv, r & 63) << 16;
+	g.jq = r >> 7;
+	g.lane_st = (st & 127) >> 1; g.lane_r = (r & 127) >> 1;
+	g.prow = (size_t)r * R.n_col - st;
+	const int jsh = (sce - 1) >> 7;
+	// 1. the query moves (descending: block J takes the last cell of block J-1 before that one moves); blocks beyond t = r hold zeros
+#define DP_SLIDE(k, m) if constexpr (NP > k) { if (k <= JHI || k <= g.jq) dp_slide(S.QQ##k, k > 0? rdlane(S.QQ##m, 63) : g.qc_hi); }
+	DP_SLIDE(7, 6) DP_SLIDE(6, 5) DP_SLIDE(5, 4) DP_SLIDE(4, 3) DP_SLIDE(3, 2) DP_SLIDE(2, 1) DP_SLIDE(1, 0) DP_SLIDE(0, 0)
+	// 2. scores of [st0, sce): the active blocks, plus the next one when the last 16-cell chunk spills over
+#define DP_SCORE(k) if constexpr (NP > k) { if (DP_IN(k) || (k == JHI + 1 && jsh > JHI)) dp_score<k>(g, K, lane, S.SC##k, S.TQ##k, S.QQ##k); }
+	DP_SCORE(0) DP_SCORE(1) DP_SCORE(2) DP_SCORE(3) DP_SCORE(4) DP_SCORE(5) DP_SCORE(6) DP_SCORE(7)
+	// 3. the recurrence, descending for the same reason
+#define DP_CORE(k, m) if constexpr (DP_IN(k)) dp_core<k, k == JLO, k == JHI, RIGHT>(g, K, lane, R.p, S.U##k, S.V##k, S.X##k, S.Y##k, S.X2##k, S.Y2##k, S.SC##k, S.X##m, S.V##m, S.X2##m);
+	DP_CORE(7, 6) DP_CORE(6, 5) DP_CORE(5, 4) DP_CORE(4, 3) DP_CORE(3, 2) DP_CORE(2, 1) DP_CORE(1, 0) DP_CORE(0, 0)
+	R.cells += (unsigned long long)(en0 - st0 + 1);
+	EzState &ez = R.ez;
+	if constexpr (EXACT) {
+		int32_t max_H, max_t, Hen0, Hst0;
+		if (r > 0) {
+			const int32_t hen = en0 > 0? DP_HAT(en0 - 1) + DP_CELL8(U, en0) : DP_HAT(en0) + DP_CELL8(V, en0);
+			const int en1 = st0 + (en0 - st0) / 4 * 4;
+			long long best = INT64_MIN;
+#define DP_STEP_H(k) if constexpr (DP_IN(k)) dp_block_h<k>(lane, st0, en0, en1, hen, S.V##k, S.Hl##k, S.Hh##k, best);
+			DP_STEP_H(0) DP_STEP_H(1) DP_STEP_H(2) DP_STEP_H(3) DP_STEP_H(4) DP_STEP_H(5) DP_STEP_H(6) DP_STEP_H(7)
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const long long other = __shfl_xor(best, o);
+				best = other > best? other : best;
+			}
+			max_H = hen; max_t = en0;
+			if (best != INT64_MIN) {
+				const int32_t ch = (int32_t)(best >> 32);
+				if (ch > hen) { max_H = ch; max_t = (int)(~(uint32_t)best & 0xffffu); }
+			}
+			Hen0 = hen; Hst0 = st0 == en0? hen : DP_HAT(st0);
+		} else {
+			const int32_t h0 = DP_CELL8(V, 0) - R.qe;
+			S.Hl0 = lane == 0? h0 : S.Hl0;
+			max_H = h0; max_t = 0; Hen0 = Hst0 = h0;
+		}
+		if (en0 == R.tlen - 1 && Hen0 > ez.mte) ez.mte = Hen0, ez.mte_q = r - en;
+		if (r - st0 == R.qlen - 1 && Hst0 > ez.mqe) ez.mqe = Hst0, ez.mqe_t = st0;
+		if (apply_zdrop(ez, max_H, r, max_t, R.zdrop, R.e2)) return false;
+		if (r == R.qlen + R.tlen - 2 && en0 == R.tlen - 1) ez.score = Hen0;   // en0 == tlen - 1: H[tlen-1] is H[en0]
+	} else {
+		if (r > 0) {
+			const int lt = R.last_H0_t;
+			const bool in0 = lt >= st0 && lt <= en0, in1 = lt + 1 >= st0 && lt + 1 <= en0;
+			if (in0 && in1) {
+				const int32_t d0 = DP_CELL8(V, lt), d1 = DP_CELL8(U, lt + 1);
+				if (d0 > d1) R.H0 += d0;
+				else R.H0 += d1, ++R.last_H0_t;
+			} else if (in0) R.H0 += DP_CELL8(V, lt);
+			else { ++R.last_H0_t; R.H0 += DP_CELL8(U, lt + 1); }
+		} else R.H0 = DP_CELL8(V, 0) - R.qe, R.last_H0_t = 0;
+		if ((R.flag & EZ_APPROX_DROP) && apply_zdrop(ez, R.H0, r, R.last_H0_t, R.zdrop, R.e2)) return false;
+		if (r == R.qlen + R.tlen - 2 && en0 == R.tlen - 1) ez.score = R.H0;
+	}
+	return true;
+}
+
+// all anti-diagonals whose active blocks are JLO..JHI (WIDE: the catch-all instance that covers every block, used while the
+// band spans more than DP_MAX_TIGHT blocks); returns true when the sweep is finished
+#define DP_MAX_TIGHT 4
+template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI, bool WIDE>
+__device__ __forceinline__ bool dp_segment(DpRun &R, DpSt &S, const DpK &K, const int lane)
+{
+	for (;;) {
+		if (!dp_diag<NP, EXACT, RIGHT, JLO, JHI>(R, S, K, lane)) return true;
+		R.last_st = R.st; R.last_en = R.en;
+		if (++R.r >= R.r_total) return true;
+		if (!dp_bounds(R)) { R.ez.zdropped = 1; return true; }
+		const int jlo = R.st >> 7, jhi = R.en >> 7;
+		if (WIDE? jhi - jlo < DP_MAX_TIGHT : (jlo != JLO || jhi != JHI)) return false;
+	}
+}
+
+template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI>
+__device__ __forceinline__ bool dp_dispatch(const int jlo, const int jhi, DpRun &R, DpSt &S, const DpK &K, const int lane)
+{
+	if (jlo == JLO && jhi == JHI) return dp_segment<NP, EXACT, RIGHT, JLO, JHI, false>(R, S, K, lane);
+	if constexpr (JHI + 1 < NP && JHI + 1 - JLO < DP_MAX_TIGHT) return dp_dispatch<NP, EXACT, RIGHT, JLO, JHI + 1>(jlo, jhi, R, S, K, lane);
+	else if constexpr (JLO + 1 < NP) return dp_dispatch<NP, EXACT, RIGHT, JLO + 1, JLO + 1>(jlo, jhi, R, S, K, lane);
+	else return true;   // not reached
+}
+
+template <int NP, bool EXACT, bool RIGHT>
+__device__ __forceinline__ void dp_sweep(DpRun &R, DpSt &S, const DpK &K, const int lane)
+{
+	if (R.r_total <= 0) return;
+	if (!dp_bounds(R)) { R.ez.zdropped = 1; return; }
+	for (;;) {
+		const int jlo = R.st >> 7, jhi = R.en >> 7;
+		bool done;
+		if (NP > DP_MAX_TIGHT && jhi - jlo >= DP_MAX_TIGHT) done = dp_segment<NP, EXACT, RIGHT, 0, NP - 1, true>(R, S, K, lane);
+		else done = dp_dispatch<NP, EXACT, RIGHT, 0, 0>(jlo, jhi, R, S, K, lane);
+		if (done) break;
+	}
+}
+
+template <int NP, bool EXACT>
+__global__ __launch_bounds__(64) void k_ksw_reg(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+                                                 const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr)
+{
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_jobs) return;
+	const int jid = job_ids[blockIdx.x];
+	const DpJobDev jb = jobs[jid];
+	DpRun R;
+	R.qlen = jb.qlen; R.tlen = jb.tlen; R.flag = jb.flag; R.zdrop = jb.zdrop; R.end_bonus = jb.end_bonus;
+	EzState &ez = R.ez;
+	ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
+	ez.max = 0; ez.score = ez.mqe = ez.mte = KSW_NEG_INF; ez.zdropped = 0; ez.reach_end = 0;
+	if (R.qlen <= 0 || R.tlen <= 0 || jb.skip) {   // skip: tlen*qlen > max_sw_mat => treated as z-dropped by mm_align_pair
+		if (lane == 0) {
+			mm355_dpres_t o; o.max = 0; o.zdropped = jb.skip? 1 : 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1;
+			o.mqe = o.mte = o.score = KSW_NEG_INF; o.reach_end = 0; o.n_cigar = -1; o.cigar_off = -1;
+			res[jid] = o;
+		}
+		return;
+	}
+	const uint8_t *target = tbase + jb.toff;
+	R.query = qbase + jb.qoff;
+	R.q = dc.q; R.e = dc.e; R.q2 = dc.q2; R.e2 = dc.e2; R.qe = dc.qe_preswap; R.long_thres = dc.long_thres; R.long_diff = dc.long_diff;
+	const int qlen = R.qlen, tlen = R.tlen;
+	R.w = jb.w < 0? (tlen > qlen? tlen : qlen) : jb.w;
+	R.T = (tlen + 15) / 16 * 16;
+	int n_col_ = qlen < tlen? qlen : tlen;
+	n_col_ = ((n_col_ < R.w + 1? n_col_ : R.w + 1) + 15) / 16 + 1;
+	R.n_col = n_col_ * 16;
+	R.p = pbase + jb.p_off;
+	R.r_total = qlen + tlen - 1;
+	R.r = 0; R.last_st = R.last_en = -1; R.H0 = 0; R.last_H0_t = 0; R.cells = 0; R.qv = 0;
+	DpK K;
+	K.nqe = pk8(-R.q - R.e); K.nq2e2 = pk8(-R.q2 - R.e2); K.q = pk8(R.q); K.q2 = pk8(R.q2); K.qe = pk8(R.q + R.e); K.q2e2 = pk8(R.q2 + R.e2);
+	K.mch = pk8(dc.sc_mch); K.dmis_v = vreg_const(pk8(dc.sc_mis - dc.sc_mch)); K.N = pk8(dc.sc_N); K.one = 0x00010001u; K.c256 = 0x01000100u; K.m256 = 0xff00ff00u;
+	K.two = 0x00020002u; K.three = 0x00030003u; K.four = 0x00040004u; K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u;
+	K.dx1 = K.nqe & 0xffff0000u; K.dx21 = K.nq2e2 & 0xffff0000u;
+	DpSt S;
+#define DP_INIT(k) { const int t = 128 * k + 2 * lane; \
+		S.U##k = S.V##k = S.X##k = S.Y##k = K.nqe; S.X2##k = S.Y2##k = K.nq2e2; S.SC##k = 0; S.QQ##k = 0; S.Hl##k = S.Hh##k = KSW_NEG_INF; \
+		S.TQ##k = (NP > k && t < tlen? (uint32_t)target[t] : 0u) | (NP > k && t + 1 < tlen? (uint32_t)target[t + 1] : 0u) << 16; }
+	DP_INIT(0) DP_INIT(1) DP_INIT(2) DP_INIT(3) DP_INIT(4) DP_INIT(5) DP_INIT(6) DP_INIT(7)
+	{   // ambiguous bases anywhere?  (the common case has none and skips the sc_N selection)
+		bool n = false;
+		for (int i = lane; i < tlen; i += 64) n |= target[i] > 3;
+		for (int i = lane; i < qlen; i += 64) n |= R.query[i] > 3;
+		R.any_n = __ballot(n) != 0;
+	}
+	if (R.flag & EZ_RIGHT) dp_sweep<NP, EXACT, true>(R, S, K, lane);
+	else dp_sweep<NP, EXACT, false>(R, S, K, lane);
+	if (lane == 0) {
+		const int flag = R.flag;
+		int i0 = -1, j0 = -1;
+		if (!ez.zdropped && !(flag & EZ_EXTZ_ONLY)) { i0 = tlen - 1; j0 = qlen - 1; }
+		else if (!ez.zdropped && (flag & EZ_EXTZ_ONLY) && ez.mqe + R.end_bonus > ez.max) { ez.reach_end = 1; i0 = ez.mqe_t; j0 = qlen - 1; }
+		else if (ez.max_t >= 0 && ez.max_q >= 0) { i0 = ez.max_t; j0 = ez.max_q; }
+		mm355_dpres_t o;
+		o.max = ez.max; o.zdropped = ez.zdropped; o.max_q = ez.max_q; o.max_t = ez.max_t; o.mqe = ez.mqe; o.mqe_t = ez.mqe_t;
+		o.mte = ez.mte; o.mte_q = ez.mte_q; o.score = ez.score; o.reach_end = ez.reach_end;
+		o.n_cigar = i0; o.cigar_off = j0;   // start cell for k_ksw_backtrack
+		res[jid] = o;
+		if (R.cells) atomicAdd(cells_ctr, R.cells);
+	}
+}

@@ -56,7 +56,7 @@ struct mm355_ctx {
 	DBuf rq;       // per-read query codes fwd|rev
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
-	hipStream_t dp_st[8] = {0,0,0,0,0,0,0,0}; hipEvent_t dp_ev[8] = {0,0,0,0,0,0,0,0};
+	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[16] = {};
 	HostBatch hb;
 };
 

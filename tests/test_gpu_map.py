@@ -119,22 +119,29 @@ def test_dp_kernel_parity(ont):
     al = ont["al"]
     jobs, qs, ts = [], [], []
     EXTZ, RIGHT, REV, APPROX = 0x40, 0x02, 0x80, 0x08
-    for i in range(120):
-        tl = int(rng.integers(1, 700)) if i % 7 else int(rng.integers(900, 2600))
+    APPROX_DROP = 0x10
+    kinds = [(EXTZ, 751, 400), (EXTZ | RIGHT | REV, 751, 200), (APPROX, 30001, 400), (0, None, 400), (APPROX | RIGHT, 30001, 400),
+             (EXTZ | APPROX | APPROX_DROP, 751, 100), (RIGHT, None, 400), (APPROX, None, 400), (EXTZ, None, 60)]
+    spans = [(1, 40), (100, 140), (240, 270), (500, 530), (1000, 1040), (1, 700), (900, 2600)]   # around the size-class borders
+    for i in range(540):
+        lo, hi = spans[i % len(spans)]
+        tl = int(rng.integers(lo, hi))
         t = S.random_codes(rng, tl)
         q = S.mutate(t, rng, 0.05, 0.03, 0.03)
         if i % 11 == 0 and len(q) > 20:
             q[len(q) // 2:len(q) // 2 + 3] = 4
+        if i % 17 == 0 and tl > 30:
+            t[tl // 3:tl // 3 + 2] = 4
         if i % 13 == 0:
             q = np.concatenate([q[:len(q) // 2], S.random_codes(rng, 300)])   # forces z-drop
+        if i % 19 == 0:
+            q = q[:max(1, len(q) // 3)]                                       # query much shorter than the target
         if len(q) == 0:
             q = S.random_codes(rng, 5)
-        kind = i % 4
-        flag = [EXTZ, EXTZ | RIGHT | REV, APPROX, 0][kind]
-        w = [751, 751, 30001, int(rng.integers(5, 200))][kind]
-        zd = [400, 200, 400, 400][kind]
-        eb = [-1, -1, -1, -1][kind]
-        jobs.append((len(q), tl, w, zd, eb, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
+        flag, w, zd = kinds[i % len(kinds)]
+        if w is None:
+            w = int(rng.integers(5, 200))
+        jobs.append((len(q), tl, w, zd, -1 if i % 5 else 10, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
     qcat = np.concatenate(qs); tcat = np.concatenate(ts)
     ja = (_ffi.DpJob * len(jobs))()
     qo = to = 0
