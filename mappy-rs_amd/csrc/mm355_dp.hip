@@ -482,7 +482,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
 			if (ids[g].empty()) continue;
 			const DpClass &k = classes[g >> 1];
-			if (c->dp_st[g] == 0) { HIPCHK(hipStreamCreateWithFlags(&c->dp_st[g], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming)); }
+			if (c->dp_st[g] == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[g], hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[g], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming)); }
 			const unsigned nj = (unsigned)ids[g].size();
 			const int32_t *gid = d_ids + grp_off[g];
 			const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();

@@ -14,6 +14,12 @@
 #include <assert.h>
 #include <algorithm>
 #include "mm355_glue.h"
+#include "mm355_prof.h"
+#include <atomic>
+#include <chrono>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define PARENT_UNSET   (-1)
 #define PARENT_TMP_PRI (-2)
@@ -789,6 +795,7 @@ void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, Read
 	hash = wang32(hash);
 	const float pen_gap = (float)(opt->chain_gap_scale * 0.01 * mi->k), pen_skip = (float)(opt->chain_skip_scale * 0.01 * mi->k);
 	int n_regs0 = (int)rs.u.size();
+	{ ProfScope pf(PF_PRE_RMQ);
 	if (opt->bw_long > opt->bw && (opt->flag & (MMF_SPLICE | MMF_SR | MMF_NO_LJOIN)) == 0 && n_regs0 > 1) {
 		int32_t st = (int32_t)rs.a[0].y, en = (int32_t)rs.a[(int32_t)rs.u[0] - 1].y;
 		if (qlen - (en - st) > opt->rmq_rescue_size || en - st > qlen * opt->rmq_rescue_ratio) {
@@ -800,15 +807,22 @@ void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, Read
 			            pen_gap, pen_skip, rs.a, rs.u);
 		}
 	}
+	}
+	int n;
+	{ ProfScope pf(PF_PRE_REGS);
 	gen_regs(hash, qlen, rs);
-	int n = (int)rs.regs.size();
+	n = (int)rs.regs.size();
 	if (!(opt->flag & MMF_ALL_CHAINS) && n > 0) {
 		set_parent(opt->mask_level, opt->mask_len, n, rs.regs.data(), opt->a * 2 + opt->b, (int)(opt->flag & MMF_HARD_MLEVEL));
 		select_sub(opt->pri_ratio, mi->k * 2, opt->best_n, 1, (int)(opt->max_gap * 0.8), &n, rs.regs.data());
 	}
+	}
+	{ ProfScope pf(PF_PRE_ESTERR);
 	est_err(mi, qlen, n, rs.regs.data(), rs.a.data(), (int32_t)rs.mini_pos.size(), rs.mini_pos.data());
+	}
 	n = filter_strand_retained(n, rs.regs.data());
 	rs.regs.resize(n);
+	ProfScope pfc(PF_PRE_CODES);
 	// U:align.c::mm_align_skeleton prologue: query codes and anchor squeeze
 	static const struct Nt4Lut { uint8_t t[256]; Nt4Lut() { for (int c = 0; c < 256; ++c) t[c] = (uint8_t)mm_nt4((uint8_t)c); } } lut;
 	rs.qc[0].resize(qlen);
@@ -823,6 +837,41 @@ void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, Read
 	rs.n_a = squeeze_a(n, rs.regs.data(), rs.a.data());
 	rs.cursor = 0; rs.aligned = n == 0;
 	rs.tasks.clear();
+}
+
+bool g_prof_on = getenv("MM355_PROF") != 0;
+static std::atomic<ProfThread*> g_prof_threads(nullptr);
+ProfThread *mm355_prof_thread()
+{
+	static thread_local ProfThread *me = nullptr;
+	if (me == nullptr) {
+		me = new ProfThread();   // leaked with the thread
+		memset(me, 0, sizeof(*me));
+		ProfThread *head = g_prof_threads.load();
+		do { me->next = head; } while (!g_prof_threads.compare_exchange_weak(head, me));
+	}
+	return me;
+}
+static double tsc_per_us()
+{
+	static double v = [] { auto t0 = std::chrono::steady_clock::now(); uint64_t c0 = __rdtsc();
+		while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 20000.0) {}
+		uint64_t c1 = __rdtsc(); return (double)(c1 - c0) / std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }();
+	return v;
+}
+void mm355_prof_dump(int64_t n_reads)   // call while no worker is inside a section
+{
+	static const char *nm[PF_N] = { "pre:copy", "pre:rmq", "pre:regs", "pre:est_err", "pre:codes", "pre:squeeze", "task_prepare", "getseq", "test_zdrop", "add_cigar",
+	                                "update_extra", "task_run(total)", "align_step(total)", "finish", "dp:distribute", "dp:gather_build", "assemble", "x1:newExtra+getseq", "x2:fix_cigar", "x3:extra_loop", "x4:cs_md", "x5" };
+	if (!g_prof_on) return;
+	const double f = tsc_per_us(), nr = (double)(n_reads > 0? n_reads : 1);
+	fprintf(stderr, "[mm355 prof] CPU microseconds per read (%lld reads):", (long long)n_reads);
+	for (int i = 0; i < PF_N; ++i) {
+		uint64_t t = 0, c = 0;
+		for (ProfThread *p = g_prof_threads.load(); p; p = p->next) { t += p->tsc[i]; c += p->cnt[i]; p->tsc[i] = 0; p->cnt[i] = 0; }
+		if (c) fprintf(stderr, " %s=%.1f(x%.1f)", nm[i], t / f / nr, c / nr);
+	}
+	fprintf(stderr, "\n");
 }
 
 // ================================================================== alignment driver (U:align.c)
@@ -897,9 +946,38 @@ static int test_zdrop(const mm355_mapopt_t *opt, const uint8_t *qseq, const uint
 	for (int k = 0; k < n_cigar; ++k) {
 		uint32_t l, op = cigar[k] & 0xf, len = cigar[k] >> 4;
 		if (op == 0) {
-			for (l = 0; l < len; ++l) {
-				score += mat[tseq[i + l] * 5 + qseq[j + l]];
-				update_max_zdrop(score, i + l, j + l, &max, &max_i, &max_j, opt->e, &max_zdrop, pos);
+			// Runs of equal unambiguous bases are folded: along such a run the score grows by `a` per base, so (U:align.c::
+			// mm_update_max_zdrop) only its first base can raise max_zdrop while score < max, and once score >= max every
+			// further base just moves the maximum -- same final state as the base-by-base loop.
+			const int32_t a_m = mat[0];
+			l = 0;
+			while (l < len) {
+				uint32_t run = 0;
+				if (a_m > 0) {
+					while (l + run + 8 <= len) {
+						uint64_t tw, qw; memcpy(&tw, tseq + i + l + run, 8); memcpy(&qw, qseq + j + l + run, 8);
+						const uint64_t bad = (tw ^ qw) | ((tw | qw) & 0xfcfcfcfcfcfcfcfcULL);
+						if (bad == 0) { run += 8; continue; }
+						run += (uint32_t)(__builtin_ctzll(bad) >> 3);
+						goto run_done;
+					}
+					while (l + run < len && tseq[i + l + run] == qseq[j + l + run] && tseq[i + l + run] < 4) ++run;
+				}
+			run_done:
+				if (run > 0) {
+					const int bi = i + (int)l, bj = j + (int)l;     // first base of the run
+					int64_t k_star = 1;                              // first base (1-based) whose score reaches max
+					if (max != INT32_MIN && (int64_t)max - score > a_m) k_star = ((int64_t)max - score + a_m - 1) / a_m;
+					if (k_star > 1) update_max_zdrop(score + a_m, bi, bj, &max, &max_i, &max_j, opt->e, &max_zdrop, pos);   // score < max there
+					score += a_m * (int32_t)run;
+					if (k_star <= (int64_t)run) { max = score; max_i = bi + (int)run - 1; max_j = bj + (int)run - 1; }
+					l += run;
+				}
+				if (l < len) {   // a mismatch or an ambiguous base
+					score += mat[tseq[i + l] * 5 + qseq[j + l]];
+					update_max_zdrop(score, i + l, j + l, &max, &max_i, &max_j, opt->e, &max_zdrop, pos);
+					++l;
+				}
 			}
 			i += len, j += len;
 		} else if (op == 1 || op == 2 || op == 3) {
@@ -997,19 +1075,41 @@ static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const
 	double s = 0.0, max = 0.0;
 	Extra *p = r->p;
 	if (p == 0) return;
-	fix_cigar(r, qseq, tseq, &qshift, &tshift);
+	{ ProfScope pf2(PF_X2); fix_cigar(r, qseq, tseq, &qshift, &tshift); }
 	qseq += qshift, tseq += tshift;
 	r->blen = r->mlen = 0;
+	ProfScope *pf3 = new ProfScope(PF_X3);
 	for (size_t k = 0; k < p->cigar.size(); ++k) {
 		uint32_t op = p->cigar[k] & 0xf, len = p->cigar[k] >> 4, l;
 		if (op == 0) {
 			int n_ambi = 0, n_diff = 0;
-			for (l = 0; l < len; ++l) {
-				int cq = qseq[qoff + l], ct = tseq[toff + l];
-				if (ct > 3 || cq > 3) ++n_ambi;
-				else if (ct != cq) ++n_diff;
-				s += mat[ct * 5 + cq];
-				if (s < 0) s = 0; else max = max > s? max : s;
+			// runs of equal unambiguous bases in one step: s only grows along them, so the running maximum is taken at their end.
+			// (s is a sum of small integers and of float-valued gap costs: every partial sum is exact in double, the order of the
+			// additions cannot change it)
+			const double a_m = mat[0];
+			l = 0;
+			while (l < len) {
+				uint32_t run = 0;
+				if (a_m > 0) {
+					while (l + run + 8 <= len) {
+						uint64_t tw, qw; memcpy(&tw, tseq + toff + l + run, 8); memcpy(&qw, qseq + qoff + l + run, 8);
+						const uint64_t bad = (tw ^ qw) | ((tw | qw) & 0xfcfcfcfcfcfcfcfcULL);
+						if (bad == 0) { run += 8; continue; }
+						run += (uint32_t)(__builtin_ctzll(bad) >> 3);
+						goto run_done;
+					}
+					while (l + run < len && tseq[toff + l + run] == qseq[qoff + l + run] && tseq[toff + l + run] < 4) ++run;
+				}
+			run_done:
+				if (run > 0) { s += a_m * run; max = max > s? max : s; l += run; }
+				if (l < len) {
+					int cq = qseq[qoff + l], ct = tseq[toff + l];
+					if (ct > 3 || cq > 3) ++n_ambi;
+					else if (ct != cq) ++n_diff;
+					s += mat[ct * 5 + cq];
+					if (s < 0) s = 0; else max = max > s? max : s;
+					++l;
+				}
 			}
 			r->blen += len - n_ambi, r->mlen += len - (n_ambi + n_diff), p->n_ambi += n_ambi;
 			toff += len, qoff += len;
@@ -1030,6 +1130,8 @@ static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const
 		} else if (op == 3) toff += len;
 	}
 	p->dp_max = (int32_t)(max + .499);
+	delete pf3;
+	ProfScope pf4(PF_X4);
 	if (out_flags & MM355_OUT_CS) { p->cs.clear(); gen_cs(r, qseq, tseq, p->cs); }
 	if (out_flags & MM355_OUT_MD) { p->md.clear(); gen_md(r, qseq, tseq, p->md); }
 }
@@ -1146,6 +1248,7 @@ static void fix_bad_ends(const Reg *r, const mm128 *a, int bw, int min_match, in
 // one-off part of mm_align1: seed filtering and the extension windows
 static void task_prepare(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs, const Reg *r, AlnTask &T)
 {
+	ProfScope pf(PF_TASK_PREPARE);
 	mm128 *a = rs.a.data();
 	const int qlen = rs.qlen, n_a = rs.n_a, kh = mi->k >> 1;
 	int32_t i, l, rs1, qs1, re1, qe1;
@@ -1239,6 +1342,7 @@ static void request_left(const mm355_mapopt_t *opt, int read_id, int task_id, Al
 // replayable part of mm_align1.  Returns true when region `ri` is fully aligned (r, and *r2 when split, are final).
 static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_id, ReadState &rs, int ri, int task_id, Reg *r2, std::vector<DpReq> &reqs)
 {
+	ProfScope pf_run(PF_TASK_RUN);
 	AlnTask &T = rs.tasks[task_id];
 	Reg *r = &rs.regs[ri];
 	mm128 *a = rs.a.data();
@@ -1252,7 +1356,7 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 	gen_simple_mat(mat, opt->a, opt->b, opt->sc_ambi);
 	Extra tmp;        // alignment under construction; committed only when every needed DP result is present
 	bool have_p = false;
-	auto add_cigar = [&](const uint32_t *cg, int ncg) { if (ncg <= 0) return; Reg t2; t2.p = &tmp; append_cigar(&t2, cg, ncg); have_p = true; };
+	auto add_cigar = [&](const uint32_t *cg, int ncg) { if (ncg <= 0) return; ProfScope pf(PF_ADD_CIGAR); Reg t2; t2.p = &tmp; append_cigar(&t2, cg, ncg); have_p = true; };
 	auto RES = [&](int slot) -> EzRes& { return T.res[T.slot_of[slot]]; };
 	std::vector<uint8_t> tseq;
 	r2->cnt = 0;
@@ -1282,9 +1386,9 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 			if (!ok) { complete = false; rs_run = re_run, qs_run = qe_run; continue; }   // speculate: not dropped
 			EzRes *e = &RES(sa);
 			tseq.resize((size_t)(re_run - rs_run) + 1);
-			getseq(mi, (uint32_t)rid, rs_run, re_run, tseq.data());
+			{ ProfScope pf(PF_GETSEQ); getseq(mi, (uint32_t)rid, rs_run, re_run, tseq.data()); }
 			const uint8_t *qseq = rs.qc[rev].data() + qs_run;
-			zdrop_code = test_zdrop(opt, qseq, tseq.data(), e->cigar, e->n_cigar, mat);
+			{ ProfScope pf(PF_TEST_ZDROP); zdrop_code = test_zdrop(opt, qseq, tseq.data(), e->cigar, e->n_cigar, mat); }
 			if (zdrop_code != 0) {
 				ok = want(T, se, read_id, task_id, reqs, qe_run - qs_run, re_run - rs_run, qs_run, rev, (uint32_t)rid, rs_run, 0, bw1,
 				          zdrop_code == 2? opt->zdrop_inv : opt->zdrop, -1, 0);
@@ -1327,9 +1431,11 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 	if (rev) r->qs = qlen - qe1, r->qe = qlen - qs1;
 	else r->qs = qs1, r->qe = qe1;
 	if (have_p) {
+		ProfScope pf(PF_UPDATE_EXTRA);
+		{ ProfScope pf1(PF_X1);
 		r->p = new Extra(tmp);
 		tseq.resize((size_t)(re1 - rs1) + 1);
-		getseq(mi, (uint32_t)rid, rs1, re1, tseq.data());
+		getseq(mi, (uint32_t)rid, rs1, re1, tseq.data()); }
 		update_extra(r, rs.qc[r->rev].data() + qs1, tseq.data(), mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags);
 	}
 	return true;
@@ -1426,6 +1532,7 @@ bool mm355_glue_align_step(const mm355_index *mi, const mm355_mapopt_t *opt, int
 {
 	rs.out_flags = flags;
 	if (rs.aligned) return true;
+	ProfScope pf_step(PF_STEP_TOTAL);
 	// commit in skeleton order
 	while (rs.cursor < (int)rs.regs.size()) {
 		const int i = rs.cursor;
@@ -1483,22 +1590,40 @@ static void get_aln_seqs(const mm355_index *mi, const ReadState &rs, const Reg *
 	else for (int i = r->qs; i < r->qe; ++i) { uint8_t c = rs.qc[0][i]; q[r->qe - i - 1] = c >= 4? 4 : 3 - c; }
 }
 
-static void gen_cs(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::string &s)
+static inline void put_uint(std::string &s, char lead, unsigned v)   // lead (if non-zero) followed by v in decimal
+{
+	char buf[12]; int n = 0;
+	do { buf[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+	if (lead) s += lead;
+	while (n > 0) s += buf[--n];
+}
+// length of the common prefix of q[0..len) and t[0..len), eight bases per step
+static inline int match_run(const uint8_t *q, const uint8_t *t, int len)
+{
+	int j = 0;
+	while (j + 8 <= len) {
+		uint64_t qw, tw; memcpy(&qw, q + j, 8); memcpy(&tw, t + j, 8);
+		const uint64_t x = qw ^ tw;
+		if (x) return j + (int)(__builtin_ctzll(x) >> 3);
+		j += 8;
+	}
+	while (j < len && q[j] == t[j]) ++j;
+	return j;
+}
+
+static void gen_cs(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::string &s)   // U:format.c::write_cs_core (short form, no introns)
 {
 	int q_off = 0, t_off = 0;
-	char buf[16];
 	s.reserve(s.size() + (size_t)(r->qe - r->qs) / 2 + 64);
 	for (size_t i = 0; i < r->p->cigar.size(); ++i) {
 		int op = r->p->cigar[i] & 0xf, len = r->p->cigar[i] >> 4;
 		if (op == 0 || op == 7 || op == 8) {
-			int l_tmp = 0;
-			for (int j = 0; j < len; ++j) {
-				if (qseq[q_off + j] != tseq[t_off + j]) {
-					if (l_tmp > 0) { snprintf(buf, 16, ":%d", l_tmp); s += buf; l_tmp = 0; }
-					s += '*'; s += "acgtn"[tseq[t_off + j]]; s += "acgtn"[qseq[q_off + j]];
-				} else ++l_tmp;
+			int j = 0;
+			while (j < len) {
+				const int m = match_run(qseq + q_off + j, tseq + t_off + j, len - j);
+				if (m > 0) { put_uint(s, ':', (unsigned)m); j += m; }
+				if (j < len) { s += '*'; s += "acgtn"[tseq[t_off + j]]; s += "acgtn"[qseq[q_off + j]]; ++j; }
 			}
-			if (l_tmp > 0) { snprintf(buf, 16, ":%d", l_tmp); s += buf; }
 			q_off += len, t_off += len;
 		} else if (op == 1) { s += '+'; for (int j = 0; j < len; ++j) s += "acgtn"[qseq[q_off + j]]; q_off += len; }
 		else if (op == 2) { s += '-'; for (int j = 0; j < len; ++j) s += "acgtn"[tseq[t_off + j]]; t_off += len; }
@@ -1506,26 +1631,27 @@ static void gen_cs(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::
 	}
 }
 
-static void gen_md(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::string &s)
+static void gen_md(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::string &s)   // U:format.c::write_MD_core
 {
 	int q_off = 0, t_off = 0, l_MD = 0;
-	char buf[16];
 	for (size_t i = 0; i < r->p->cigar.size(); ++i) {
 		int op = r->p->cigar[i] & 0xf, len = r->p->cigar[i] >> 4;
 		if (op == 0 || op == 7 || op == 8) {
-			for (int j = 0; j < len; ++j) {
-				if (qseq[q_off + j] != tseq[t_off + j]) { snprintf(buf, 16, "%d", l_MD); s += buf; s += "ACGTN"[tseq[t_off + j]]; l_MD = 0; }
-				else ++l_MD;
+			int j = 0;
+			while (j < len) {
+				const int m = match_run(qseq + q_off + j, tseq + t_off + j, len - j);
+				l_MD += m; j += m;
+				if (j < len) { put_uint(s, 0, (unsigned)l_MD); s += "ACGTN"[tseq[t_off + j]]; l_MD = 0; ++j; }
 			}
 			q_off += len, t_off += len;
 		} else if (op == 1) q_off += len;
 		else if (op == 2) {
-			snprintf(buf, 16, "%d", l_MD); s += buf; s += '^';
+			put_uint(s, 0, (unsigned)l_MD); s += '^';
 			for (int j = 0; j < len; ++j) s += "ACGTN"[tseq[t_off + j]];
 			l_MD = 0; t_off += len;
 		} else if (op == 3) t_off += len;
 	}
-	if (l_MD > 0) { snprintf(buf, 16, "%d", l_MD); s += buf; }
+	if (l_MD > 0) put_uint(s, 0, (unsigned)l_MD);
 }
 
 // ================================================================== stage 3

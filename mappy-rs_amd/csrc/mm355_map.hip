@@ -14,6 +14,7 @@
 #include "mm355_pipeline.h"
 #include "mm355_dp.h"
 #include "mm355_glue.h"
+#include "mm355_prof.h"
 
 // packs u[], compacted anchors and mini_pos[] of all reads into three dense arrays (one D2H copy each)
 __global__ __launch_bounds__(256) void k_pack_chains(int n_reads, const int64_t *aoff, const int64_t *roff, const int32_t *n_u, const int32_t *n_v, const int32_t *n_mini,
@@ -237,9 +238,10 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	parallel_for(n_reads, nt, [&](int64_t i, int) {
 		ReadState &r = rs[i];
 		r.qlen = dl[i]; r.seq = seqs[i]; r.rep_len = hb.rep_len[i];
+		{ ProfScope pf(PF_PRE_COPY);
 		r.u.assign(pu + uo[i], pu + uo[i + 1]);
 		r.a.assign(pa + vo[i], pa + vo[i + 1]);
-		r.mini_pos.assign(pm + mo_[i], pm + mo_[i + 1]);
+		r.mini_pos.assign(pm + mo_[i], pm + mo_[i + 1]); }
 		if (r.qlen > 0) mm355_glue_pre_align(mi, mo, r); else r.aligned = true;
 	});
 	double ms_host = now_ms() - t_host0;
@@ -270,6 +272,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	std::vector<std::vector<uint32_t>> rc_(n_reads);
 	std::vector<std::string> rstr(n_reads);
 	parallel_for(n_reads, nt, [&](int64_t i, int) {
+		ProfScope pf(PF_FINISH);
 		if (rs[i].qlen > 0) mm355_glue_finish(mi, mo, rs[i], flags, rh[i], rc_[i], rstr[i]);
 		mm355_glue_release(rs[i]);
 	});
@@ -302,6 +305,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	                     tv_front, tv_pack, tv_pre, tv_steps, n_rounds, tv_dp, c->stats.ms_dp, tv_fin, tv_asm, now_ms() - t_start);
 	c->stats.ms_host = ms_host;
 	c->stats.ms_total = now_ms() - t_start;
+	if (verbose) mm355_prof_dump(n_reads);
 	*out = H;
 	return 0;
 }

@@ -47,6 +47,7 @@ struct mm355_ctx {
 	// per-batch device buffers
 	DBuf heavy, seq, roff, rlen, order, ck_read, ck_start, ck_n, ck_r0;
 	int64_t n_chunks = 0;
+	int prio_low = 0, prio_high = 0; bool use_prio = false;
 	int n_heavy = 0; hipStream_t aux_st = 0; hipEvent_t aux_ev = 0, aux_ev2 = 0; DBuf sort_tasks;
 	DBuf mz, mz_tmp, n_mz, sn, sv, sflt, hl, soff, n_a, rep_len, n_mini, mini_pos, counters, err;
 	DBuf aoff, a, f, p, v, z, t8, vi, b, wk, u, u2, n_u, n_v;

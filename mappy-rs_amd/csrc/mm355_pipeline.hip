@@ -53,7 +53,15 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	HIPCHK(hipSetDevice(device_id));
 	mm355_ctx *c = new mm355_ctx();
 	c->mi = mi; c->dev = device_id;
-	HIPCHK(hipStreamCreate(&c->st));
+	{   // the per-read front kernels are latency chains of single waves: their stream outranks the extension streams, whose wide
+		// grids would otherwise occupy every CU slot and stretch the front of the other contexts (MM355_STREAM_PRIO=0 disables)
+		int lo = 0, hi = 0;
+		static const bool use_prio = [] { const char *e = getenv("MM355_STREAM_PRIO"); return !(e && atoi(e) == 0); }();
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest (numerically lower)
+		if (use_prio && hi < lo) HIPCHK(hipStreamCreateWithPriority(&c->st, hipStreamDefault, hi));
+		else HIPCHK(hipStreamCreate(&c->st));
+		c->prio_low = use_prio && hi < lo? lo : 0; c->prio_high = use_prio && hi < lo? hi : 0; c->use_prio = use_prio && hi < lo;
+	}
 	HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
 	if (mi->dev_resident) {   // built on this device: the table is already in HBM
 		if (mi->dev_id != device_id) { delete c; return MM355_EINVAL; }
@@ -251,7 +259,7 @@ static int check_err(mm355_ctx *c)
 int mm355_run_sort(mm355_ctx *c)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
-	if (c->aux_st == 0) { HIPCHK(hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev2, hipEventDisableTiming)); }
+	if (c->aux_st == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->aux_st, hipStreamNonBlocking, c->prio_high)); else HIPCHK(hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev2, hipEventDisableTiming)); }
 	{
 		// every emitted task covers > 64 elements, so tot_a / 64 bounds each list
 		const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->n_heavy + 1024;
