@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--workload", default="ecoli")
     ap.add_argument("--reads", type=int, default=16384, help="reads per step per GPU")
     ap.add_argument("--streams", type=int, default=4, help="concurrent contexts (HIP streams) per GPU")
+    ap.add_argument("--depth", type=int, default=1, help="sub-batches each stream maps one after the other within a step")
     ap.add_argument("--scale", type=float, default=1.0, help="genome scale of the human workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -155,7 +156,8 @@ def main():
     L.mm355_mapopt_update(C.byref(mo), idx)
     # `--streams S`: S contexts (own HIP stream + buffers) on this GPU, each with 1/S of the step's reads resident in HBM;
     # a step maps all of them concurrently from S host threads, so the host tail of one sub-batch overlaps kernels of another.
-    n_str = max(1, args.streams)
+    n_thr = max(1, args.streams)
+    n_str = n_thr * max(1, args.depth)
     ctxs, parts = [], []
     for si in range(n_str):
         ctx = C.c_void_p()
@@ -186,10 +188,13 @@ def main():
         return aligned, n_hits, st
 
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(n_str)
+    pool = ThreadPoolExecutor(n_thr)
+
+    def step_thread(ti):   # sub-batches ti, ti + n_thr, ... one after the other: their phases interleave with the other threads'
+        return [step_one(si) for si in range(ti, n_str, n_thr)]
 
     def step():
-        res = list(pool.map(step_one, range(n_str)))
+        res = [r for part in pool.map(step_thread, range(n_thr)) for r in part]
         agg_st = _ffi.Stats()
         for _a, _h, st in res:
             for k, _t in _ffi.Stats._fields_:
@@ -253,7 +258,7 @@ def main():
             "value": round(aligned_all / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (+f32 chaining gap cost)", "data": "synthetic",
-            "config": dict(workload=wl["workload"], reads_per_step_per_gpu=len(reads), streams_per_gpu=n_str, mbases_per_step_per_gpu=round(n_bases / 1e6, 3),
+            "config": dict(workload=wl["workload"], reads_per_step_per_gpu=len(reads), streams_per_gpu=n_thr, sub_batches_per_stream=max(1, args.depth), mbases_per_step_per_gpu=round(n_bases / 1e6, 3),
                            preset=wl["preset"], parallelism="reads sharded over %d GPU(s), index replicated, no collective" % world),
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
             "pcie_inclusive_mbases_per_s": round(n_bases / dt_pcie / 1e6, 3),

@@ -27,7 +27,7 @@ struct DpGather {           // where the code strings of a job come from
 };
 
 DpConst mm355_dp_const(const mm355_mapopt_t *mo);
-int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
-                 const mm355_dpres_t **res_out, const uint32_t **cigar_out);   // results live in pinned host buffers of the context
-int mm355_dp_gather(mm355_ctx *c, const std::vector<DpGather> &g, size_t q_tot, size_t t_tot);
+int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t n, const uint8_t *d_q, const uint8_t *d_t, HBuf *arena,
+                 const mm355_dpres_t **res_out, const uint32_t **cigar_out);   // results live in pinned host buffers (c->h_res, *arena)
+int mm355_dp_gather(mm355_ctx *c, const DpGather *g, size_t n, size_t q_tot, size_t t_tot);   // g: pinned, valid until the next call
 int mm355_run_read_codes(mm355_ctx *c);

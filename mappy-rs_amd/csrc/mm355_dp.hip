@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <vector>
+#include <mutex>
 #include <algorithm>
 #include "mm355_pipeline.h"
 #include "mm355_dp.h"
@@ -429,19 +430,23 @@ static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc
 	else hipLaunchKernelGGL((k_ksw_reg<NP, false>), dim3(n), dim3(64), 0, st, dc, jobs, ids, (int)n, d_q, d_t, bt, res, cells);
 }
 
-// runs jobs whose code strings are already on the device (qbuf/tbuf); fills res[] and the cigar arena (host copies)
-int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &jobs, const uint8_t *d_q, const uint8_t *d_t,
+// runs n jobs whose code strings are already on the device (d_q/d_t).  `jobs` is host memory that stays valid until the call
+// returns (pinned when it comes from the mapping path).  Results: res_out -> c->h_res (pinned, valid until the next call),
+// cigar_out -> dense CIGAR arena in *arena (pinned, owned by the caller's batch).
+int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t n, const uint8_t *d_q, const uint8_t *d_t, HBuf *arena,
                  const mm355_dpres_t **res_out, const uint32_t **cigar_out)
 {
-	const size_t n = jobs.size();
 	*res_out = 0; *cigar_out = 0;
 	if (n == 0) return 0;
 	DpConst dc = mm355_dp_const(mo);
-	// lay out per-job work areas
-	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
 	static const bool legacy = [] { const char *e = getenv("MM355_DP_LEGACY"); return e && atoi(e) != 0; }();
 	const DpClass *classes = legacy? DP_CLASSES_LEGACY : DP_CLASSES;
-	std::vector<int32_t> ids[DP_N_GROUP];
+	// lay out per-job work areas; group = size class * 2 + exact
+	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
+	std::vector<uint8_t> grp(n);
+	size_t n_grp[DP_N_GROUP + 1] = {0};
+	const int LB = 1024;                       // backtrack order: buckets of (qlen + tlen) / 8, longest first (approximate is enough)
+	std::vector<uint32_t> lcnt(LB + 1, 0);
 	for (size_t i = 0; i < n; ++i) {
 		DpJobDev &j = jobs[i];
 		j.skip = (mo->max_sw_mat > 0 && (int64_t)j.tlen * j.qlen > mo->max_sw_mat) || !dc.valid;
@@ -450,19 +455,47 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 		n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
 		int T = (j.tlen + 15) / 16 * 16;
 		j.p_off = (int64_t)p_tot; j.off_off = (int64_t)off_tot; j.cig_off = (int64_t)cig_tot; j.st_off = 0;
+		int g = 0;
 		if (j.qlen > 0 && j.tlen > 0 && !j.skip) {
 			p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
 			cig_tot += (size_t)j.qlen + j.tlen + 2;
 			int cls = 0;
 			while (cls < DP_N_CLASS - 1 && T > classes[cls].cap) ++cls;
 			if (cls == DP_N_CLASS - 1) { j.st_off = (int64_t)st_tot; st_tot += T; }
-			ids[cls * 2 + ((j.flag & EZ_APPROX_MAX)? 0 : 1)].push_back((int32_t)i);
-		} else ids[0].push_back((int32_t)i);
+			g = cls * 2 + ((j.flag & EZ_APPROX_MAX)? 0 : 1);
+		}
+		grp[i] = (uint8_t)g; ++n_grp[g];
+		int lb = (j.qlen + j.tlen) >> 3; if (lb < 0) lb = 0; if (lb >= LB) lb = LB - 1;
+		++lcnt[LB - 1 - lb];
+	}
+	if (c->h_ids.ensure((2 * n + 64) * 4)) return MM355_ENOMEM;
+	int32_t *h_ids = (int32_t*)c->h_ids.p, *h_ord = h_ids + n + 8;
+	size_t grp_off[DP_N_GROUP + 1];
+	{
+		size_t acc = 0;
+		for (int g = 0; g < DP_N_GROUP; ++g) { grp_off[g] = acc; acc += n_grp[g]; }
+		grp_off[DP_N_GROUP] = acc;
+		size_t cur[DP_N_GROUP];
+		for (int g = 0; g < DP_N_GROUP; ++g) cur[g] = grp_off[g];
+		for (size_t i = 0; i < n; ++i) h_ids[cur[grp[i]]++] = (int32_t)i;
+		uint32_t a2 = 0;
+		for (int k = 0; k <= LB; ++k) { uint32_t t = lcnt[k]; lcnt[k] = a2; a2 += t; }
+		for (size_t i = 0; i < n; ++i) {
+			int lb = (jobs[i].qlen + jobs[i].tlen) >> 3; if (lb < 0) lb = 0; if (lb >= LB) lb = LB - 1;
+			h_ord[lcnt[LB - 1 - lb]++] = (int32_t)i;
+		}
 	}
 	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64) ||
 	    c->dp_work.ensure((off_tot + 16) * 4 + (2 * n + 32) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_dense.ensure((cig_tot + 16) * 4) ||
 	    c->dp_H.ensure((st_tot + 16) * 12)) return MM355_ENOMEM;
-	HIPCHK(hipMemcpyAsync(c->dp_jobs.p, jobs.data(), n * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
+	// One extension round saturates the GPU.  Rounds of different contexts take turns (per device): run side by side they would all
+	// finish late together and the contexts would march in lock-step -- GPU idle while every host tail runs, hosts idle while every
+	// round runs.  Taking turns lets the first finisher start its host tail while the next round has the whole GPU.
+	static std::mutex dp_turn[16];
+	static const bool take_turns = [] { const char *e = getenv("MM355_DP_TURNS"); return !(e && atoi(e) == 0); }();
+	std::unique_lock<std::mutex> turn(dp_turn[c->dev & 15], std::defer_lock);
+	if (take_turns) turn.lock();
+	HIPCHK(hipMemcpyAsync(c->dp_jobs.p, jobs, n * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
 	int32_t *d_off = c->dp_work.as<int32_t>();
 	int32_t *d_ids = d_off + off_tot + 16;
 	uint64_t *d_S = c->dp_H.as<uint64_t>();
@@ -471,19 +504,18 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
-		// every size class gets its own HIP stream: the few long alignments of the big classes run concurrently with the
-		// thousands of short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
-		std::vector<int32_t> all_ids; all_ids.reserve(n);
-		size_t grp_off[DP_N_GROUP];
-		for (int g = 0; g < DP_N_GROUP; ++g) { grp_off[g] = all_ids.size(); all_ids.insert(all_ids.end(), ids[g].begin(), ids[g].end()); }
-		HIPCHK(hipMemcpyAsync(d_ids, all_ids.data(), all_ids.size() * 4, hipMemcpyHostToDevice, c->st));
-		HIPCHK(hipStreamSynchronize(c->st));   // all_ids is pageable; also orders the class streams after the uploads
+		// every group gets its own HIP stream: the few long alignments of the big classes run concurrently with the thousands of
+		// short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
+		HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
+		if (c->dp_up_ev == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_up_ev, hipEventDisableTiming));
+		HIPCHK(hipEventRecord(c->dp_up_ev, c->st));   // the group streams start after the uploads
 		(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
-			if (ids[g].empty()) continue;
+			if (n_grp[g] == 0) continue;
 			const DpClass &k = classes[g >> 1];
 			if (c->dp_st[g] == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[g], hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[g], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming)); }
-			const unsigned nj = (unsigned)ids[g].size();
+			HIPCHK(hipStreamWaitEvent(c->dp_st[g], c->dp_up_ev, 0));
+			const unsigned nj = (unsigned)n_grp[g];
 			const int32_t *gid = d_ids + grp_off[g];
 			const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();
 			mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
@@ -503,39 +535,34 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<DpJobDev> &
 			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		}
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
-		std::vector<int32_t> order(n);
-		for (size_t i = 0; i < n; ++i) order[i] = (int32_t)i;
-		std::sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return jobs[x].qlen + jobs[x].tlen > jobs[y].qlen + jobs[y].tlen; });
-		int32_t *d_ord = d_ids + n + 8;
-		HIPCHK(hipMemcpyAsync(d_ord, order.data(), n * 4, hipMemcpyHostToDevice, c->st));
-		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ord, (int)n,
+		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
-		HIPCHK(hipStreamSynchronize(c->st));   // `order` is pageable
 	}
 	HIPCHK(hipGetLastError());
-	unsigned long long ctr[2] = {0, 0};
+	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 64)) return MM355_ENOMEM;
+	unsigned long long *ctr = (unsigned long long*)((char*)c->h_res.p + n * sizeof(mm355_dpres_t));   // pinned landing zone of the two counters
 	HIPCHK(hipMemcpyAsync(ctr, d_cells, 16, hipMemcpyDeviceToHost, c->st));
-	if (c->h_res.ensure(n * sizeof(mm355_dpres_t))) return MM355_ENOMEM;
 	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
+	if (take_turns) turn.unlock();
 	const size_t n_dense = (size_t)ctr[1];
-	if (c->h_cig.ensure((n_dense + 16) * 4)) return MM355_ENOMEM;
-	if (n_dense) HIPCHK(hipMemcpyAsync(c->h_cig.p, c->dp_dense.p, n_dense * 4, hipMemcpyDeviceToHost, c->st));
+	if (arena->ensure((n_dense + 16) * 4)) return MM355_ENOMEM;
+	if (n_dense) HIPCHK(hipMemcpyAsync(arena->p, c->dp_dense.p, n_dense * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipStreamSynchronize(c->st));
 	c->stats.dp_cells = (int64_t)ctr[0]; c->stats.n_dp_jobs += (int64_t)n;
-	*res_out = (const mm355_dpres_t*)c->h_res.p; *cigar_out = (const uint32_t*)c->h_cig.p;
+	*res_out = (const mm355_dpres_t*)c->h_res.p; *cigar_out = (const uint32_t*)arena->p;
 	return 0;
 }
 
-int mm355_dp_gather(mm355_ctx *c, const std::vector<DpGather> &g, size_t q_tot, size_t t_tot)
+// gather descriptors g[0..n) live in pinned host memory of the context until the next call
+int mm355_dp_gather(mm355_ctx *c, const DpGather *g, size_t n, size_t q_tot, size_t t_tot)
 {
-	if (g.empty()) return 0;
-	if (c->dp_q.ensure(q_tot + 64) || c->dp_t.ensure(t_tot + 64) || c->dp_gather.ensure(g.size() * sizeof(DpGather))) return MM355_ENOMEM;
-	HIPCHK(hipMemcpyAsync(c->dp_gather.p, g.data(), g.size() * sizeof(DpGather), hipMemcpyHostToDevice, c->st));
-	hipLaunchKernelGGL(k_dp_gather, dim3((unsigned)g.size()), dim3(256), 0, c->st, c->dix, c->dp_gather.as<DpGather>(), (int)g.size(),
+	if (n == 0) return 0;
+	if (c->dp_q.ensure(q_tot + 64) || c->dp_t.ensure(t_tot + 64) || c->dp_gather.ensure(n * sizeof(DpGather))) return MM355_ENOMEM;
+	HIPCHK(hipMemcpyAsync(c->dp_gather.p, g, n * sizeof(DpGather), hipMemcpyHostToDevice, c->st));
+	hipLaunchKernelGGL(k_dp_gather, dim3((unsigned)n), dim3(256), 0, c->st, c->dix, c->dp_gather.as<DpGather>(), (int)n,
 	                   c->rq.as<uint8_t>(), c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>());
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipStreamSynchronize(c->st));   // g (pageable) may go out of scope at the caller
 	return 0;
 }
 
@@ -568,7 +595,7 @@ extern "C" int mm355_stage_dp(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t 
 		dj[i].w = jobs[i].w; dj[i].zdrop = jobs[i].zdrop; dj[i].end_bonus = jobs[i].end_bonus; dj[i].flag = jobs[i].flag;
 	}
 	const mm355_dpres_t *r = 0; const uint32_t *cg = 0;
-	int rc = mm355_dp_run(c, mo, dj, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), &r, &cg);
+	int rc = mm355_dp_run(c, mo, dj.data(), dj.size(), c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), &c->h_cig, &r, &cg);
 	if (rc) return rc;
 	int64_t tot = 0;
 	for (int64_t i = 0; i < n_jobs; ++i) {

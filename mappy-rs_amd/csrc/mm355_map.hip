@@ -84,6 +84,25 @@ static void parallel_for(int64_t n, int n_threads, F f)
 	HostPool::get().run(n, n_threads, std::function<void(int64_t, int)>(f));
 }
 
+// MM355_TRACE=<file>: host-side phase timeline (context, phase, start ms, end ms), written at process exit
+struct TraceEv { const void *ctx; const char *phase; double t0, t1; };
+static std::mutex g_trace_mu;
+static std::vector<TraceEv> g_trace;
+static const char *g_trace_path = getenv("MM355_TRACE");
+static void trace_dump()
+{
+	FILE *fp = fopen(g_trace_path, "w");
+	if (!fp) return;
+	for (const TraceEv &e : g_trace) fprintf(fp, "%p\t%s\t%.3f\t%.3f\n", e.ctx, e.phase, e.t0, e.t1);
+	fclose(fp);
+}
+static void trace_add(const void *ctx, const char *phase, double t0, double t1)
+{
+	if (!g_trace_path) return;
+	std::lock_guard<std::mutex> lk(g_trace_mu);
+	if (g_trace.empty()) atexit(trace_dump);
+	g_trace.push_back(TraceEv{ctx, phase, t0, t1});
+}
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int host_threads() { return HostPool::get().size(); }
@@ -96,10 +115,15 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 	(void)hipMemGetInfo(&free_b, &total_b);
 	size_t budget = std::min<size_t>((size_t)24 << 30, free_b / 3);
 	if (budget < ((size_t)256 << 20)) budget = (size_t)256 << 20;
+	const bool verbose = getenv("MM355_VERBOSE") != 0;
+	const int nt = host_threads();
+	std::vector<int64_t> qo, to;
 	size_t i = 0;
 	while (i < reqs.size()) {
-		std::vector<DpGather> g; std::vector<DpJobDev> jobs;
+		const double tb0 = now_ms();
+		// serial part: chunk end and the offsets of the code strings (a prefix sum); everything else is filled in parallel
 		size_t q_tot = 0, t_tot = 0, p_tot = 0, j = i;
+		qo.clear(); to.clear();
 		for (; j < reqs.size(); ++j) {
 			const DpReq &q = reqs[j];
 			int w = q.w < 0? std::max(q.qlen, q.tlen) : q.w;
@@ -108,33 +132,48 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 			size_t pb = q.qlen > 0 && q.tlen > 0? ((size_t)(q.qlen + q.tlen - 1) * n_col_ + 1) * 16 : 0;
 			if (mo->max_sw_mat > 0 && (int64_t)q.tlen * q.qlen > mo->max_sw_mat) pb = 0;
 			if (j > i && p_tot + pb > budget) break;
-			DpGather gg; memset(&gg, 0, sizeof(gg));
-			gg.qlen = q.qlen > 0? q.qlen : 0; gg.tlen = q.tlen > 0? q.tlen : 0;
-			gg.qoff = (int64_t)q_tot; gg.toff = (int64_t)t_tot;
-			gg.q_src = 2 * c->hb.roff[q.read] + (q.rev_strand? rs[q.read].qlen : 0) + q.q_st;
-			gg.rid = q.rid; gg.t_st = q.t_st; gg.rev = q.reversed;
-			g.push_back(gg);
-			DpJobDev jd; memset(&jd, 0, sizeof(jd));
-			jd.qlen = q.qlen; jd.tlen = q.tlen; jd.qoff = gg.qoff; jd.toff = gg.toff; jd.w = q.w; jd.zdrop = q.zdrop; jd.end_bonus = q.end_bonus; jd.flag = q.flag;
-			jobs.push_back(jd);
-			q_tot += (size_t)gg.qlen + 16; t_tot += (size_t)gg.tlen + 16; p_tot += pb;
+			qo.push_back((int64_t)q_tot); to.push_back((int64_t)t_tot);
+			q_tot += (size_t)(q.qlen > 0? q.qlen : 0) + 16; t_tot += (size_t)(q.tlen > 0? q.tlen : 0) + 16; p_tot += pb;
 		}
+		const size_t n = j - i;
+		if (c->h_gather.ensure(n * sizeof(DpGather)) || c->h_jobs.ensure(n * sizeof(DpJobDev))) return MM355_ENOMEM;
+		DpGather *g = (DpGather*)c->h_gather.p; DpJobDev *jobs = (DpJobDev*)c->h_jobs.p;
+		parallel_for(nt, nt, [&](int64_t part, int) {
+			const size_t lo = n * (size_t)part / nt, hi = n * (size_t)(part + 1) / nt;
+			for (size_t k = lo; k < hi; ++k) {
+				const DpReq &q = reqs[i + k];
+				DpGather gg; memset(&gg, 0, sizeof(gg));
+				gg.qlen = q.qlen > 0? q.qlen : 0; gg.tlen = q.tlen > 0? q.tlen : 0;
+				gg.qoff = qo[k]; gg.toff = to[k];
+				gg.q_src = 2 * c->hb.roff[q.read] + (q.rev_strand? rs[q.read].qlen : 0) + q.q_st;
+				gg.rid = q.rid; gg.t_st = q.t_st; gg.rev = q.reversed;
+				g[k] = gg;
+				DpJobDev jd; memset(&jd, 0, sizeof(jd));
+				jd.qlen = q.qlen; jd.tlen = q.tlen; jd.qoff = gg.qoff; jd.toff = gg.toff; jd.w = q.w; jd.zdrop = q.zdrop; jd.end_bonus = q.end_bonus; jd.flag = q.flag;
+				jobs[k] = jd;
+			}
+		});
 		const double tg0 = now_ms();
-		int rc = mm355_dp_gather(c, g, q_tot, t_tot);
+		int rc = mm355_dp_gather(c, g, n, q_tot, t_tot);
 		if (rc) return rc;
 		const double tg1 = now_ms();
 		const mm355_dpres_t *res = 0; const uint32_t *cig = 0;
-		rc = mm355_dp_run(c, mo, jobs, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), &res, &cig);
+		// the dense CIGAR arena of this launch stays alive until the batch is finished (results point into it): one pinned buffer per
+		// launch, heap copies beyond the eighth
+		HBuf *ab = c->n_arena < 8? &c->h_arena[c->n_arena] : &c->h_cig;
+		rc = mm355_dp_run(c, mo, jobs, n, c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>(), ab, &res, &cig);
 		if (rc) return rc;
 		const double tr1 = now_ms();
-		// one bulk copy of the dense CIGAR arena of this launch; results point into it (kept alive until the batch is finished)
-		size_t n_cg = 0;
-		for (size_t k = i; k < j; ++k) n_cg = std::max(n_cg, (size_t)(res[k - i].cigar_off + res[k - i].n_cigar));
-		arenas.emplace_back(cig, cig + n_cg);
-		const uint32_t *arena = arenas.back().data();
-		const int nt_d = host_threads();
-		parallel_for(nt_d, nt_d, [&](int64_t part, int) {   // static partition; every request owns a distinct (read, task, slot)
-			const size_t lo = i + (j - i) * (size_t)part / nt_d, hi = i + (j - i) * (size_t)(part + 1) / nt_d;
+		const uint32_t *arena = cig;
+		if (c->n_arena < 8) ++c->n_arena;
+		else {
+			size_t n_cg = 0;
+			for (size_t k = 0; k < n; ++k) n_cg = std::max(n_cg, (size_t)(res[k].cigar_off + res[k].n_cigar));
+			arenas.emplace_back(cig, cig + n_cg);
+			arena = arenas.back().data();
+		}
+		parallel_for(nt, nt, [&](int64_t part, int) {   // static partition; every request owns a distinct (read, task, slot)
+			const size_t lo = i + n * (size_t)part / nt, hi = i + n * (size_t)(part + 1) / nt;
 			for (size_t k = lo; k < hi; ++k) {
 				const DpReq &q = reqs[k];
 				const mm355_dpres_t &r = res[k - i];
@@ -146,7 +185,7 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 				e.state = 2;
 			}
 		});
-		if (getenv("MM355_VERBOSE")) fprintf(stderr, "[mm355]     dp chunk: %zu jobs, gather %.1f ms, run %.1f ms, distribute %.1f ms\n", j - i, tg1 - tg0, tr1 - tg1, now_ms() - tr1);
+		if (verbose) fprintf(stderr, "[mm355]     dp chunk: %zu jobs, build %.1f ms, gather %.1f ms, run %.1f ms, distribute %.1f ms\n", n, tg0 - tb0, tg1 - tg0, tr1 - tg1, now_ms() - tr1);
 		i = j;
 	}
 	return 0;
@@ -184,6 +223,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	DevParams pr = mm355_make_params(mo, mi);
 	const int64_t n_reads = c->hb.n_reads;
 	memset(&c->stats, 0, sizeof(c->stats));
+	c->n_arena = 0;
 	c->stats.n_reads = n_reads; c->stats.n_bases = c->hb.n_bases;
 	HIPCHK(hipMemsetAsync(c->counters.p, 0, 64, c->st));
 	HIPCHK(hipMemsetAsync(c->err.p, 0, 16, c->st));
@@ -203,7 +243,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	if ((rc = mm355_run_backtrack(c, pr))) return rc;
 	if ((rc = mm355_run_read_codes(c))) return rc;
 	HostBatch &hb = c->hb;
-	tv_front = now_ms() - tv0; tv0 = now_ms();
+	tv_front = now_ms() - tv0; trace_add(c, "front", tv0, now_ms()); tv0 = now_ms();
 	// pack chains / anchors / mini_pos and bring them to the host
 	std::vector<int64_t> uo(n_reads + 1), vo(n_reads + 1), mo_(n_reads + 1);
 	int64_t tu = 0, tv = 0, tm = 0;
@@ -231,7 +271,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		if (tm) HIPCHK(hipMemcpyAsync(pm, d_pm, (size_t)tm * 8, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipStreamSynchronize(c->st));
 	}
-	tv_pack = now_ms() - tv0; tv0 = now_ms();
+	tv_pack = now_ms() - tv0; trace_add(c, "pack", tv0, now_ms()); tv0 = now_ms();
 	const double t_host0 = now_ms();
 	const int nt = host_threads();
 	std::vector<ReadState> rs(n_reads);
@@ -245,7 +285,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		if (r.qlen > 0) mm355_glue_pre_align(mi, mo, r); else r.aligned = true;
 	});
 	double ms_host = now_ms() - t_host0;
-	tv_pre = now_ms() - tv0;
+	tv_pre = now_ms() - tv0; trace_add(c, "pre", tv0, now_ms());
 	int n_rounds = 0;
 	std::vector<std::vector<uint32_t>> arenas;   // CIGAR arenas of all extension launches of this batch
 	// extension rounds: every pending problem of every read goes into the same launches
@@ -259,12 +299,12 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		std::vector<DpReq> reqs;
 		for (auto &v : treq) reqs.insert(reqs.end(), v.begin(), v.end());
 		ms_host += now_ms() - th0;
-		tv_steps += now_ms() - th0;
+		tv_steps += now_ms() - th0; trace_add(c, "align", th0, now_ms());
 		if (n_open.load() == 0) break;
 		if (reqs.empty()) return MM355_EINVAL;   // a read is waiting for a result nobody requested: logic error
 		const double td0 = now_ms();
 		if ((rc = run_dp_round(c, mo, rs, reqs, arenas))) return rc;
-		tv_dp += now_ms() - td0; ++n_rounds;
+		tv_dp += now_ms() - td0; ++n_rounds; trace_add(c, "dp", td0, now_ms());
 		if (verbose) fprintf(stderr, "[mm355]   round %d: %zu jobs, %lld reads open\n", round, reqs.size(), (long long)n_open.load());
 	}
 	const double th1 = now_ms();
@@ -276,7 +316,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		if (rs[i].qlen > 0) mm355_glue_finish(mi, mo, rs[i], flags, rh[i], rc_[i], rstr[i]);
 		mm355_glue_release(rs[i]);
 	});
-	tv_fin = now_ms() - th1; tv0 = now_ms();
+	tv_fin = now_ms() - th1; trace_add(c, "finish", th1, now_ms()); tv0 = now_ms();
 	mm355_hits_t *H = (mm355_hits_t*)calloc(1, sizeof(mm355_hits_t));
 	H->n_reads = n_reads;
 	H->hit_off = (int64_t*)malloc((n_reads + 1) * 8);
@@ -300,7 +340,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		nc += (int64_t)rc_[i].size(); ns += (int64_t)rstr[i].size();
 	}
 	ms_host += now_ms() - th1;
-	tv_asm = now_ms() - tv0;
+	tv_asm = now_ms() - tv0; trace_add(c, "asm", tv0, now_ms());
 	if (verbose) fprintf(stderr, "[mm355] map_resident: front %.1f ms | pack+d2h %.1f | pre_align %.1f | align_steps %.1f | dp rounds(%d) %.1f (kernel %.1f) | finish %.1f | assemble %.1f | total %.1f\n",
 	                     tv_front, tv_pack, tv_pre, tv_steps, n_rounds, tv_dp, c->stats.ms_dp, tv_fin, tv_asm, now_ms() - t_start);
 	c->stats.ms_host = ms_host;

@@ -104,8 +104,9 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
 		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
 	for (DBuf *b : bufs) b->release();
-	c->h_res.release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
+	c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
 	for (int i = 0; i < 16; ++i) { if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]); if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); }
+	if (c->dp_up_ev) (void)hipEventDestroy(c->dp_up_ev);
 	if (c->aux_st) (void)hipStreamDestroy(c->aux_st);
 	if (c->aux_ev) (void)hipEventDestroy(c->aux_ev);
 	if (c->aux_ev2) (void)hipEventDestroy(c->aux_ev2);
