@@ -73,3 +73,4 @@ int mm355_sort_heavy_threshold(void);
 int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr, hipStream_t st);
 void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st);
 #endif
+hipError_t mm355_wait_stream(hipStream_t st);   // like hipStreamSynchronize, but the calling thread sleeps

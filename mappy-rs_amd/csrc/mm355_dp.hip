@@ -495,6 +495,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	static const bool take_turns = [] { const char *e = getenv("MM355_DP_TURNS"); return !(e && atoi(e) == 0); }();
 	std::unique_lock<std::mutex> turn(dp_turn[c->dev & 15], std::defer_lock);
 	if (take_turns) turn.lock();
+	const double t_turn0 = mm355_now_ms();
 	HIPCHK(hipMemcpyAsync(c->dp_jobs.p, jobs, n * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
 	int32_t *d_off = c->dp_work.as<int32_t>();
 	int32_t *d_ids = d_off + off_tot + 16;
@@ -543,12 +544,13 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	unsigned long long *ctr = (unsigned long long*)((char*)c->h_res.p + n * sizeof(mm355_dpres_t));   // pinned landing zone of the two counters
 	HIPCHK(hipMemcpyAsync(ctr, d_cells, 16, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	if (take_turns) turn.unlock();
+	mm355_trace_add(c, "dpk", t_turn0, mm355_now_ms());
 	const size_t n_dense = (size_t)ctr[1];
 	if (arena->ensure((n_dense + 16) * 4)) return MM355_ENOMEM;
 	if (n_dense) HIPCHK(hipMemcpyAsync(arena->p, c->dp_dense.p, n_dense * 4, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	c->stats.dp_cells = (int64_t)ctr[0]; c->stats.n_dp_jobs += (int64_t)n;
 	*res_out = (const mm355_dpres_t*)c->h_res.p; *cigar_out = (const uint32_t*)arena->p;
 	return 0;

@@ -34,8 +34,12 @@
 // mm_sketch emits minimizers in increasing position, so chunk outputs concatenated in chunk order are the sequential
 // output.  k_sketch_compact then packs the chunk outputs of a read to the front of its slot range.
 #include "mm355_sketch.h"
+// kernels whose waves are serial dependence chains (one read or one chain segment per wave): raise their issue priority inside the
+// SIMD so that they are not starved by the wide, throughput-bound extension grids of other contexts sharing the CU
+#define MM355_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(3)
 __global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
 {
+	MM355_LATENCY_KERNEL();
 	extern __shared__ mm128 ring[];   // w entries per lane, lane-interleaved
 	int t = blockIdx.x * WAVE + threadIdx.x;
 	if (t >= n_chunks) return;
@@ -252,6 +256,7 @@ struct key_hi32 { __host__ __device__ uint64_t operator()(const uint64_t &v) con
 #define MZ_STAGE 2048
 __global__ __launch_bounds__(WAVE) void k_mzflt(DevParams pr, DevBatch bt, DevSeeds sd)
 {
+	MM355_LATENCY_KERNEL();
 	__shared__ SortLds L;
 	__shared__ mm128 stage[MZ_STAGE];
 	const int r = blockIdx.x, lane = threadIdx.x;
@@ -355,6 +360,7 @@ __device__ inline void heapdown_u64(uint32_t i, uint32_t n, uint64_t *l)
 
 __global__ __launch_bounds__(WAVE) void k_seed_select(DevIndex ix, DevParams pr, DevBatch bt, DevSeeds sd)
 {
+	MM355_LATENCY_KERNEL();
 	__shared__ uint64_t heap[128];
 	const int r = blockIdx.x, lane = threadIdx.x;
 	const int n = sd.n_mz[r], qlen = bt.rlen[r];
@@ -479,6 +485,7 @@ __global__ __launch_bounds__(256) void k_seed_expand(DevIndex ix, DevParams pr, 
 #define A_STAGE 2048
 __global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors an, int *err, const int32_t *heavy_first)
 {
+	MM355_LATENCY_KERNEL();
 	__shared__ SortLds L;
 	__shared__ mm128 stage[A_STAGE];
 	const int r = heavy_first[blockIdx.x];
@@ -654,7 +661,7 @@ static int sort_heavy_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_small,
 		// counters: ctr[0] = children for the next block level (restarted per level), ctr[1] = running total of wave tasks
 		unsigned int hh[2];
 		if (hipMemcpyAsync(hh, d_ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-		if (hipStreamSynchronize(st) != hipSuccess) return -1;
+		if (mm355_wait_stream(st) != hipSuccess) return -1;
 		n_big = (int)hh[0]; h[1] += hh[1];
 		if (hipMemsetAsync(d_ctr, 0, 8, st) != hipSuccess) return -1;
 		cur ^= 1;
@@ -676,15 +683,64 @@ __global__ void k_make_heavy_tasks(DevAnchors an, const int32_t *heavy_first, in
 #define TW_SIZE 8192
 #define TW_MASK (TW_SIZE - 1)
 
+// Cross-lane scans and reductions by DPP register moves (row_shr / row_bcast): ~12 VALU operations, no LDS crossbar round trips
+// (a __shfl is a ds_bpermute, >100 cycles each -- seven of them were the longest part of a chaining step)
+#define DPP_I32(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (rmask), 0xf, false)
+__device__ inline int32_t wave_incl_scan_max(int32_t x)   // inclusive prefix max over lanes 0..lane
+{
+	int32_t y;
+	y = DPP_I32(INT32_MIN, x, 0x111, 0xf); x = x > y? x : y;   // row_shr:1
+	y = DPP_I32(INT32_MIN, x, 0x112, 0xf); x = x > y? x : y;   // row_shr:2
+	y = DPP_I32(INT32_MIN, x, 0x114, 0xf); x = x > y? x : y;   // row_shr:4
+	y = DPP_I32(INT32_MIN, x, 0x118, 0xf); x = x > y? x : y;   // row_shr:8
+	y = DPP_I32(INT32_MIN, x, 0x142, 0xa); x = x > y? x : y;   // row_bcast:15 into rows 1 and 3
+	y = DPP_I32(INT32_MIN, x, 0x143, 0xc); x = x > y? x : y;   // row_bcast:31 into rows 2 and 3
+	return x;
+}
+__device__ inline int32_t wave_incl_scan_add(int32_t x)   // inclusive prefix sum over lanes 0..lane
+{
+	x += DPP_I32(0, x, 0x111, 0xf); x += DPP_I32(0, x, 0x112, 0xf); x += DPP_I32(0, x, 0x114, 0xf); x += DPP_I32(0, x, 0x118, 0xf);
+	x += DPP_I32(0, x, 0x142, 0xa); x += DPP_I32(0, x, 0x143, 0xc);
+	return x;
+}
+__device__ inline int32_t wave_incl_scan_min(int32_t x)   // inclusive prefix minimum over lanes 0..lane
+{
+	int32_t y;
+	y = DPP_I32(INT32_MAX, x, 0x111, 0xf); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x112, 0xf); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x114, 0xf); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x118, 0xf); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x142, 0xa); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x143, 0xc); x = x < y? x : y;
+	return x;
+}
 __device__ inline int32_t wave_excl_prefix_max(int32_t v, int lane)   // exclusive prefix max over lanes, INT32_MIN identity
 {
-	int32_t x = v;
-	for (int o = 1; o < 64; o <<= 1) {
-		int32_t y = __shfl_up(x, o);
-		if (lane >= o) x = x > y? x : y;
+	(void)lane;
+	const int32_t x = wave_incl_scan_max(v);
+	return DPP_I32(INT32_MIN, x, 0x138, 0xf);   // wave_shr:1, lane 0 keeps the identity
+}
+__device__ inline int32_t wave_reduce_max(int32_t v) { return __builtin_amdgcn_readlane(wave_incl_scan_max(v), 63); }
+__device__ inline long long wave_reduce_max64(long long v)   // maximum of a 64-bit key over the wave (uniform result)
+{
+	const int ctrl[6] = { 0x111, 0x112, 0x114, 0x118, 0x142, 0x143 }, rm[6] = { 0xf, 0xf, 0xf, 0xf, 0xa, 0xc };
+#pragma unroll
+	for (int k = 0; k < 6; ++k) {
+		int lo = (int)(uint32_t)v, hi = (int)(v >> 32), ylo, yhi;
+		switch (k) {   // the builtin wants immediate control words
+		case 0: ylo = DPP_I32(0, lo, 0x111, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x111, 0xf); break;
+		case 1: ylo = DPP_I32(0, lo, 0x112, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x112, 0xf); break;
+		case 2: ylo = DPP_I32(0, lo, 0x114, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x114, 0xf); break;
+		case 3: ylo = DPP_I32(0, lo, 0x118, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x118, 0xf); break;
+		case 4: ylo = DPP_I32(0, lo, 0x142, 0xa); yhi = DPP_I32(INT32_MIN, hi, 0x142, 0xa); break;
+		default: ylo = DPP_I32(0, lo, 0x143, 0xc); yhi = DPP_I32(INT32_MIN, hi, 0x143, 0xc); break;
+		}
+		(void)ctrl; (void)rm;
+		const long long y = (long long)(((unsigned long long)(uint32_t)yhi << 32) | (uint32_t)ylo);
+		v = v > y? v : y;
 	}
-	int32_t e = __shfl_up(x, 1);
-	return lane == 0? INT32_MIN : e;
+	const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), rhi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), 63);
+	return (long long)(((unsigned long long)rhi << 32) | rlo);
 }
 
 // Chaining is independent between "segments": maximal runs of the sorted anchor array with the same strand|rid whose
@@ -737,6 +793,7 @@ __global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch b
 // one lane per short segment: the literal sequential recurrence (U:lchain.c::mg_lchain_dp)
 __global__ __launch_bounds__(256) void k_chain_small(DevParams pr, DevBatch bt, DevAnchors an, const ChainSeg *segs, unsigned int n_segs, unsigned long long *pairs_ctr)
 {
+	MM355_LATENCY_KERNEL();
 	__shared__ int32_t tl[CHAIN_SMALL][256];
 	const unsigned int sidx = blockIdx.x * 256 + threadIdx.x;
 	unsigned long long pairs = 0;
@@ -788,18 +845,26 @@ __global__ __launch_bounds__(256) void k_chain_small(DevParams pr, DevBatch bt, 
 }
 
 // one wave per long segment
+#ifndef CH_RING
+#define CH_RING 256                  // anchors (and their f/p/v) kept in LDS behind the current one
+#endif
+#define CH_RMASK (CH_RING - 1)
+#define CH_XRING 1024                // reference coordinates only (window start search): a longer ring
+#define CH_XMASK (CH_XRING - 1)
+#define CH_XNEAR (CH_XRING - 2 * WAVE)
+#define CH_NEAR (CH_RING - 2 * WAVE)    // j is served from the rings when i - j <= CH_NEAR (the a[] ring also holds one chunk ahead)
 __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, DevAnchors an, const ChainSeg *segs, unsigned int n_segs, unsigned long long *pairs_ctr)
 {
+	MM355_LATENCY_KERNEL();
 	// t[] marks of the active window, circular by anchor index: 15 bits of the marking anchor + a valid bit (a stale mark
 	// would need an index distance that is a multiple of 32768, larger than window + ring size)
 	__shared__ uint16_t tw[TW_SIZE];
-	// f/p/v of the last 64 anchors: the next anchors read them from LDS, so the loop-carried dependence never waits for a
-	// global store -> load round trip; older entries come from HBM (their stores were issued >= 64 anchors ago)
-	__shared__ int32_t rf[WAVE], rp[WAVE], rv[WAVE];
+	// The last CH_RING anchors and their f/p/v live in LDS rings: the loop-carried dependence of the chain never waits for HBM.
+	// a[] enters the ring one 64-anchor chunk ahead of the sweep (coalesced load, issued a chunk earlier); f/p/v are written by
+	// lane 0 when an anchor is finished.  Predecessors further back than CH_NEAR (repeat-dense windows) come from HBM.
+	__shared__ uint64_t rax[CH_XRING], ray[CH_RING];
+	__shared__ int32_t rf[CH_RING], rp[CH_RING], rv[CH_RING];
 #define CH_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
-#define GETF(j) ((i - (j)) <= WAVE? rf[(j) & 63] : f[j])
-#define GETP(j) ((i - (j)) <= WAVE? rp[(j) & 63] : p[j])
-#define GETV(j) ((i - (j)) <= WAVE? rv[(j) & 63] : v[j])
 	const int lane = threadIdx.x;
 	if (blockIdx.x >= n_segs) return;
 	const ChainSeg sg = segs[blockIdx.x];
@@ -818,34 +883,47 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 	if (max_dist_y < bw) max_dist_y = bw;
 	const float pen_gap = pr.pen_gap, pen_skip = pr.pen_skip;
 	for (int i = lane; i < TW_SIZE; i += WAVE) tw[i] = 0;
+	mm128 nx; nx.x = nx.y = 0;
+	if (i_begin + lane < n) nx = a[i_begin + lane];   // first chunk
 	__syncthreads();
 	int st = i_begin, max_ii = -1;
+	uint64_t max_ii_x = 0;                      // a[max_ii].x
 	unsigned long long pairs = 0;
 	for (int i = i_begin; i < n; ++i) {
-		const mm128 ai = a[i];
+		if (((i - i_begin) & (WAVE - 1)) == 0) {   // chunk boundary: publish the prefetched chunk, fetch the next one
+			if (i + lane < n) { rax[(i + lane) & CH_XMASK] = nx.x; ray[(i + lane) & CH_RMASK] = nx.y; }
+			if (i + WAVE + lane < n) nx = a[i + WAVE + lane];
+			CH_SYNC();
+		}
+		const uint64_t aix = rax[i & CH_XMASK], aiy = ray[i & CH_RMASK];
 		// advance st (U: while (st < i && (other rid/strand || too far)) ++st)
 		for (;;) {
 			int idx = st + lane;
 			bool c = false;
-			if (idx < i) { uint64_t xs = a[idx].x; c = (ai.x >> 32 != xs >> 32) || ai.x > xs + (uint64_t)(int64_t)max_dist_x; }
+			if (idx < i) {
+				const uint64_t xs = (i - st <= CH_XNEAR)? rax[idx & CH_XMASK] : a[idx].x;
+				c = (aix >> 32 != xs >> 32) || aix > xs + (uint64_t)(int64_t)max_dist_x;
+			}
 			unsigned long long m = __ballot(c);
 			if (m == ~0ULL) { st += 64; continue; }
 			st += __builtin_ctzll(~m);
 			break;
 		}
 		if (i - st > max_iter) st = i - max_iter;
-		int32_t max_f = (int32_t)(ai.y >> 32 & 0xff), max_j = -1, n_skip = 0;
+		int32_t max_f = (int32_t)(aiy >> 32 & 0xff), max_j = -1, n_skip = 0;
 		int end_j = st - 1;
 		const uint16_t mark = (uint16_t)((i & 0x7fff) | 0x8000);
 		for (int jb = i - 1; jb >= st; jb -= WAVE) {
 			const int j = jb - lane;
 			const bool active = j >= st;
+			const bool near_ = i - (jb - (WAVE - 1)) <= CH_NEAR;   // the whole batch is inside the rings
 			int32_t sc = MM355_SC_NONE, pj = -1;
-			if (jb != i - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // older f/p come from HBM: their stores have landed
+			if (!near_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // older f/p come from HBM: their stores have landed
 			if (active) {
-				const mm128 aj = a[j];
-				sc = mm_comput_sc(ai.x, ai.y, aj.x, aj.y, max_dist_x, max_dist_y, bw, pen_gap, pen_skip);
-				if (sc != MM355_SC_NONE) { sc += GETF(j); pj = GETP(j); }
+				uint64_t ajx, ajy;
+				if (near_) { ajx = rax[j & CH_XMASK]; ajy = ray[j & CH_RMASK]; } else { const mm128 aj = a[j]; ajx = aj.x; ajy = aj.y; }
+				sc = mm_comput_sc(aix, aiy, ajx, ajy, max_dist_x, max_dist_y, bw, pen_gap, pen_skip);
+				if (sc != MM355_SC_NONE) { sc += near_? rf[j & CH_RMASK] : f[j]; pj = near_? rp[j & CH_RMASK] : p[j]; }
 			}
 			const bool valid = sc != MM355_SC_NONE;
 			pairs += __popcll(__ballot(active));
@@ -856,19 +934,21 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 			int32_t pm = wave_excl_prefix_max(scv, lane);
 			pm = pm > max_f? pm : max_f;
 			const bool improved = valid && sc > pm;
-			unsigned long long imask = __ballot(improved), mmask = __ballot(marked && !improved);
-			unsigned long long ev = imask | mmask;
+			// n_skip over the lanes in scan order: +1 on a marked lane, -1 (not below 0) on an improving one; the scan stops at the
+			// first marked lane that lifts it above max_skip.  A walk reflected at 0 has the closed form c_k = S_k - min(0, min_{m<=k} S_m)
+			// with S the plain prefix sums (Lindley), so two DPP scans replace the lane-by-lane replay -- in a co-linear chain nearly
+			// every lane is marked and the replay was ~10 scalar instructions per lane.
+			const int32_t dstep = improved? -1 : marked? 1 : 0;
+			const int32_t S = n_skip + wave_incl_scan_add(dstep);
+			const int32_t m0 = wave_incl_scan_min(S);
+			const int32_t ck = S - (m0 < 0? m0 : 0);
+			const unsigned long long bmask = __ballot(dstep == 1 && ck > max_skip);
 			int brk = -1;
-			while (ev) {   // wave-uniform replay of the n_skip counter over the event lanes
-				int l = __builtin_ctzll(ev);
-				ev &= ev - 1;
-				if (imask >> l & 1) { if (n_skip > 0) --n_skip; }
-				else if (++n_skip > max_skip) { brk = l; break; }
-			}
+			if (bmask) brk = __builtin_ctzll(bmask);
+			else n_skip = __builtin_amdgcn_readlane(ck, 63);
 			const bool considered = brk < 0 || lane <= brk;
 			int32_t cv = (valid && considered)? sc : INT32_MIN;
-			int32_t cmax = cv;
-			for (int of = 32; of > 0; of >>= 1) { int32_t y2 = __shfl_xor(cmax, of); cmax = cmax > y2? cmax : y2; }
+			const int32_t cmax = wave_reduce_max(cv);
 			if (cmax > max_f) {
 				unsigned long long w = __ballot(cv == cmax);
 				int wl = __builtin_ctzll(w);   // lowest lane = highest j = first met by the sequential scan
@@ -879,38 +959,45 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 		}
 		// max_ii rescue
 		bool need = max_ii < 0;
-		if (!need) need = ai.x - a[max_ii].x > (uint64_t)(int64_t)max_dist_x;
+		if (!need) need = aix - max_ii_x > (uint64_t)(int64_t)max_dist_x;
 		if (need) {
 			int32_t bf = INT32_MIN, bj = -1;
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			for (int j = i - 1 - lane; j >= st; j -= WAVE) { int32_t fj = GETF(j); if (bf < fj) bf = fj, bj = j; }
-			for (int of = 32; of > 0; of >>= 1) {
-				int32_t of_f = __shfl_xor(bf, of), of_j = __shfl_xor(bj, of);
-				if (of_f > bf || (of_f == bf && of_j > bj)) bf = of_f, bj = of_j;
-			}
-			max_ii = bj;
+			const bool near_ = i - st <= CH_NEAR;
+			if (!near_) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			for (int j = i - 1 - lane; j >= st; j -= WAVE) { int32_t fj = near_? rf[j & CH_RMASK] : f[j]; if (bf < fj) bf = fj, bj = j; }
+			// best f, ties -> larger j: one 64-bit key (f in the high word, j >= -1 biased to be non-negative in the low word)
+			const long long best = wave_reduce_max64((long long)(((unsigned long long)(uint32_t)bf << 32) | (uint32_t)(bj + 1)));
+			max_ii = (int)(uint32_t)best - 1;
+			if (max_ii >= 0) max_ii_x = (i - max_ii <= CH_XNEAR)? rax[max_ii & CH_XMASK] : a[max_ii].x;
 		}
 		if (max_ii >= 0 && max_ii < end_j) {
-			const mm128 am = a[max_ii];
-			int32_t tmp = mm_comput_sc(ai.x, ai.y, am.x, am.y, max_dist_x, max_dist_y, bw, pen_gap, pen_skip);
-			if (tmp != MM355_SC_NONE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); int32_t fm = GETF(max_ii); if (max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii; }
+			const bool near_ = i - max_ii <= CH_NEAR;
+			uint64_t amx, amy;
+			if (near_) { amx = rax[max_ii & CH_XMASK]; amy = ray[max_ii & CH_RMASK]; } else { const mm128 am = a[max_ii]; amx = am.x; amy = am.y; }
+			int32_t tmp = mm_comput_sc(aix, aiy, amx, amy, max_dist_x, max_dist_y, bw, pen_gap, pen_skip);
+			if (tmp != MM355_SC_NONE) {
+				int32_t fm;
+				if (near_) fm = rf[max_ii & CH_RMASK]; else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fm = f[max_ii]; }
+				if (max_f < tmp + fm) max_f = tmp + fm, max_j = max_ii;
+			}
 		}
 		int32_t vi = max_f;
-		if (max_j >= 0) { if (i - max_j > WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); int32_t vm = GETV(max_j); if (vm > max_f) vi = vm; }
-		if (max_ii < 0) max_ii = i;
-		else {
-			uint64_t d = ai.x - a[max_ii].x;
-			if (i - max_ii > WAVE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			int32_t fm = GETF(max_ii);
-			if (d <= (uint64_t)(int64_t)max_dist_x && fm < max_f) max_ii = i;
+		if (max_j >= 0) {
+			int32_t vm;
+			if (i - max_j <= CH_NEAR) vm = rv[max_j & CH_RMASK]; else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); vm = v[max_j]; }
+			if (vm > max_f) vi = vm;
 		}
-		CH_SYNC();   // every lane has finished reading ring slot (i & 63) (it held anchor i-64)
-		if (lane == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; rf[i & 63] = max_f; rp[i & 63] = max_j; rv[i & 63] = vi; }
+		if (max_ii < 0) { max_ii = i; max_ii_x = aix; }
+		else {
+			const uint64_t d = aix - max_ii_x;
+			int32_t fm;
+			if (i - max_ii <= CH_NEAR) fm = rf[max_ii & CH_RMASK]; else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); fm = f[max_ii]; }
+			if (d <= (uint64_t)(int64_t)max_dist_x && fm < max_f) { max_ii = i; max_ii_x = aix; }
+		}
+		CH_SYNC();   // every lane has finished reading the ring slots this anchor overwrites
+		if (lane == 0) { f[i] = max_f; p[i] = max_j; v[i] = vi; rf[i & CH_RMASK] = max_f; rp[i & CH_RMASK] = max_j; rv[i & CH_RMASK] = vi; }
 		CH_SYNC();
 	}
-#undef GETF
-#undef GETP
-#undef GETV
 #undef CH_SYNC
 	if (lane == 0 && pairs) atomicAdd(pairs_ctr, pairs);
 }
@@ -919,6 +1006,7 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 #define Z_STAGE 4096
 __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, DevAnchors an, int *err, const int32_t *heavy_first)
 {
+	MM355_LATENCY_KERNEL();
 	__shared__ SortLds L;
 	__shared__ uint64_t zstage[Z_STAGE];
 	const int r = heavy_first[blockIdx.x], lane = threadIdx.x;
@@ -1084,7 +1172,7 @@ int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, 
 	hipLaunchKernelGGL(k_chain_segments, dim3(bt.n_reads), dim3(256), 0, st, pr, bt, an, (ChainSeg*)seg_small, (ChainSeg*)seg_big, ctr, CHAIN_SMALL);
 	unsigned int h[2] = {0, 0};
 	if (hipMemcpyAsync(h, ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-	if (hipStreamSynchronize(st) != hipSuccess) return -1;
+	if (mm355_wait_stream(st) != hipSuccess) return -1;
 	if (h[1]) hipLaunchKernelGGL(k_chain_big, dim3(h[1]), dim3(WAVE), 0, st, pr, bt, an, (const ChainSeg*)seg_big, h[1], pairs);
 	if (h[0]) hipLaunchKernelGGL(k_chain_small, dim3((h[0] + 255) / 256), dim3(256), 0, st, pr, bt, an, (const ChainSeg*)seg_small, h[0], pairs);
 	return 0;

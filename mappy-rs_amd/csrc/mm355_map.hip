@@ -96,13 +96,27 @@ static void trace_dump()
 	for (const TraceEv &e : g_trace) fprintf(fp, "%p\t%s\t%.3f\t%.3f\n", e.ctx, e.phase, e.t0, e.t1);
 	fclose(fp);
 }
-static void trace_add(const void *ctx, const char *phase, double t0, double t1)
+void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1)
 {
 	if (!g_trace_path) return;
 	std::lock_guard<std::mutex> lk(g_trace_mu);
 	if (g_trace.empty()) atexit(trace_dump);
 	g_trace.push_back(TraceEv{ctx, phase, t0, t1});
 }
+static void trace_add(const void *ctx, const char *phase, double t0, double t1) { mm355_trace_add(ctx, phase, t0, t1); }
+hipError_t mm355_wait_stream(hipStream_t st)
+{
+	static const bool spin = [] { const char *e = getenv("MM355_SPIN_WAIT"); return e && atoi(e) != 0; }();
+	if (spin) return hipStreamSynchronize(st);
+	static thread_local hipEvent_t ev = 0;   // one per calling thread (leaked with it); valid for any stream of the current device
+	static thread_local int ev_dev = -1;
+	int dev = 0; (void)hipGetDevice(&dev);
+	if (ev == 0 || ev_dev != dev) { hipError_t e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming); if (e != hipSuccess) return e; ev_dev = dev; }
+	hipError_t e = hipEventRecord(ev, st);
+	if (e != hipSuccess) return e;
+	return hipEventSynchronize(ev);
+}
+double mm355_now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static int host_threads() { return HostPool::get().size(); }
@@ -269,7 +283,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		if (tu) HIPCHK(hipMemcpyAsync(pu, d_pu, (size_t)tu * 8, hipMemcpyDeviceToHost, c->st));
 		if (tv) HIPCHK(hipMemcpyAsync(pa, d_pa, (size_t)tv * 16, hipMemcpyDeviceToHost, c->st));
 		if (tm) HIPCHK(hipMemcpyAsync(pm, d_pm, (size_t)tm * 8, hipMemcpyDeviceToHost, c->st));
-		HIPCHK(hipStreamSynchronize(c->st));
+		HIPCHK(mm355_wait_stream(c->st));
 	}
 	tv_pack = now_ms() - tv0; trace_add(c, "pack", tv0, now_ms()); tv0 = now_ms();
 	const double t_host0 = now_ms();

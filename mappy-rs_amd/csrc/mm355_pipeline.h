@@ -86,3 +86,7 @@ struct EvTimer {
 typedef EvTimer EvTimer2;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)
+
+hipError_t mm355_wait_stream(hipStream_t st);   // like hipStreamSynchronize, but the calling thread sleeps (MM355_SPIN_WAIT=1: spins)
+void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1);   // MM355_TRACE timeline (no-op when unset)
+double mm355_now_ms();

@@ -185,7 +185,7 @@ int mm355_run_pack(mm355_ctx *c, int64_t n_reads, const char *const *seqs, const
 			HIPCHK(hipMemcpyAsync(c->ck_start.p, cst.data(), nc * 4, hipMemcpyHostToDevice, c->st));
 		}
 		HIPCHK(hipMemcpyAsync(c->ck_r0.p, r0.data(), nr * 8, hipMemcpyHostToDevice, c->st));
-		HIPCHK(hipStreamSynchronize(c->st));   // the staging vectors above are about to go out of scope
+		HIPCHK(mm355_wait_stream(c->st));   // the staging vectors above are about to go out of scope
 	}
 	return 0;
 }
@@ -218,7 +218,7 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 	}
 	unsigned long long ctr[8];
 	HIPCHK(hipMemcpyAsync(ctr, c->counters.p, 64, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	int64_t tot = 0, tmz = 0;
 	for (int64_t i = 0; i < n; ++i) { hb.aoff[i] = tot; tot += hb.n_a[i]; tmz += hb.n_mz[i]; }
 	hb.aoff[n] = tot; hb.tot_a = tot;
@@ -236,7 +236,7 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 		for (int64_t i = 0; i < n && hb.n_a[hv[i]] > mm355_sort_heavy_threshold(); ++i) ++c->n_heavy;
 		if (c->heavy.ensure((size_t)(n + 1) * 4)) return MM355_ENOMEM;
 		if (n) HIPCHK(hipMemcpyAsync(c->heavy.p, hv.data(), n * 4, hipMemcpyHostToDevice, c->st));
-		HIPCHK(hipStreamSynchronize(c->st));
+		HIPCHK(mm355_wait_stream(c->st));
 	}
 	return 0;
 }
@@ -253,7 +253,7 @@ static int check_err(mm355_ctx *c)
 {
 	int e[4] = {0,0,0,0};
 	HIPCHK(hipMemcpyAsync(e, c->err.p, 16, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	return e[0]? MM355_ENOMEM : 0;
 }
 
@@ -282,7 +282,7 @@ int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
 	HIPCHK(hipGetLastError());
 	unsigned long long pairs = 0;
 	HIPCHK(hipMemcpyAsync(&pairs, c->counters.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	c->stats.chain_pairs = (int64_t)pairs;
 	return 0;
 }
@@ -318,14 +318,14 @@ extern "C" int mm355_stage_sketch(mm355_ctx_t *c, int64_t n_reads, const char *c
 	if ((rc = mm355_run_sketch(c))) return rc;
 	std::vector<int32_t> n_mz(n_reads);
 	if (n_reads) HIPCHK(hipMemcpyAsync(n_mz.data(), c->n_mz.p, n_reads * 4, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	int64_t tot = 0;
 	for (int64_t i = 0; i < n_reads; ++i) { mz_off[i] = tot; tot += n_mz[i]; }
 	mz_off[n_reads] = tot;
 	if (tot > mz_cap) return MM355_ENOMEM;
 	for (int64_t i = 0; i < n_reads; ++i)
 		if (n_mz[i]) HIPCHK(hipMemcpyAsync(mz + mz_off[i] * 2, c->mz.as<mm128>() + c->hb.roff[i], (size_t)n_mz[i] * 16, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	return 0;
 }
 
@@ -342,7 +342,7 @@ extern "C" int mm355_stage_anchors(mm355_ctx_t *c, const mm355_mapopt_t *mo, int
 	for (int64_t i = 0; i <= n_reads; ++i) a_off[i] = hb.aoff[i];
 	if (hb.tot_a > a_cap) return MM355_ENOMEM;
 	if (hb.tot_a) HIPCHK(hipMemcpyAsync(a, c->a.p, (size_t)hb.tot_a * 16, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	for (int64_t i = 0; i < n_reads; ++i) { if (rep_len) rep_len[i] = hb.rep_len[i]; if (n_mini_pos) n_mini_pos[i] = hb.n_mini[i]; }
 	return 0;
 }
@@ -366,7 +366,7 @@ extern "C" int mm355_stage_chain(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64
 		HIPCHK(hipMemcpyAsync(p, c->p.p, (size_t)hb.tot_a * 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipMemcpyAsync(v, c->v.p, (size_t)hb.tot_a * 4, hipMemcpyDeviceToHost, c->st));
 	}
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	return 0;
 }
 
@@ -390,6 +390,6 @@ extern "C" int mm355_stage_chains(mm355_ctx_t *c, const mm355_mapopt_t *mo, int6
 		if (hb.n_u[i]) HIPCHK(hipMemcpyAsync(u + u_off[i], c->u.as<uint64_t>() + hb.aoff[i], (size_t)hb.n_u[i] * 8, hipMemcpyDeviceToHost, c->st));
 		if (hb.n_v[i]) HIPCHK(hipMemcpyAsync(a + a_off[i] * 2, c->a.as<mm128>() + hb.aoff[i], (size_t)hb.n_v[i] * 16, hipMemcpyDeviceToHost, c->st));
 	}
-	HIPCHK(hipStreamSynchronize(c->st));
+	HIPCHK(mm355_wait_stream(c->st));
 	return 0;
 }
