@@ -27,6 +27,9 @@ sys.path.insert(0, os.path.join(ROOT, "mappy-rs_amd"))
 
 import numpy as np
 
+# HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 corrections of
+# MI355X_MICROARCH.md applied); measured on the default workload's sub-batch, see profiles/README.md.  None = not measured.
+PMC_TRAFFIC = {"k_ksw_reg<2, false>": 6.18e9}   # default workload, 4096-read sub-batch: WRITE_SIZE 6.020 GB + 2 x FETCH_SIZE 0.078 GB
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured streaming copy)
 
 
@@ -106,9 +109,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ecoli")
-    ap.add_argument("--reads", type=int, default=16384, help="reads per step per GPU")
-    ap.add_argument("--streams", type=int, default=4, help="concurrent contexts (HIP streams) per GPU")
-    ap.add_argument("--depth", type=int, default=1, help="sub-batches each stream maps one after the other within a step")
+    ap.add_argument("--reads", type=int, default=49152, help="reads per step per GPU")
+    ap.add_argument("--streams", type=int, default=6, help="host threads per GPU, each driving its own contexts (HIP streams + buffers)")
+    ap.add_argument("--depth", type=int, default=2, help="sub-batches each stream maps one after the other within a step")
     ap.add_argument("--scale", type=float, default=1.0, help="genome scale of the human workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -195,10 +198,12 @@ def main():
 
     def step():
         res = [r for part in pool.map(step_thread, range(n_thr)) for r in part]
-        agg_st = _ffi.Stats()
+        agg_st = {}
         for _a, _h, st in res:
             for k, _t in _ffi.Stats._fields_:
-                setattr(agg_st, k, getattr(agg_st, k) + getattr(st, k))
+                v = getattr(st, k)
+                v = np.array(list(v), dtype=np.float64) if hasattr(v, "__len__") else v
+                agg_st[k] = agg_st.get(k, 0) + v
         return sum(r[0] for r in res), sum(r[1] for r in res), agg_st
 
     def barrier():
@@ -215,7 +220,7 @@ def main():
         aligned, n_hits, st = step()
         aligned_tot += aligned
         for k, _t in _ffi.Stats._fields_:
-            agg[k] = agg.get(k, 0) + getattr(st, k)
+            agg[k] = agg.get(k, 0) + st[k]
     barrier()
     dt = time.perf_counter() - t0
     dt, aligned_all, bases_all = aggregate(dist, dt, aligned_tot, n_bases * args.steps)
@@ -242,17 +247,28 @@ def main():
         seed_ms = kern_ms["seed_lookup"] + kern_ms["seed_expand"]
         dp_bytes = cells                                                   # 1 B/cell direction matrix written to HBM
         chain_bytes = 36 * n_a
-        cand = {
-            "k_ksw_extd2": (dp_bytes, kern_ms["dp"], "1 B/cell backtrack write x %.3g cells per launch group" % cells),
-            "k_seed_lookup+k_seed_expand": (seed_bytes, seed_ms, "16*n_mz+16*n_hit+8*n_a_multi+16*n_a"),
-            "k_chain": (chain_bytes, kern_ms["chain"], "16*n_a read + 20*n_a written"),
+        n_ldp = max(1.0, agg["n_launch_dp"] / K)          # extension launch groups per step (one per sub-batch and round)
+        # the extension kernel that takes the most time, timed alone with HIP events on its own stream (group = 2 * size class + exact)
+        gnames = ["k_ksw_reg<%d, %s>" % (np_, ex) for np_ in (1, 2, 4, 8) for ex in ("false", "true")] + \
+                 ["k_ksw_extd2<512> (lds 4096, %s)" % m for m in ("approx", "exact")] + ["k_ksw_extd2<512> (lds 12288, %s)" % m for m in ("approx", "exact")] + \
+                 ["k_ksw_extd2<512> (hbm state, %s)" % m for m in ("approx", "exact")] + ["-", "-"]
+        gi = int(np.argmax(agg["ms_dp_group"]))
+        g_ms, g_cells, g_nl = agg["ms_dp_group"][gi] / K, agg["dp_cells_group"][gi] / K, max(1.0, agg["n_launch_group"][gi] / K)
+        n_lfront = float(n_str)                            # one launch of every front kernel per sub-batch
+        cand = {   # name: (algorithmic bytes per step, summed kernel ms per step, launches per step, formula)
+            gnames[gi]: (g_cells, g_ms, g_nl, "1 B/cell direction matrix written to HBM, %.4g cells per launch (HIP events on the kernel's own stream)" % (g_cells / g_nl)),
+            "extension launch group": (dp_bytes, kern_ms["dp"], n_ldp, "1 B/cell x %.4g cells per group = all k_ksw_reg<NP,exact> / k_ksw_extd2 size classes "
+                                       "on their streams + k_ksw_backtrack; one HIP-event pair around the group" % (cells / n_ldp)),
+            "k_seed_lookup+k_seed_expand": (seed_bytes, seed_ms, n_lfront, "16*n_mz+16*n_hit+8*n_a_multi+16*n_a"),
+            "k_chain": (chain_bytes, kern_ms["chain"], n_lfront, "16*n_a read + 20*n_a written"),
         }
-        dom = max(cand, key=lambda k: cand[k][1])
+        dom = gnames[gi]
         roof = {}
-        for k, (b, ms, how) in cand.items():
-            ach = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        for k, (b, ms, nl, how) in cand.items():
+            ach = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0     # bytes per launch / average launch duration (ratio of the per-step sums)
             roof[k] = dict(bound="hbm", achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
-                           traffic=None, kernel=k, ms_per_launch=round(ms, 4), algorithmic_bytes=int(b), formula=how)
+                           traffic=(PMC_TRAFFIC.get(k) if args.workload == "ecoli" and len(reads) // n_str == 4096 else None), kernel=k, launches_per_step=round(nl, 2), ms_per_launch=round(ms / nl, 4),
+                           algorithmic_bytes=int(b / nl), formula=how)
         out = {
             "metric": "aligned Mbases/sec, synthetic ONT reads, map-ont, MI355X",
             "value": round(aligned_all / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
@@ -263,6 +279,7 @@ def main():
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
             "pcie_inclusive_mbases_per_s": round(n_bases / dt_pcie / 1e6, 3),
             "roofline": roof[dom], "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
+            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(14) if agg["n_launch_group"][i] > 0},
             "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
                                       n_dp_jobs=int(agg["n_dp_jobs"] / K)),
         }

@@ -139,6 +139,11 @@ typedef struct {
 	double ms_sketch, ms_seed, ms_sort, ms_chain, ms_backtrack, ms_dp, ms_host, ms_total;
 	double ms_seed_lookup, ms_seed_expand;
 	int64_t n_launch_seed;
+	int64_t n_launch_dp;                         /* extension launch groups (one per round and HBM-budget chunk) */
+	/* per extension kernel of a launch group, timed with HIP events on the stream it is launched on; group = 2 * size class + exact,
+	 * size classes: targets <= 128, 256, 512, 1024 (k_ksw_reg<1|2|4|8, exact>), <= 4096, <= 12288, larger (k_ksw_extd2<512>) */
+	double ms_dp_group[16];
+	int64_t dp_cells_group[16], n_launch_group[16];
 } mm355_stats_t;
 
 /* sketch: minimizers of each read (mm_sketch). mz_off[n_reads+1] host array is filled; mz = (x,y) pairs */

@@ -503,6 +503,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	int32_t *d_H = (int32_t*)(d_S + st_tot + 8);
 	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4, *d_dense = c->counters.as<unsigned long long>() + 5;
 	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
+	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + 8;   // cells per group [16]
+	HIPCHK(hipMemsetAsync(d_cells, 0, 8, c->st));
+	HIPCHK(hipMemsetAsync(d_gcells, 0, 128, c->st));
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
 		// every group gets its own HIP stream: the few long alignments of the big classes run concurrently with the thousands of
@@ -516,22 +519,27 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			const DpClass &k = classes[g >> 1];
 			if (c->dp_st[g] == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[g], hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[g], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming)); }
 			HIPCHK(hipStreamWaitEvent(c->dp_st[g], c->dp_up_ev, 0));
+			if (c->dp_ev0[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev0[g]));
+			if (c->dp_ev1[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev1[g]));
+			HIPCHK(hipEventRecord(c->dp_ev0[g], c->dp_st[g]));
+			unsigned long long *gc = d_gcells + g;
 			const unsigned nj = (unsigned)n_grp[g];
 			const int32_t *gid = d_ids + grp_off[g];
 			const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();
 			mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
 			if (k.kind == 0) {
 				const bool ex = g & 1;
-				if (k.np == 1) launch_reg<1>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_cells);
-				else if (k.np == 2) launch_reg<2>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_cells);
-				else if (k.np == 4) launch_reg<4>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_cells);
-				else launch_reg<8>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_cells);
+				if (k.np == 1) launch_reg<1>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
+				else if (k.np == 2) launch_reg<2>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
+				else if (k.np == 4) launch_reg<4>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
+				else launch_reg<8>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
 			} else if (k.kind == 1)
 				hipLaunchKernelGGL(k_ksw_extd2<64>, dim3(nj), dim3(64), (size_t)k.cap * 12, c->dp_st[g], dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
-				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
+				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense);
 			else
 				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3(nj), dim3(512), (size_t)k.cap * 12, c->dp_st[g], dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
-				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, d_cells, c->dp_dense.as<uint32_t>(), d_dense);
+				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense);
+			HIPCHK(hipEventRecord(c->dp_ev1[g], c->dp_st[g]));
 			HIPCHK(hipEventRecord(c->dp_ev[g], c->dp_st[g]));
 			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		}
@@ -540,9 +548,10 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
 	}
 	HIPCHK(hipGetLastError());
-	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 64)) return MM355_ENOMEM;
-	unsigned long long *ctr = (unsigned long long*)((char*)c->h_res.p + n * sizeof(mm355_dpres_t));   // pinned landing zone of the two counters
+	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 256)) return MM355_ENOMEM;
+	unsigned long long *ctr = (unsigned long long*)((char*)c->h_res.p + n * sizeof(mm355_dpres_t));   // pinned landing zone of the counters
 	HIPCHK(hipMemcpyAsync(ctr, d_cells, 16, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, 128, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
 	if (take_turns) turn.unlock();
@@ -551,7 +560,17 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	if (arena->ensure((n_dense + 16) * 4)) return MM355_ENOMEM;
 	if (n_dense) HIPCHK(hipMemcpyAsync(arena->p, c->dp_dense.p, n_dense * 4, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
-	c->stats.dp_cells = (int64_t)ctr[0]; c->stats.n_dp_jobs += (int64_t)n;
+	{
+		int64_t tot = 0;
+		for (int g = 0; g < DP_N_GROUP; ++g) {
+			if (n_grp[g] == 0) continue;
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, c->dp_ev0[g], c->dp_ev1[g]) == hipSuccess) c->stats.ms_dp_group[g] += ms;
+			c->stats.dp_cells_group[g] += (int64_t)ctr[2 + g]; ++c->stats.n_launch_group[g];
+			tot += (int64_t)ctr[2 + g];
+		}
+		c->stats.dp_cells += tot; c->stats.n_dp_jobs += (int64_t)n; ++c->stats.n_launch_dp;
+	}
 	*res_out = (const mm355_dpres_t*)c->h_res.p; *cigar_out = (const uint32_t*)arena->p;
 	return 0;
 }
@@ -586,7 +605,7 @@ extern "C" int mm355_stage_dp(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t 
 	if (c == 0 || mo == 0) return MM355_EINVAL;
 	HIPCHK(hipSetDevice(c->dev));
 	memset(&c->stats, 0, sizeof(c->stats));
-	HIPCHK(hipMemsetAsync(c->counters.p, 0, 64, c->st));
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, 256, c->st));
 	if (c->dp_q.ensure((size_t)n_q + 64) || c->dp_t.ensure((size_t)n_t + 64)) return MM355_ENOMEM;
 	if (n_q) HIPCHK(hipMemcpyAsync(c->dp_q.p, qcodes, n_q, hipMemcpyHostToDevice, c->st));
 	if (n_t) HIPCHK(hipMemcpyAsync(c->dp_t.p, tcodes, n_t, hipMemcpyHostToDevice, c->st));

@@ -60,7 +60,7 @@ struct mm355_ctx {
 	DBuf rq;       // per-read query codes fwd|rev
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
-	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[16] = {};
+	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[16] = {}, dp_ev0[16] = {}, dp_ev1[16] = {};
 	HostBatch hb;
 };
 

@@ -72,7 +72,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		c->dix.pos = (const uint64_t*)mi->d_pos; c->dix.S = (const uint32_t*)mi->d_S;
 		c->dix.seq_off = c->ix_off.as<uint64_t>(); c->dix.seq_len = c->ix_len.as<uint32_t>();
 		c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
-		if (c->counters.ensure(64) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
+		if (c->counters.ensure(256) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
 		memset(&c->stats, 0, sizeof(c->stats));
 		*out = c;
 		return 0;
@@ -89,7 +89,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	c->dix.pos = c->ix_pos.as<uint64_t>(); c->dix.S = c->ix_S.as<uint32_t>();
 	c->dix.seq_off = c->ix_off.as<uint64_t>(); c->dix.seq_len = c->ix_len.as<uint32_t>();
 	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
-	if (c->counters.ensure(64) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
+	if (c->counters.ensure(256) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
 	memset(&c->stats, 0, sizeof(c->stats));
 	*out = c;
 	return 0;
@@ -105,7 +105,7 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
 	for (DBuf *b : bufs) b->release();
 	c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
-	for (int i = 0; i < 16; ++i) { if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]); if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); }
+	for (int i = 0; i < 16; ++i) { if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]); if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); if (c->dp_ev0[i]) (void)hipEventDestroy(c->dp_ev0[i]); if (c->dp_ev1[i]) (void)hipEventDestroy(c->dp_ev1[i]); }
 	if (c->dp_up_ev) (void)hipEventDestroy(c->dp_up_ev);
 	if (c->aux_st) (void)hipStreamDestroy(c->aux_st);
 	if (c->aux_ev) (void)hipEventDestroy(c->aux_ev);
@@ -168,7 +168,7 @@ int mm355_run_pack(mm355_ctx *c, int64_t n_reads, const char *const *seqs, const
 		HIPCHK(hipMemcpyAsync(c->rlen.p, hb.rlen.data(), n_reads * 4, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipMemcpyAsync(c->order.p, hb.order.data(), n_reads * 4, hipMemcpyHostToDevice, c->st));
 	}
-	HIPCHK(hipMemsetAsync(c->counters.p, 0, 64, c->st));
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, 256, c->st));
 	HIPCHK(hipMemsetAsync(c->err.p, 0, 16, c->st));
 	c->stats.n_reads = n_reads; c->stats.n_bases = bases;
 	{   // chunk table of the sketch kernel: longest reads first so that a wave holds chunks of similar cost
