@@ -1385,10 +1385,29 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 			bool ok = want(T, sa, read_id, task_id, reqs, qe_run - qs_run, re_run - rs_run, qs_run, rev, (uint32_t)rid, rs_run, 0, bw1, opt->zdrop, -1, EZ_APPROX_MAX);
 			if (!ok) { complete = false; rs_run = re_run, qs_run = qe_run; continue; }   // speculate: not dropped
 			EzRes *e = &RES(sa);
-			tseq.resize((size_t)(re_run - rs_run) + 1);
-			{ ProfScope pf(PF_GETSEQ); getseq(mi, (uint32_t)rid, rs_run, re_run, tseq.data()); }
-			const uint8_t *qseq = rs.qc[rev].data() + qs_run;
-			{ ProfScope pf(PF_TEST_ZDROP); zdrop_code = test_zdrop(opt, qseq, tseq.data(), e->cigar, e->n_cigar, mat); }
+			// U:align.c::mm_test_zdrop walks the path and returns 0 unless some score drop along it exceeds zdrop (or zdrop_inv).
+			// A gap fill is a full-matrix global alignment (bw1 covers it), so e->score is the score of the path in the CIGAR:
+			// a*M - score - (two-piece gap costs) = everything the matched columns lose, and no drop can exceed that loss plus the
+			// one-piece gap costs the test itself charges.  If that bound is within both thresholds the walk is skipped.
+			bool quiet = false;
+			if (!e->zdropped && e->score > -0x20000000 && e->n_cigar > 0) {
+				int64_t M = 0, G1 = 0, G2 = 0;
+				for (int k = 0; k < e->n_cigar; ++k) {
+					const int64_t op = e->cigar[k] & 0xf, len = e->cigar[k] >> 4;
+					if (op == 0) M += len;
+					else if (op == 1 || op == 2) { const int64_t c1 = opt->q + (int64_t)opt->e * len, c2 = opt->q2 + (int64_t)opt->e2 * len; G1 += c1; G2 += c1 < c2? c1 : c2; }
+					else { M = -1; break; }
+				}
+				const int64_t loss = M >= 0? (int64_t)opt->a * M - G2 - e->score : -1;
+				const int64_t lim = opt->zdrop < opt->zdrop_inv? opt->zdrop : opt->zdrop_inv;
+				quiet = M >= 0 && loss >= 0 && loss + G1 <= lim;
+			}
+			if (!quiet) {
+				tseq.resize((size_t)(re_run - rs_run) + 1);
+				{ ProfScope pf(PF_GETSEQ); getseq(mi, (uint32_t)rid, rs_run, re_run, tseq.data()); }
+				const uint8_t *qseq = rs.qc[rev].data() + qs_run;
+				{ ProfScope pf(PF_TEST_ZDROP); zdrop_code = test_zdrop(opt, qseq, tseq.data(), e->cigar, e->n_cigar, mat); }
+			}
 			if (zdrop_code != 0) {
 				ok = want(T, se, read_id, task_id, reqs, qe_run - qs_run, re_run - rs_run, qs_run, rev, (uint32_t)rid, rs_run, 0, bw1,
 				          zdrop_code == 2? opt->zdrop_inv : opt->zdrop, -1, 0);
