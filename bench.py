@@ -109,9 +109,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ecoli")
-    ap.add_argument("--reads", type=int, default=49152, help="reads per step per GPU")
-    ap.add_argument("--streams", type=int, default=6, help="host threads per GPU, each driving its own contexts (HIP streams + buffers)")
-    ap.add_argument("--depth", type=int, default=2, help="sub-batches each stream maps one after the other within a step")
+    ap.add_argument("--reads", type=int, default=262144, help="reads per step per GPU")
+    ap.add_argument("--streams", type=int, default=8, help="host threads per GPU, each driving its own contexts (HIP streams + buffers)")
+    ap.add_argument("--depth", type=int, default=8, help="sub-batches each stream maps one after the other within a step")
     ap.add_argument("--scale", type=float, default=1.0, help="genome scale of the human workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -160,24 +160,30 @@ def main():
     # `--streams S`: S contexts (own HIP stream + buffers) on this GPU, each with 1/S of the step's reads resident in HBM;
     # a step maps all of them concurrently from S host threads, so the host tail of one sub-batch overlaps kernels of another.
     n_thr = max(1, args.streams)
-    n_str = n_thr * max(1, args.depth)
+    depth = max(1, args.depth)
+    n_str = n_thr * depth                 # sub-batches per step
+    # one context (own HIP streams + working buffers) per host thread; every context holds `depth` sub-batches resident in HBM
+    # (mm355_batch_select) and maps them one after the other within a step.
     ctxs, parts = [], []
-    for si in range(n_str):
+    for ti in range(n_thr):
         ctx = C.c_void_p()
         _ffi.check(L.mm355_ctx_create(idx, local_rank, C.byref(ctx)))
         ctxs.append(ctx)
+    for si in range(n_str):
         parts.append(reads[si::n_str])
     log("[bench] index built + uploaded in %.1fs (mid_occ=%d)" % (time.time() - t0, mo.mid_occ))
 
     packed = [_ffi.pack_reads(p) for p in parts]
     n_bases = sum(len(b) for pk in packed for b in pk[2])
     t0 = time.time()
-    for ctx, (rarr, rlens, keep) in zip(ctxs, packed):
-        _ffi.check(L.mm355_batch_upload(ctx, len(keep), rarr, rlens))
+    for si, (rarr, rlens, keep) in enumerate(packed):      # sub-batch si lives in context si % n_thr, slot si // n_thr
+        _ffi.check(L.mm355_batch_select(ctxs[si % n_thr], si // n_thr))
+        _ffi.check(L.mm355_batch_upload(ctxs[si % n_thr], len(keep), rarr, rlens))
     t_upload = time.time() - t0
 
     def step_one(si):
-        ctx, (rarr, rlens, keep) = ctxs[si], packed[si]
+        ctx, (rarr, rlens, keep) = ctxs[si % n_thr], packed[si]
+        _ffi.check(L.mm355_batch_select(ctx, si // n_thr))
         hp = C.POINTER(_ffi.Hits)()
         _ffi.check(L.mm355_map_resident(ctx, C.byref(mo), _ffi.OUT_CS, C.byref(hp)))
         h = hp.contents
@@ -227,12 +233,13 @@ def main():
 
     # PCIe-inclusive variant (never `value`): upload + map of the same reads
     def pcie_one(si):
-        ctx, (rarr, rlens, keep) = ctxs[si], packed[si]
+        ctx, (rarr, rlens, keep) = ctxs[si % n_thr], packed[si]
+        _ffi.check(L.mm355_batch_select(ctx, si // n_thr))
         hp = C.POINTER(_ffi.Hits)()
         _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(keep), rarr, rlens, _ffi.OUT_CS, C.byref(hp)))
         L.mm355_free_hits(hp)
     t0 = time.perf_counter()
-    list(pool.map(pcie_one, range(n_str)))
+    list(pool.map(lambda ti: [pcie_one(si) for si in range(ti, n_str, n_thr)], range(n_thr)))
     dt_pcie = time.perf_counter() - t0
 
     if rank == 0:

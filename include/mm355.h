@@ -127,6 +127,8 @@ int mm355_map_batch(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads,
 /* the same call split in two, for callers that keep a batch resident in HBM (bench.py times mm355_map_resident):
  * mm355_map_batch == mm355_batch_upload + mm355_map_resident */
 int mm355_batch_upload(mm355_ctx_t *ctx, int64_t n_reads, const char *const *seqs, const int32_t *lens);
+/* several resident batches per context: make batch `slot` (0..63) the current one; upload / map_resident act on the current batch */
+int mm355_batch_select(mm355_ctx_t *ctx, int slot);
 int mm355_map_resident(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int flags, mm355_hits_t **out);
 void mm355_free_hits(mm355_hits_t *hits);
 

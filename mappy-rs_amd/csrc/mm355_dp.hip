@@ -494,25 +494,26 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	static std::mutex dp_turn[16];
 	static const bool take_turns = [] { const char *e = getenv("MM355_DP_TURNS"); return !(e && atoi(e) == 0); }();
 	std::unique_lock<std::mutex> turn(dp_turn[c->dev & 15], std::defer_lock);
-	if (take_turns) turn.lock();
-	const double t_turn0 = mm355_now_ms();
 	HIPCHK(hipMemcpyAsync(c->dp_jobs.p, jobs, n * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
 	int32_t *d_off = c->dp_work.as<int32_t>();
 	int32_t *d_ids = d_off + off_tot + 16;
 	uint64_t *d_S = c->dp_H.as<uint64_t>();
 	int32_t *d_H = (int32_t*)(d_S + st_tot + 8);
 	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4, *d_dense = c->counters.as<unsigned long long>() + 5;
+	double t_turn0 = 0;
 	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
 	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + 8;   // cells per group [16]
 	HIPCHK(hipMemsetAsync(d_cells, 0, 8, c->st));
 	HIPCHK(hipMemsetAsync(d_gcells, 0, 128, c->st));
+	// every group gets its own HIP stream: the few long alignments of the big classes run concurrently with the thousands of
+	// short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
+	HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
+	if (c->dp_up_ev == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_up_ev, hipEventDisableTiming));
+	HIPCHK(hipEventRecord(c->dp_up_ev, c->st));   // the group streams start after the uploads
+	if (take_turns) turn.lock();                  // uploads are already on their way when the turn starts
+	t_turn0 = mm355_now_ms();
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
-		// every group gets its own HIP stream: the few long alignments of the big classes run concurrently with the thousands of
-		// short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
-		HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
-		if (c->dp_up_ev == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_up_ev, hipEventDisableTiming));
-		HIPCHK(hipEventRecord(c->dp_up_ev, c->st));   // the group streams start after the uploads
 		(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
 			if (n_grp[g] == 0) continue;
@@ -543,6 +544,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			HIPCHK(hipEventRecord(c->dp_ev[g], c->dp_st[g]));
 			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		}
+		// the turn ends when the extension kernels are done: the backtrack below is a latency-bound pointer walk and, like the result
+		// copies, overlaps the next context's round
+		if (take_turns) { HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); mm355_trace_add(c, "dpk", t_turn0, mm355_now_ms()); }
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
@@ -554,8 +558,6 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, 128, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
-	if (take_turns) turn.unlock();
-	mm355_trace_add(c, "dpk", t_turn0, mm355_now_ms());
 	const size_t n_dense = (size_t)ctr[1];
 	if (arena->ensure((n_dense + 16) * 4)) return MM355_ENOMEM;
 	if (n_dense) HIPCHK(hipMemcpyAsync(arena->p, c->dp_dense.p, n_dense * 4, hipMemcpyDeviceToHost, c->st));

@@ -205,6 +205,24 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 	return 0;
 }
 
+// Several batches can be resident in one context: select(slot) parks the current batch (packed reads + tables, device and host
+// side) and makes the batch of `slot` current (an empty one the first time).  Working buffers are shared; they only grow.
+extern "C" int mm355_batch_select(mm355_ctx_t *c, int slot)
+{
+	if (c == 0 || slot < 0 || slot >= 64) return MM355_EINVAL;
+	if (slot == c->cur_slot) return 0;
+	const size_t need = (size_t)std::max(slot, c->cur_slot) + 1;
+	if (c->slots.size() < need) c->slots.resize(need);
+	auto exchange = [&](ResidentBatch &r) {
+		std::swap(r.hb, c->hb); std::swap(r.seq, c->seq); std::swap(r.roff, c->roff); std::swap(r.rlen, c->rlen); std::swap(r.order, c->order);
+		std::swap(r.ck_read, c->ck_read); std::swap(r.ck_start, c->ck_start); std::swap(r.ck_r0, c->ck_r0); std::swap(r.n_chunks, c->n_chunks);
+	};
+	exchange(c->slots[c->cur_slot]);   // park the current batch in its own slot
+	exchange(c->slots[slot]);          // and take the requested one
+	c->cur_slot = slot;
+	return 0;
+}
+
 extern "C" int mm355_batch_upload(mm355_ctx_t *c, int64_t n_reads, const char *const *seqs, const int32_t *lens)
 {
 	if (c == 0 || n_reads < 0) return MM355_EINVAL;

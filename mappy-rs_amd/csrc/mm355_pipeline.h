@@ -38,8 +38,13 @@ struct HostBatch {            // packed reads of one sub-batch
 	int64_t tot_a = 0;
 };
 
+// a batch of reads resident in HBM that is not the context's current one (mm355_batch_select): the packed reads, their tables and
+// the host copy; every working buffer stays with the context
+struct ResidentBatch { HostBatch hb; DBuf seq, roff, rlen, order, ck_read, ck_start, ck_r0; int64_t n_chunks = 0; };
+
 struct mm355_ctx {
 	const mm355_index *mi = 0;
+	std::vector<ResidentBatch> slots; int cur_slot = 0;
 	int dev = 0;
 	hipStream_t st = 0;
 	DevIndex dix;

@@ -82,7 +82,7 @@ EXPORTS = [
     "mm355_set_opt", "mm355_mapopt_update", "mm355_index_load", "mm355_index_build", "mm355_index_build_device", "mm355_index_free",
     "mm355_index_info", "mm355_index_seq_name", "mm355_index_seq_len", "mm355_index_name2id", "mm355_index_getseq",
     "mm355_index_get", "mm355_index_stat", "mm355_ctx_create", "mm355_ctx_destroy", "mm355_map_batch",
-    "mm355_free_hits", "mm355_batch_upload", "mm355_map_resident", "mm355_stage_sketch", "mm355_stage_anchors", "mm355_stage_chain", "mm355_stage_chains",
+    "mm355_free_hits", "mm355_batch_upload", "mm355_batch_select", "mm355_map_resident", "mm355_stage_sketch", "mm355_stage_anchors", "mm355_stage_chain", "mm355_stage_chains",
     "mm355_stage_dp", "mm355_get_stats", "mm355_device_count", "mm355_strerror", "mm355_version",
 ]
 
@@ -119,6 +119,7 @@ def lib():
     L.mm355_map_batch.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, C.POINTER(C.c_char_p), i32p, C.c_int, C.POINTER(C.POINTER(Hits))]
     L.mm355_free_hits.argtypes = [C.POINTER(Hits)]
     L.mm355_batch_upload.argtypes = [vp, C.c_int64, C.POINTER(C.c_char_p), i32p]
+    L.mm355_batch_select.argtypes = [vp, C.c_int]
     L.mm355_map_resident.argtypes = [vp, C.POINTER(MapOpt), C.c_int, C.POINTER(C.POINTER(Hits))]
     L.mm355_stage_sketch.argtypes = [vp, C.c_int64, C.POINTER(C.c_char_p), i32p, vp, vp, C.c_int64]
     L.mm355_stage_anchors.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, C.POINTER(C.c_char_p), i32p, C.c_int, vp, vp, C.c_int64, vp, vp]
