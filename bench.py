@@ -15,6 +15,11 @@ The JSON line also carries `roofline` (dominant kernel; algorithmic bytes of SUR
 launch stream) and `cpu_baseline` (the CPU oracle timed on the host cores on a bounded sample of the same reads).
 """
 import argparse
+import os as _os
+# ROCclr multiplexes all HIP streams of a process over GPU_MAX_HW_QUEUES hardware queues (default 4); with 8 contexts in flight the
+# per-read front kernels of one context queue behind the extension grids of another.  8 queues measured best (16+ lets the
+# extension rounds interleave again).  Must be set before the HIP runtime starts.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import ctypes as C
 import json
 import os
@@ -181,19 +186,27 @@ def main():
         _ffi.check(L.mm355_batch_upload(ctxs[si % n_thr], len(keep), rarr, rlens))
     t_upload = time.time() - t0
 
+    rlens_np = [np.asarray(pk[1], dtype=np.int64) for pk in packed]
+
     def step_one(si):
         ctx, (rarr, rlens, keep) = ctxs[si % n_thr], packed[si]
+        tt0 = time.perf_counter()
         _ffi.check(L.mm355_batch_select(ctx, si // n_thr))
         hp = C.POINTER(_ffi.Hits)()
         _ffi.check(L.mm355_map_resident(ctx, C.byref(mo), _ffi.OUT_CS, C.byref(hp)))
+        tt1 = time.perf_counter()
         h = hp.contents
         off = np.ctypeslib.as_array(h.hit_off, shape=(len(keep) + 1,))
         mapped = np.diff(off) > 0
-        aligned = int(np.asarray(rlens)[mapped].sum())
+        aligned = int(rlens_np[si][mapped].sum())
         n_hits = int(h.n_hits)
+        tt2 = time.perf_counter()
         L.mm355_free_hits(hp)
+        tt3 = time.perf_counter()
         st = _ffi.Stats()
         L.mm355_get_stats(ctx, C.byref(st))
+        if os.environ.get("BENCH_PY_TIMES"):
+            log("[py] map %.1f ms, numpy %.1f ms, free %.1f ms, stats %.1f ms" % ((tt1 - tt0) * 1e3, (tt2 - tt1) * 1e3, (tt3 - tt2) * 1e3, (time.perf_counter() - tt3) * 1e3))
         return aligned, n_hits, st
 
     from concurrent.futures import ThreadPoolExecutor

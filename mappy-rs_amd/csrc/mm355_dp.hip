@@ -426,8 +426,11 @@ template <int NP>
 static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc, const DpJobDev *jobs, const int32_t *ids, const uint8_t *d_q, const uint8_t *d_t,
                        uint8_t *bt, mm355_dpres_t *res, unsigned long long *cells)
 {
-	if (exact) hipLaunchKernelGGL((k_ksw_reg<NP, true>), dim3(n), dim3(64), 0, st, dc, jobs, ids, (int)n, d_q, d_t, bt, res, cells);
-	else hipLaunchKernelGGL((k_ksw_reg<NP, false>), dim3(n), dim3(64), 0, st, dc, jobs, ids, (int)n, d_q, d_t, bt, res, cells);
+	// MM355_DP_LDS_PAD: bytes of (unused) LDS requested per wave, a cap on the extension waves per CU (160 KB / pad) that keeps wave slots
+	// free for the latency-bound front kernels of the other contexts
+	static const size_t pad = [] { const char *e = getenv("MM355_DP_LDS_PAD"); return (size_t)(e? atoi(e) : 0); }();
+	if (exact) hipLaunchKernelGGL((k_ksw_reg<NP, true>), dim3(n), dim3(64), pad, st, dc, jobs, ids, (int)n, d_q, d_t, bt, res, cells);
+	else hipLaunchKernelGGL((k_ksw_reg<NP, false>), dim3(n), dim3(64), pad, st, dc, jobs, ids, (int)n, d_q, d_t, bt, res, cells);
 }
 
 // runs n jobs whose code strings are already on the device (d_q/d_t).  `jobs` is host memory that stays valid until the call

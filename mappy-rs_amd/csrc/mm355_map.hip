@@ -267,13 +267,18 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	for (int64_t i = 0; i < n_reads; ++i) seqs[i] = (const char*)&c->hb.seq[c->hb.roff[i]];
 	const bool verbose = getenv("MM355_VERBOSE") != 0;
 	double tv0 = now_ms(), tv_front, tv_pack, tv_pre, tv_steps = 0, tv_dp = 0, tv_fin, tv_asm;
-	if ((rc = mm355_run_sketch(c))) return rc;
-	if ((rc = mm355_run_seeds(c, pr))) return rc;
-	if ((rc = mm355_run_expand(c, pr))) return rc;
-	if ((rc = mm355_run_sort(c))) return rc;
-	if ((rc = mm355_run_chain(c, pr))) return rc;
-	if ((rc = mm355_run_backtrack(c, pr))) return rc;
-	if ((rc = mm355_run_read_codes(c))) return rc;
+	{
+		double ts = now_ms();
+#define FRONT_STAGE(name, call) do { if ((rc = (call))) return rc; if (g_trace_path) { const double te = now_ms(); trace_add(c, name, ts, te); ts = te; } } while (0)
+		FRONT_STAGE("f:sketch", mm355_run_sketch(c));      // (asynchronous: its time shows up in the next stage's wait)
+		FRONT_STAGE("f:seeds", mm355_run_seeds(c, pr));
+		FRONT_STAGE("f:expand", mm355_run_expand(c, pr));
+		FRONT_STAGE("f:sort", mm355_run_sort(c));
+		FRONT_STAGE("f:chain", mm355_run_chain(c, pr));
+		FRONT_STAGE("f:backtrack", mm355_run_backtrack(c, pr));
+		FRONT_STAGE("f:codes", mm355_run_read_codes(c));
+#undef FRONT_STAGE
+	}
 	HostBatch &hb = c->hb;
 	tv_front = now_ms() - tv0; trace_add(c, "front", tv0, now_ms()); tv0 = now_ms();
 	// pack chains / anchors / mini_pos and bring them to the host
