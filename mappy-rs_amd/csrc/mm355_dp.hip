@@ -518,14 +518,21 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
 		(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
+		// groups share a few streams (launch order = big problems first): 0 the wide approx classes (targets <= 256), 1 every exact
+		// class <= 1024, 2 approx 512/1024, 3 the eight-wave kernels.  MM355_DP_STREAMS=0: one stream per group.
+		static const bool few_streams = [] { const char *e = getenv("MM355_DP_STREAMS"); return !(e && atoi(e) == 0); }();
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
 			if (n_grp[g] == 0) continue;
 			const DpClass &k = classes[g >> 1];
-			if (c->dp_st[g] == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[g], hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[g], hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming)); }
-			HIPCHK(hipStreamWaitEvent(c->dp_st[g], c->dp_up_ev, 0));
+			const int sidx = !few_streams? g : (g >= 8? 3 : (g & 1)? 1 : g >= 4? 2 : 0);
+			hipStream_t gst;
+			if (c->dp_st[sidx] == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[sidx], hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[sidx], hipStreamNonBlocking)); }
+			if (c->dp_ev[g] == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming));
+			gst = c->dp_st[sidx];
+			HIPCHK(hipStreamWaitEvent(gst, c->dp_up_ev, 0));
 			if (c->dp_ev0[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev0[g]));
 			if (c->dp_ev1[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev1[g]));
-			HIPCHK(hipEventRecord(c->dp_ev0[g], c->dp_st[g]));
+			HIPCHK(hipEventRecord(c->dp_ev0[g], gst));
 			unsigned long long *gc = d_gcells + g;
 			const unsigned nj = (unsigned)n_grp[g];
 			const int32_t *gid = d_ids + grp_off[g];
@@ -533,18 +540,18 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
 			if (k.kind == 0) {
 				const bool ex = g & 1;
-				if (k.np == 1) launch_reg<1>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
-				else if (k.np == 2) launch_reg<2>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
-				else if (k.np == 4) launch_reg<4>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
-				else launch_reg<8>(ex, nj, c->dp_st[g], dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
+				if (k.np == 1) launch_reg<1>(ex, nj, gst, dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
+				else if (k.np == 2) launch_reg<2>(ex, nj, gst, dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
+				else if (k.np == 4) launch_reg<4>(ex, nj, gst, dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
+				else launch_reg<8>(ex, nj, gst, dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
 			} else if (k.kind == 1)
-				hipLaunchKernelGGL(k_ksw_extd2<64>, dim3(nj), dim3(64), (size_t)k.cap * 12, c->dp_st[g], dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+				hipLaunchKernelGGL(k_ksw_extd2<64>, dim3(nj), dim3(64), (size_t)k.cap * 12, gst, dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
 				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense);
 			else
-				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3(nj), dim3(512), (size_t)k.cap * 12, c->dp_st[g], dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3(nj), dim3(512), (size_t)k.cap * 12, gst, dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
 				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense);
-			HIPCHK(hipEventRecord(c->dp_ev1[g], c->dp_st[g]));
-			HIPCHK(hipEventRecord(c->dp_ev[g], c->dp_st[g]));
+			HIPCHK(hipEventRecord(c->dp_ev1[g], gst));
+			HIPCHK(hipEventRecord(c->dp_ev[g], gst));
 			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		}
 		// the turn ends when the extension kernels are done: the backtrack below is a latency-bound pointer walk and, like the result
