@@ -1,0 +1,56 @@
+// mm355_fastsort.hip -- row a6 for anchor-rich reads (GRCh38-scale): the anchors of a read are sorted by x with the unstable in-place
+// radix sort of U:ksort.h (radix_sort_128x), whose only observable difference from ANY other sort by x is the order of anchors with
+// EQUAL x.  Reads without equal keys (≈95 % of them even on a repeat-rich genome) therefore get the same array from a plain parallel
+// sort.  This file sorts every read out of place with one rocPRIM segmented radix sort (all reads at once, HBM-bound), flags the
+// reads that contain equal keys, and copies the result back for the others; the flagged reads go through the literal emulation
+// (k_sort_anchors / k_sort_level_mw in mm355_kernels.hip), starting from their untouched generation-order anchors.
+#include <cstring>
+#include <cstdio>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include "mm355_pipeline.h"
+
+__global__ __launch_bounds__(256) void k_fs_split(const mm128 *a, uint64_t *kx, uint64_t *ky, int64_t n)
+{
+	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) { const mm128 e = a[i]; kx[i] = e.x; ky[i] = e.y; }
+}
+
+// one block per read: does the sorted key array of the read contain two equal neighbours?
+__global__ __launch_bounds__(256) void k_fs_ties(const int64_t *aoff, const uint64_t *kx, uint8_t *flag, int n_reads)
+{
+	const int r = blockIdx.x;
+	if (r >= n_reads) return;
+	const int64_t b = aoff[r], e = aoff[r + 1];
+	bool tie = false;
+	for (int64_t i = b + 1 + threadIdx.x; i < e; i += 256) tie |= kx[i] == kx[i - 1];
+	const int any = __syncthreads_or(tie);
+	if (threadIdx.x == 0) flag[r] = any? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_fs_merge(const int64_t *aoff, const uint64_t *kx, const uint64_t *ky, mm128 *a, const uint8_t *flag, int n_reads)
+{
+	const int r = blockIdx.x;
+	if (r >= n_reads || flag[r]) return;   // reads with equal keys keep their generation-order anchors for the literal sort
+	const int64_t b = aoff[r], e = aoff[r + 1];
+	for (int64_t i = b + threadIdx.x; i < e; i += 256) { mm128 v; v.x = kx[i]; v.y = ky[i]; a[i] = v; }
+}
+
+// sorts a[] of every tie-free read; h_flag[r] = 1 for the reads that still have to be sorted literally.  Scratch: b[] and wk[] (16 B per anchor each).
+int mm355_fast_sort(mm355_ctx *c, int64_t tot, int n_reads, std::vector<uint8_t> &h_flag)
+{
+	h_flag.assign((size_t)n_reads, 0);
+	if (tot <= 0 || n_reads <= 0) return 0;
+	uint64_t *kx_in = c->b.as<uint64_t>(), *ky_in = kx_in + tot, *kx_out = c->wk.as<uint64_t>(), *ky_out = kx_out + tot;
+	const int64_t *aoff = c->aoff.as<int64_t>();
+	hipLaunchKernelGGL(k_fs_split, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->st, c->a.as<mm128>(), kx_in, ky_in, tot);
+	size_t tb = 0;
+	if (rocprim::segmented_radix_sort_pairs(nullptr, tb, kx_in, kx_out, ky_in, ky_out, (unsigned int)tot, (unsigned int)n_reads, aoff, aoff + 1, 0u, 64u, c->st) != hipSuccess) return MM355_EHIP;
+	if (c->sort_tmp.ensure(tb + 256) || c->sort_flag.ensure((size_t)n_reads + 64)) return MM355_ENOMEM;
+	if (rocprim::segmented_radix_sort_pairs(c->sort_tmp.p, tb, kx_in, kx_out, ky_in, ky_out, (unsigned int)tot, (unsigned int)n_reads, aoff, aoff + 1, 0u, 64u, c->st) != hipSuccess) return MM355_EHIP;
+	hipLaunchKernelGGL(k_fs_ties, dim3((unsigned)n_reads), dim3(256), 0, c->st, aoff, kx_out, c->sort_flag.as<uint8_t>(), n_reads);
+	hipLaunchKernelGGL(k_fs_merge, dim3((unsigned)n_reads), dim3(256), 0, c->st, aoff, kx_out, ky_out, c->a.as<mm128>(), c->sort_flag.as<uint8_t>(), n_reads);
+	if (hipMemcpyAsync(h_flag.data(), c->sort_flag.p, (size_t)n_reads, hipMemcpyDeviceToHost, c->st) != hipSuccess) return MM355_EHIP;
+	if (mm355_wait_stream(c->st) != hipSuccess) return MM355_EHIP;
+	return hipGetLastError() == hipSuccess? 0 : MM355_EHIP;
+}

@@ -1146,10 +1146,11 @@ void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const Dev
 }
 // heavy_first[0..n_heavy) = reads with more than MW_BIG anchors (block-level path, on st_heavy); the others take one wave each.
 // task_buf: device scratch for 3 task lists of `task_cap` entries each + 2 counters
-int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, int n_heavy, void *task_buf, size_t task_cap, hipStream_t st, hipStream_t st_heavy)
+// list[0..n_list): the reads to sort, most anchors first; the first n_heavy of them take the block-level path
+int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, int n_heavy, int n_list, void *task_buf, size_t task_cap, hipStream_t st, hipStream_t st_heavy)
 {
-	if (bt.n_reads == 0) return 0;
-	if (bt.n_reads > n_heavy) hipLaunchKernelGGL(k_sort_anchors, dim3(bt.n_reads - n_heavy), dim3(WAVE), 0, st, bt, an, err, heavy_first + n_heavy);
+	if (n_list == 0) return 0;
+	if (n_list > n_heavy) hipLaunchKernelGGL(k_sort_anchors, dim3(n_list - n_heavy), dim3(WAVE), 0, st, bt, an, err, heavy_first + n_heavy);
 	if (n_heavy > 0) {
 		SortTask *big[2] = { (SortTask*)task_buf, (SortTask*)task_buf + task_cap };
 		SortTask *small = (SortTask*)task_buf + 2 * task_cap;

@@ -106,8 +106,10 @@ void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1)
 static void trace_add(const void *ctx, const char *phase, double t0, double t1) { mm355_trace_add(ctx, phase, t0, t1); }
 hipError_t mm355_wait_stream(hipStream_t st)
 {
-	static const bool spin = [] { const char *e = getenv("MM355_SPIN_WAIT"); return e && atoi(e) != 0; }();
-	if (spin) return hipStreamSynchronize(st);
+	// default: the runtime's own wait (hipStreamSynchronize); MM355_BLOCKING_WAIT=1 sleeps on a blocking-sync event instead (no measurable
+	// throughput difference on the bench box; interrupt-driven waits were erratic on some hosts)
+	static const bool blocking = [] { const char *e = getenv("MM355_BLOCKING_WAIT"); return e && atoi(e) != 0; }();
+	if (!blocking) return hipStreamSynchronize(st);
 	static thread_local hipEvent_t ev = 0;   // one per calling thread (leaked with it); valid for any stream of the current device
 	static thread_local int ev_dev = -1;
 	int dev = 0; (void)hipGetDevice(&dev);

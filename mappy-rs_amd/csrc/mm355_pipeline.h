@@ -53,6 +53,7 @@ struct mm355_ctx {
 	DBuf heavy, seq, roff, rlen, order, ck_read, ck_start, ck_n, ck_r0;
 	int64_t n_chunks = 0;
 	int prio_low = 0, prio_high = 0; bool use_prio = false;
+	DBuf sort_tmp, sort_flag, tie_list;   // fast anchor sort (mm355_fastsort.hip)
 	int n_heavy = 0; hipStream_t aux_st = 0; hipEvent_t aux_ev = 0, aux_ev2 = 0; DBuf sort_tasks;
 	DBuf mz, mz_tmp, n_mz, sn, sv, sflt, hl, soff, n_a, rep_len, n_mini, mini_pos, counters, err;
 	DBuf aoff, a, f, p, v, z, t8, vi, b, wk, u, u2, n_u, n_v;
@@ -92,6 +93,7 @@ typedef EvTimer EvTimer2;
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)
 
-hipError_t mm355_wait_stream(hipStream_t st);   // like hipStreamSynchronize, but the calling thread sleeps (MM355_SPIN_WAIT=1: spins)
+int mm355_fast_sort(mm355_ctx *c, int64_t tot, int n_reads, std::vector<uint8_t> &h_flag);
+hipError_t mm355_wait_stream(hipStream_t st);   // hipStreamSynchronize, or with MM355_BLOCKING_WAIT=1 a sleep on a blocking-sync event
 void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1);   // MM355_TRACE timeline (no-op when unset)
 double mm355_now_ms();

@@ -99,7 +99,7 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 {
 	if (c == 0) return;
 	(void)hipSetDevice(c->dev);
-	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->sort_tasks, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
+	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->sort_tasks, &c->sort_tmp, &c->sort_flag, &c->tie_list, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
 		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
@@ -267,8 +267,31 @@ int mm355_run_sort(mm355_ctx *c)
 		const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->n_heavy + 1024;
 		if (c->sort_tasks.ensure(task_cap * 3 * 16 + 64)) return MM355_ENOMEM;
 		EvTimer t(c, &c->stats.ms_sort);
+		const int n_reads = (int)c->hb.n_reads;
+		const int32_t *list = c->heavy.as<int32_t>();
+		int n_list = n_reads, n_heavy = c->n_heavy;
+		// anchor-rich batches (GRCh38-scale): one segmented radix sort for all reads; only the reads with equal keys -- where the tie
+		// order of the reference's unstable sort is observable -- go through the literal emulation (MM355_FAST_SORT=0/1 forces the choice)
+		static const int force = [] { const char *e = getenv("MM355_FAST_SORT"); return e? atoi(e) : -1; }();
+		const bool fast = force >= 0? force != 0 : (n_reads > 0 && c->hb.tot_a / n_reads >= 2048);
+		if (fast) {
+			std::vector<uint8_t> flag;
+			int rc = mm355_fast_sort(c, c->hb.tot_a, n_reads, flag);
+			if (rc) return rc;
+			std::vector<int32_t> tl;
+			for (int i = 0; i < n_reads; ++i) if (flag[i]) tl.push_back(i);
+			std::stable_sort(tl.begin(), tl.end(), [&](int32_t x, int32_t y) { return c->hb.n_a[x] > c->hb.n_a[y]; });
+			n_list = (int)tl.size(); n_heavy = 0;
+			for (int i = 0; i < n_list && c->hb.n_a[tl[i]] > mm355_sort_heavy_threshold(); ++i) ++n_heavy;
+			if (n_list) {
+				if (c->tie_list.ensure((size_t)n_list * 4 + 64)) return MM355_ENOMEM;
+				HIPCHK(hipMemcpyAsync(c->tie_list.p, tl.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, c->st));
+				HIPCHK(mm355_wait_stream(c->st));   // tl is pageable
+			}
+			list = c->tie_list.as<int32_t>();
+		}
 		HIPCHK(hipEventRecord(c->aux_ev, c->st)); HIPCHK(hipStreamWaitEvent(c->aux_st, c->aux_ev, 0));   // anchors are complete
-		if (mm355_launch_sort(b, a, c->err.as<int>(), c->heavy.as<int32_t>(), c->n_heavy, c->sort_tasks.p, task_cap, c->st, c->aux_st)) return MM355_EHIP;
+		if (mm355_launch_sort(b, a, c->err.as<int>(), list, n_heavy, n_list, c->sort_tasks.p, task_cap, c->st, c->aux_st)) return MM355_EHIP;
 		HIPCHK(hipEventRecord(c->aux_ev2, c->aux_st)); HIPCHK(hipStreamWaitEvent(c->st, c->aux_ev2, 0));
 	}
 	HIPCHK(hipGetLastError());

@@ -244,3 +244,24 @@ def test_heavy_sort_path_on_ordinary_reads(built, tmp_path):
     env = dict(os.environ, MM355_SORT_HEAVY_MIN="100")
     r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "heavy-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_fast_sort_path_keeps_the_reference_tie_order(built, tmp_path):
+    """MM355_FAST_SORT=1 sends every read through the segmented radix sort; reads with equal keys must still come out in the
+    literal radix_sort_128x order (they are re-sorted by the emulation), tie-free reads are identical by construction"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = %r; import tests.test_gpu_stages as T, synthdata as S, numpy as np, os\n"
+            "td = sys.argv[1]\n"
+            "g = S.make_genome(31, [400000, 250000], repeats=((4000, 6, 0.01), (900, 40, 0.02), (300, 120, 0.05)), n_runs=3)\n"
+            "fa = os.path.join(td, 'ref.fa'); S.write_fasta(fa, g, ['chrA', 'chrB'])\n"
+            "reads, _ = S.make_reads(32, g, 120, n50=5000, lo=200)\n"
+            "unit = S.codes_to_str(g[0][1000:1037])\n"
+            "reads += ['ACGT', 'A', unit * 60, 'N' * 50]\n"
+            "n = T._check_sorted_and_chains(fa, reads, 100)\n"
+            "fa2, r2 = T._repeat_world(td)\n"
+            "n += T._check_sorted_and_chains(fa2, r2, 100)\n"
+            "print('fast-ok', n)\n") % ([root, os.path.join(root, "mappy-rs_amd")],)
+    env = dict(os.environ, MM355_FAST_SORT="1")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fast-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
