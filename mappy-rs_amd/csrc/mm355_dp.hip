@@ -552,11 +552,14 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense);
 			HIPCHK(hipEventRecord(c->dp_ev1[g], gst));
 			HIPCHK(hipEventRecord(c->dp_ev[g], gst));
-			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
+			if (k.kind == 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the eight-wave kernels are joined after the turn (below)
 		}
 		// the turn ends when the extension kernels are done: the backtrack below is a latency-bound pointer walk and, like the result
 		// copies, overlaps the next context's round
+		// (only the wide register-kernel grids count: the few long alignments of the eight-wave classes are latency chains that
+		// leave the GPU almost empty; they keep running while the next context's round starts)
 		if (take_turns) { HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); mm355_trace_add(c, "dpk", t_turn0, mm355_now_ms()); }
+		for (int g = 0; g < DP_N_GROUP; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
