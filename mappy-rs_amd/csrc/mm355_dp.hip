@@ -519,12 +519,12 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		EvTimer2 tm(c, &c->stats.ms_dp);
 		(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
 		// groups share a few streams (launch order = big problems first): 0 the wide approx classes (targets <= 256), 1 every exact
-		// class <= 1024, 2 approx 512/1024, 3 the eight-wave kernels.  MM355_DP_STREAMS=0: one stream per group.
+		// class <= 1024, 2 approx 512/1024, 3.. the eight-wave kernels (few long alignments each: they overlap one another).  MM355_DP_STREAMS=0: one stream per group.
 		static const bool few_streams = [] { const char *e = getenv("MM355_DP_STREAMS"); return !(e && atoi(e) == 0); }();
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
 			if (n_grp[g] == 0) continue;
 			const DpClass &k = classes[g >> 1];
-			const int sidx = !few_streams? g : (g >= 8? 3 : (g & 1)? 1 : g >= 4? 2 : 0);
+			const int sidx = !few_streams? g : (g >= 8? 3 + (g - 8) : (g & 1)? 1 : g >= 4? 2 : 0);   // the eight-wave classes are latency chains: one stream each
 			hipStream_t gst;
 			if (c->dp_st[sidx] == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[sidx], hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[sidx], hipStreamNonBlocking)); }
 			if (c->dp_ev[g] == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming));
