@@ -44,6 +44,7 @@ __device__ __forceinline__ uint32_t pk8(int v) { const uint32_t h = (uint32_t)(u
 __device__ __forceinline__ uint32_t bfi(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }           // m ? a : b (v_bfi_b32)
 // value of lane-1 (lane 0: `first`)
 __device__ __forceinline__ uint32_t lane_shr1(uint32_t first, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ uint32_t lane_shr1_z(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xf, 0xf, true); }   // lane 0 gets 0
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 
 // Per-lane state: individually named members (arrays indexed by the unrolled block number get promoted to vector values by
@@ -106,7 +107,9 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 {
 	uint32_t fx = 0, fv = 0, fx2 = 0;
 	if (J > 0) { fx = rdlane(pX, 63); fv = rdlane(pV, 63); fx2 = rdlane(pX2, 63); }
-	uint32_t nx_ = lane_shr1(fx, X), nv_ = lane_shr1(fv, V), nx2_ = lane_shr1(fx2, X2);
+	uint32_t nx_, nv_, nx2_;
+	if (J > 0) { nx_ = lane_shr1(fx, X); nv_ = lane_shr1(fv, V); nx2_ = lane_shr1(fx2, X2); }
+	else { nx_ = lane_shr1_z(X); nv_ = lane_shr1_z(V); nx2_ = lane_shr1_z(X2); }   // lane 0 of block 0: t-1 = -1, always a boundary value (IS_LO below)
 	if (IS_LO) {   // x[st-1], v[st-1], x2[st-1] are boundary values when that cell was outside the previous anti-diagonal
 		const bool at = g.use_def && lane == g.lane_st;
 		nx_ = at? k.dx1 : nx_; nv_ = at? g.dv1 : nv_; nx2_ = at? k.dx21 : nx2_;
@@ -117,10 +120,10 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 		const uint32_t hm = (g.r & 1)? 0xffff0000u : 0xffffu, m = (g.edge && J == g.jq && lane == g.lane_r)? hm : 0u;
 		yi = bfi(m, k.nqe, yi); y2i = bfi(m, k.nq2e2, y2i); ui = bfi(m, g.edge_u8, ui);
 	}
-	// every lane computes; lanes outside [st, en] keep their state through one v_bfi per register
+	// every lane computes; the six state registers are then overwritten under an EXEC mask (lanes outside [st, en] keep theirs).
+	// The masked writes are one asm block: written as C++ under `if (act)`, or as selects, the compiler copies/selects all six.
 	const int tl = 128 * J + 2 * lane;
 	const bool act = tl >= g.st && tl <= g.en;
-	const uint32_t am = act? 0xffffffffu : 0u;
 	const uint32_t z0 = SC;
 	uint32_t a = pk_add(XT, VT), b = pk_add(yi, ui), a2 = pk_add(X2T, VT), b2 = pk_add(y2i, ui);
 	const uint32_t zm = pk_max(pk_max(pk_max(pk_max(z0, a), b), a2), b2);
@@ -152,8 +155,22 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 		fa2 = pk_minu_s(pk_add_s(pk_max_s(a2, k.m256), k.c256), k.f32); fb2 = pk_minu_s(pk_add_s(pk_max_s(b2, k.m256), k.c256), k.f64);
 	}
 	d = d | fa | fb; d = d | fa2 | fb2;
-	X = bfi(am, pk_sub_s(pa, k.qe), X); Y = bfi(am, pk_sub_s(pb, k.qe), Y); X2 = bfi(am, pk_sub_s(pa2, k.q2e2), X2); Y2 = bfi(am, pk_sub_s(pb2, k.q2e2), Y2);
-	U = bfi(am, pk_sub(z, VT), U); V = bfi(am, pk_sub(z, ui), V);
+	{
+		const uint64_t actm = __builtin_amdgcn_ballot_w64(act);
+		uint64_t saved;
+		asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
+		             "v_pk_sub_u16 %[X], %[pa], %[qe]\n\t"
+		             "v_pk_sub_u16 %[Y], %[pb], %[qe]\n\t"
+		             "v_pk_sub_u16 %[X2], %[pa2], %[q2e2]\n\t"
+		             "v_pk_sub_u16 %[Y2], %[pb2], %[q2e2]\n\t"
+		             "v_pk_sub_u16 %[U], %[z], %[VT]\n\t"
+		             "v_pk_sub_u16 %[V], %[z], %[ui]\n\t"
+		             "s_mov_b64 exec, %[sv]"
+		             : [X] "+&v"(X), [Y] "+&v"(Y), [X2] "+&v"(X2), [Y2] "+&v"(Y2), [U] "+&v"(U), [V] "+&v"(V), [sv] "=&s"(saved)
+		             : [m] "s"(actm), [pa] "v"(pa), [pb] "v"(pb), [pa2] "v"(pa2), [pb2] "v"(pb2), [z] "v"(z), [VT] "v"(VT), [ui] "v"(ui),
+		               [qe] "s"(k.qe), [q2e2] "s"(k.q2e2)
+		             : "scc");
+	}
 	if (act) *(uint16_t*)(p + g.prow + tl) = (uint16_t)(__builtin_amdgcn_perm(0, d, 0x0c0c0200));
 }
 
