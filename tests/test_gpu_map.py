@@ -188,6 +188,47 @@ def test_stats_counters(ont):
     assert st.dp_cells > 0 and st.n_dp_jobs > 0 and st.ms_seed_lookup > 0
 
 
+def test_resident_batch_slots(ont):
+    """mm355_batch_select: two batches resident in ONE context, mapped alternately, give the hits of a one-shot mm355_map_batch"""
+    from mappy_rs import _ffi
+    al = ont["al"]; L = al._L
+    ra, _ = S.make_reads(91, ont["g"], 24, n50=3000, lo=500)
+    rb, _ = S.make_reads(92, ont["g"], 17, n50=5000, lo=300)
+    ctx = C.c_void_p()
+    _ffi.check(L.mm355_ctx_create(al._idx, 0, C.byref(ctx)))
+    try:
+        packs = [_ffi.pack_reads(ra), _ffi.pack_reads(rb)]
+        for slot, (rarr, rlens, keep) in enumerate(packs):
+            _ffi.check(L.mm355_batch_select(ctx, slot))
+            _ffi.check(L.mm355_batch_upload(ctx, len(keep), rarr, rlens))
+
+        def hits_of(hp, n):
+            h = hp.contents
+            off = np.ctypeslib.as_array(h.hit_off, shape=(n + 1,)).copy()
+            rec = [(h.hits[k].rid, h.hits[k].target_start, h.hits[k].target_end, h.hits[k].query_start, h.hits[k].query_end, h.hits[k].strand,
+                    h.hits[k].mapq, h.hits[k].n_cigar, h.hits[k].NM) for k in range(int(h.n_hits))]
+            L.mm355_free_hits(hp)
+            return list(off), rec
+
+        expect = []
+        ctx2 = C.c_void_p()
+        _ffi.check(L.mm355_ctx_create(al._idx, 0, C.byref(ctx2)))
+        for rarr, rlens, keep in packs:   # reference: a fresh context, one-shot upload + map
+            hp = C.POINTER(_ffi.Hits)()
+            _ffi.check(L.mm355_map_batch(ctx2, C.byref(al._mo), len(keep), rarr, rlens, 1, C.byref(hp)))
+            expect.append(hits_of(hp, len(keep)))
+        L.mm355_ctx_destroy(ctx2)
+        for order in ((0, 1), (1, 0, 1)):
+            for slot in order:
+                _ffi.check(L.mm355_batch_select(ctx, slot))
+                hp = C.POINTER(_ffi.Hits)()
+                _ffi.check(L.mm355_map_resident(ctx, C.byref(al._mo), 1, C.byref(hp)))
+                assert hits_of(hp, len(packs[slot][2])) == expect[slot], slot
+        assert sum(len(e[1]) for e in expect) > 20
+    finally:
+        L.mm355_ctx_destroy(ctx)
+
+
 def test_committed_golden_vectors_on_gpu(built, golden_dir):
     """the HIP path reproduces the committed golden hits (tests/golden/oracle_ont_small.json) without running the oracle"""
     import json
