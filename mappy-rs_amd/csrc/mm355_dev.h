@@ -58,6 +58,7 @@ struct DevAnchors {
 	uint64_t *u;               // [total anchors / 1] chain descriptors, read r at aoff[r]
 	uint64_t *u2;
 	int32_t *n_u, *n_v;        // [n_reads]
+	const int32_t *tcnt;       // optional (fast sort): equal-key pair counts of the sorted array, see WalkScratch
 };
 
 #ifdef __HIPCC__

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include "mm355_pipeline.h"
 
 __global__ __launch_bounds__(256) void k_fs_split(const mm128 *a, uint64_t *kx, uint64_t *ky, int64_t n)
@@ -17,13 +18,15 @@ __global__ __launch_bounds__(256) void k_fs_split(const mm128 *a, uint64_t *kx, 
 }
 
 // one block per read: does the sorted key array of the read contain two equal neighbours?
-__global__ __launch_bounds__(256) void k_fs_ties(const int64_t *aoff, const uint64_t *kx, uint8_t *flag, int n_reads)
+// (also writes tf[i] = 1 where sorted element i equals its left neighbour inside the read; the inclusive scan of tf is the tcnt[] the
+// literal sort uses to skip buckets without equal keys)
+__global__ __launch_bounds__(256) void k_fs_ties(const int64_t *aoff, const uint64_t *kx, uint8_t *flag, int32_t *tf, int n_reads)
 {
 	const int r = blockIdx.x;
 	if (r >= n_reads) return;
 	const int64_t b = aoff[r], e = aoff[r + 1];
 	bool tie = false;
-	for (int64_t i = b + 1 + threadIdx.x; i < e; i += 256) tie |= kx[i] == kx[i - 1];
+	for (int64_t i = b + threadIdx.x; i < e; i += 256) { const bool t = i > b && kx[i] == kx[i - 1]; tf[i] = t? 1 : 0; tie |= t; }
 	const int any = __syncthreads_or(tie);
 	if (threadIdx.x == 0) flag[r] = any? 1 : 0;
 }
@@ -34,6 +37,29 @@ __global__ __launch_bounds__(256) void k_fs_merge(const int64_t *aoff, const uin
 	if (r >= n_reads || flag[r]) return;   // reads with equal keys keep their generation-order anchors for the literal sort
 	const int64_t b = aoff[r], e = aoff[r + 1];
 	for (int64_t i = b + threadIdx.x; i < e; i += 256) { mm128 v; v.x = kx[i]; v.y = ky[i]; a[i] = v; }
+}
+
+// reads sorted literally (flag = 1): only the positions inside equal-key runs keep what the emulation produced; every other position has a
+// unique occupant, taken from the plain sort (the emulation skipped the buckets that contain no equal keys)
+__global__ __launch_bounds__(256) void k_fs_fix(const int64_t *aoff, const uint64_t *kx, const uint64_t *ky, mm128 *a, const uint8_t *flag, int n_reads)
+{
+	const int r = blockIdx.x;
+	if (r >= n_reads || !flag[r]) return;
+	const int64_t b = aoff[r], e = aoff[r + 1];
+	for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+		const uint64_t x = kx[i];
+		const bool in_run = (i > b && kx[i - 1] == x) || (i + 1 < e && kx[i + 1] == x);
+		if (!in_run) { mm128 v; v.x = x; v.y = ky[i]; a[i] = v; }
+	}
+}
+
+int mm355_fast_sort_fix(mm355_ctx *c, int n_reads)
+{
+	if (n_reads <= 0 || c->hb.tot_a <= 0) return 0;
+	const int64_t tot = c->hb.tot_a;
+	const uint64_t *kx_out = c->wk.as<uint64_t>(), *ky_out = kx_out + tot;
+	hipLaunchKernelGGL(k_fs_fix, dim3((unsigned)n_reads), dim3(256), 0, c->st, c->aoff.as<int64_t>(), kx_out, ky_out, c->a.as<mm128>(), c->sort_flag.as<uint8_t>(), n_reads);
+	return hipGetLastError() == hipSuccess? 0 : MM355_EHIP;
 }
 
 // sorts a[] of every tie-free read; h_flag[r] = 1 for the reads that still have to be sorted literally.  Scratch: b[] and wk[] (16 B per anchor each).
@@ -48,7 +74,14 @@ int mm355_fast_sort(mm355_ctx *c, int64_t tot, int n_reads, std::vector<uint8_t>
 	if (rocprim::segmented_radix_sort_pairs(nullptr, tb, kx_in, kx_out, ky_in, ky_out, (unsigned int)tot, (unsigned int)n_reads, aoff, aoff + 1, 0u, 64u, c->st) != hipSuccess) return MM355_EHIP;
 	if (c->sort_tmp.ensure(tb + 256) || c->sort_flag.ensure((size_t)n_reads + 64)) return MM355_ENOMEM;
 	if (rocprim::segmented_radix_sort_pairs(c->sort_tmp.p, tb, kx_in, kx_out, ky_in, ky_out, (unsigned int)tot, (unsigned int)n_reads, aoff, aoff + 1, 0u, 64u, c->st) != hipSuccess) return MM355_EHIP;
-	hipLaunchKernelGGL(k_fs_ties, dim3((unsigned)n_reads), dim3(256), 0, c->st, aoff, kx_out, c->sort_flag.as<uint8_t>(), n_reads);
+	int32_t *tf = c->p.as<int32_t>(), *tcnt = c->v.as<int32_t>();   // p[] and v[] (4 B per anchor) are free until chaining; v[] = tcnt stays for the literal sort
+	hipLaunchKernelGGL(k_fs_ties, dim3((unsigned)n_reads), dim3(256), 0, c->st, aoff, kx_out, c->sort_flag.as<uint8_t>(), tf, n_reads);
+	{
+		size_t sb = 0;
+		if (rocprim::inclusive_scan(nullptr, sb, tf, tcnt, (size_t)tot, rocprim::plus<int32_t>(), c->st) != hipSuccess) return MM355_EHIP;
+		if (sb > tb) { if (c->sort_tmp.ensure(sb + 256)) return MM355_ENOMEM; }
+		if (rocprim::inclusive_scan(c->sort_tmp.p, sb, tf, tcnt, (size_t)tot, rocprim::plus<int32_t>(), c->st) != hipSuccess) return MM355_EHIP;
+	}
 	hipLaunchKernelGGL(k_fs_merge, dim3((unsigned)n_reads), dim3(256), 0, c->st, aoff, kx_out, ky_out, c->a.as<mm128>(), c->sort_flag.as<uint8_t>(), n_reads);
 	if (hipMemcpyAsync(h_flag.data(), c->sort_flag.p, (size_t)n_reads, hipMemcpyDeviceToHost, c->st) != hipSuccess) return MM355_EHIP;
 	if (mm355_wait_stream(c->st) != hipSuccess) return MM355_EHIP;

@@ -86,7 +86,10 @@ struct SortLds {
 };
 
 // per-read HBM scratch of the parallel permutation (all indexed like the array being sorted)
-struct WalkScratch { void *out; uint32_t *fpos; uint32_t *rank; uint8_t *flab; };
+// tcnt (optional): running count of equal-key neighbour pairs of the SORTED array (mm355_fastsort.hip).  A bucket [b, e) without such a
+// pair has a unique sorted content that the caller restores from the plain sort afterwards, so the literal recursion skips it.
+struct WalkScratch { void *out; uint32_t *fpos; uint32_t *rank; uint8_t *flab; const int32_t *tcnt; };
+__device__ inline bool ws_has_tie(const int32_t *tc, uint32_t b, uint32_t e) { return tc == 0 || tc[e - 1] - tc[b] > 0; }
 
 // One level of the in-place cycle-leader permutation of rs_sort, reproduced WITHOUT moving elements one by one.
 // The permutation only depends on the byte labels: inside the region R_k of bucket k an element is "home" (label k) or
@@ -227,6 +230,7 @@ __device__ void wave_rs_core(T *a, uint32_t n0, int s0, Key key, SortLds *L, T *
 			uint32_t s2 = (uint32_t)((s - 8) >> 3);
 			for (uint32_t k = lane; k < 256; k += WAVE) {
 				uint32_t b0 = L->bb[k], sz = L->cnt[k];
+				if (sz > 1 && !ws_has_tie(ws? ws->tcnt : 0, beg + b0, beg + b0 + sz)) continue;   // unique content, restored by the caller
 				if (sz > MM355_RS_MIN_SIZE) {
 					uint32_t slot = atomicAdd(&L->stk_n, 1u);
 					if (slot < RS_STK) { L->stk_beg[slot] = beg + b0; L->stk_end[slot] = (beg + b0 + sz) | (s2 << 28); }
@@ -492,6 +496,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors a
 	const int64_t o = an.aoff[r];
 	const uint32_t n = (uint32_t)(an.aoff[r+1] - o);
 	WalkScratch ws; ws.out = an.b + o; ws.fpos = (uint32_t*)an.f + o; ws.rank = (uint32_t*)an.p + o; ws.flab = an.t8 + o;   // all free before chaining
+	ws.tcnt = an.tcnt? an.tcnt + o : 0;
 	wave_radix_sort(an.a + o, n, mm_key_x(), &L, stage, (uint32_t)A_STAGE, &ws);
 	if (threadIdx.x == 0 && n > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
 }
@@ -510,11 +515,11 @@ int mm355_sort_heavy_threshold(void);
 template <typename T> struct SortArr;   // per-read base pointers of the array being sorted and of its scratch
 template <> struct SortArr<mm128> {
 	__device__ static mm128 *arr(const DevAnchors &an, int64_t o) { return an.a + o; }
-	__device__ static WalkScratch ws(const DevAnchors &an, int64_t o) { WalkScratch w; w.out = an.b + o; w.fpos = (uint32_t*)an.f + o; w.rank = (uint32_t*)an.p + o; w.flab = an.t8 + o; return w; }
+	__device__ static WalkScratch ws(const DevAnchors &an, int64_t o) { WalkScratch w; w.out = an.b + o; w.fpos = (uint32_t*)an.f + o; w.rank = (uint32_t*)an.p + o; w.flab = an.t8 + o; w.tcnt = an.tcnt? an.tcnt + o : 0; return w; }
 };
 template <> struct SortArr<uint64_t> {   // z[] of the backtrack: v[] and vi[] are free at that point
 	__device__ static uint64_t *arr(const DevAnchors &an, int64_t o) { return an.z + o; }
-	__device__ static WalkScratch ws(const DevAnchors &an, int64_t o) { WalkScratch w; w.out = an.u2 + o; w.fpos = (uint32_t*)an.vi + o; w.rank = (uint32_t*)an.v + o; w.flab = an.t8 + o; return w; }
+	__device__ static WalkScratch ws(const DevAnchors &an, int64_t o) { WalkScratch w; w.out = an.u2 + o; w.fpos = (uint32_t*)an.vi + o; w.rank = (uint32_t*)an.v + o; w.flab = an.t8 + o; w.tcnt = 0; return w; }
 };
 
 struct MwLds {
@@ -622,7 +627,8 @@ __global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const So
 	__syncthreads();
 	if (s > 0 && tid < 256) {   // children: big -> another block level, medium -> one wave each, <= 64 -> insertion sort right here
 		const uint32_t b0 = L.bb[tid], sz = L.cnt[tid];
-		if (sz > MM355_RS_MIN_SIZE) {
+		if (sz > 1 && !ws_has_tie(ws.tcnt, beg + b0, beg + b0 + sz)) { /* unique content, restored by the caller */ }
+		else if (sz > MM355_RS_MIN_SIZE) {
 			SortTask c; c.read = tk.read; c.beg = beg + b0; c.end = beg + b0 + sz; c.s = s - 8;
 			if (sz > big_min) out_big[atomicAdd(&ctr[0], 1u)] = c;
 			else out_small[atomicAdd(&ctr[1], 1u)] = c;
@@ -641,7 +647,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTa
 	const SortTask tk = tasks[blockIdx.x];
 	const int64_t o = an.aoff[tk.read];
 	WalkScratch ws = SortArr<T>::ws(an, o);
-	ws.out = (T*)ws.out + tk.beg; ws.fpos += tk.beg; ws.rank += tk.beg; ws.flab += tk.beg;
+	ws.out = (T*)ws.out + tk.beg; ws.fpos += tk.beg; ws.rank += tk.beg; ws.flab += tk.beg; if (ws.tcnt) ws.tcnt += tk.beg;
 	if (threadIdx.x == 0) { L.stk_n = 0; L.overflow = 0; }
 	__syncthreads();
 	wave_rs_core<true>(SortArr<T>::arr(an, o) + tk.beg, tk.end - tk.beg, tk.s, Key(), &L, (T*)stage, (uint32_t)(sizeof(stage) / sizeof(T)), &ws);
@@ -1035,7 +1041,7 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 	}
 	__syncthreads();
 	if (n_z == 0) return;
-	WalkScratch ws; ws.out = u2; ws.fpos = (uint32_t*)vi; ws.rank = (uint32_t*)(an.v + o); ws.flab = t8;   // v[] is dead after the DP fill
+	WalkScratch ws; ws.out = u2; ws.fpos = (uint32_t*)vi; ws.rank = (uint32_t*)(an.v + o); ws.flab = t8; ws.tcnt = 0;   // v[] is dead after the DP fill
 	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws);
 	if (lane == 0 && n_z > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
 	__syncthreads();

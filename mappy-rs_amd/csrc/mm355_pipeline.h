@@ -94,6 +94,7 @@ typedef EvTimer EvTimer2;
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)
 
 int mm355_fast_sort(mm355_ctx *c, int64_t tot, int n_reads, std::vector<uint8_t> &h_flag);
+int mm355_fast_sort_fix(mm355_ctx *c, int n_reads);   // after the literal sort of the flagged reads: restore every position outside equal-key runs
 hipError_t mm355_wait_stream(hipStream_t st);   // hipStreamSynchronize, or with MM355_BLOCKING_WAIT=1 a sleep on a blocking-sync event
 void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1);   // MM355_TRACE timeline (no-op when unset)
 double mm355_now_ms();

@@ -141,6 +141,7 @@ static DevAnchors dev_anchors(mm355_ctx *c)
 	a.aoff = c->aoff.as<int64_t>(); a.a = c->a.as<mm128>(); a.f = c->f.as<int32_t>(); a.p = c->p.as<int32_t>(); a.v = c->v.as<int32_t>();
 	a.z = c->z.as<uint64_t>(); a.t8 = c->t8.as<uint8_t>(); a.vi = c->vi.as<int32_t>(); a.b = c->b.as<mm128>(); a.wk = c->wk.as<mm128>();
 	a.u = c->u.as<uint64_t>(); a.u2 = c->u2.as<uint64_t>(); a.n_u = c->n_u.as<int32_t>(); a.n_v = c->n_v.as<int32_t>();
+	a.tcnt = 0;
 	return a;
 }
 
@@ -289,10 +290,12 @@ int mm355_run_sort(mm355_ctx *c)
 				HIPCHK(mm355_wait_stream(c->st));   // tl is pageable
 			}
 			list = c->tie_list.as<int32_t>();
+			a.tcnt = c->v.as<int32_t>();   // the literal recursion skips buckets without equal keys (restored by mm355_fast_sort_fix)
 		}
 		HIPCHK(hipEventRecord(c->aux_ev, c->st)); HIPCHK(hipStreamWaitEvent(c->aux_st, c->aux_ev, 0));   // anchors are complete
 		if (mm355_launch_sort(b, a, c->err.as<int>(), list, n_heavy, n_list, c->sort_tasks.p, task_cap, c->st, c->aux_st)) return MM355_EHIP;
 		HIPCHK(hipEventRecord(c->aux_ev2, c->aux_st)); HIPCHK(hipStreamWaitEvent(c->st, c->aux_ev2, 0));
+		if (fast && n_list > 0) { int rc = mm355_fast_sort_fix(c, n_reads); if (rc) return rc; }
 	}
 	HIPCHK(hipGetLastError());
 	return check_err(c);
