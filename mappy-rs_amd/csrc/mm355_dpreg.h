@@ -60,6 +60,7 @@ struct DpRun {             // wave-uniform state of the sweep
 	unsigned long long cells;
 	uint32_t qv;
 	bool any_n;
+	bool full;             // the band never binds (w >= qlen + tlen) and no KSW_EZ_APPROX_DROP: see dp_bounds / the approximate score tracking
 	EzState ez;
 };
 
@@ -67,6 +68,13 @@ __device__ __forceinline__ bool dp_bounds(DpRun &R)   // U:ksw2_extd2_sse.c: st/
 {
 	const int r = R.r;
 	int st = 0, en = R.tlen - 1;
+	if (R.full) {   // (r - w + 1) >> 1 <= 0 and (r + w) >> 1 >= r: only the matrix borders bind, and st <= en always
+		if (st < r - R.qlen + 1) st = r - R.qlen + 1;
+		if (en > r) en = r;
+		R.st0 = st; R.en0 = en;
+		R.st = st & ~15; R.en = (en + 16) / 16 * 16 - 1;
+		return true;
+	}
 	if (st < r - R.qlen + 1) st = r - R.qlen + 1;
 	if (en > r) en = r;
 	if (st < (r - R.w + 1) >> 1) st = (r - R.w + 1) >> 1;
@@ -262,6 +270,16 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 		if (apply_zdrop(ez, max_H, r, max_t, R.zdrop, R.e2)) return false;
 		if (r == R.qlen + R.tlen - 2 && en0 == R.tlen - 1) ez.score = Hen0;   // en0 == tlen - 1: H[tlen-1] is H[en0]
 	} else {
+		if (R.full) {
+			// Full band and no z-drop on the approximate score: H0 only feeds ez.score at the last anti-diagonal, and with every cell of
+			// the matrix exact any monotone path sums to the same H(tlen-1, qlen-1).  Take the top row (u of the edge cell t = r) and then
+			// the last column (v of t = tlen-1) instead of replaying the reference's v-or-u walk: one register read per anti-diagonal.
+			if (r == 0) R.H0 = DP_CELL8(V, 0) - R.qe;
+			else if (r < R.tlen) R.H0 += DP_CELL8(U, r);
+			else R.H0 += DP_CELL8(V, R.tlen - 1);
+			if (r == R.qlen + R.tlen - 2) ez.score = R.H0;   // en0 == tlen - 1 there
+			return true;
+		}
 		if (r > 0) {
 			const int lt = R.last_H0_t;
 			const bool in0 = lt >= st0 && lt <= en0, in1 = lt + 1 >= st0 && lt + 1 <= en0;
@@ -349,6 +367,7 @@ __global__ __launch_bounds__(64) void k_ksw_reg(DpConst dc, const DpJobDev *jobs
 	R.n_col = n_col_ * 16;
 	R.p = pbase + jb.p_off;
 	R.r_total = qlen + tlen - 1;
+	R.full = !EXACT && !(R.flag & EZ_APPROX_DROP) && R.w >= qlen + tlen;
 	R.r = 0; R.last_st = R.last_en = -1; R.H0 = 0; R.last_H0_t = 0; R.cells = 0; R.qv = 0;
 	DpK K;
 	K.nqe = pk8(-R.q - R.e); K.nq2e2 = pk8(-R.q2 - R.e2); K.q = pk8(R.q); K.q2 = pk8(R.q2); K.qe = pk8(R.q + R.e); K.q2e2 = pk8(R.q2 + R.e2);
