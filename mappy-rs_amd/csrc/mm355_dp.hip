@@ -17,6 +17,7 @@
 #include <string.h>
 #include <vector>
 #include <mutex>
+#include <condition_variable>
 #include <algorithm>
 #include "mm355_pipeline.h"
 #include "mm355_dp.h"
@@ -494,9 +495,16 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	// One extension round saturates the GPU.  Rounds of different contexts take turns (per device): run side by side they would all
 	// finish late together and the contexts would march in lock-step -- GPU idle while every host tail runs, hosts idle while every
 	// round runs.  Taking turns lets the first finisher start its host tail while the next round has the whole GPU.
-	static std::mutex dp_turn[16];
-	static const bool take_turns = [] { const char *e = getenv("MM355_DP_TURNS"); return !(e && atoi(e) == 0); }();
-	std::unique_lock<std::mutex> turn(dp_turn[c->dev & 15], std::defer_lock);
+	struct Turn {   // counting semaphore: MM355_DP_TURNS rounds at a time per device (default 1, 0 = unlimited)
+		std::mutex m; std::condition_variable cv; int busy = 0;
+		void lock(int cap) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return busy < cap; }); ++busy; }
+		void unlock() { { std::lock_guard<std::mutex> lk(m); --busy; } cv.notify_one(); }
+	};
+	static Turn dp_turn[16];
+	static const int turn_cap = [] { const char *e = getenv("MM355_DP_TURNS"); return e? atoi(e) : 1; }();
+	const bool take_turns = turn_cap > 0;
+	struct TurnGuard { Turn *t = 0; void lock(Turn *x, int cap) { x->lock(cap); t = x; } void unlock() { if (t) { t->unlock(); t = 0; } } ~TurnGuard() { unlock(); } } turn;
+	Turn *my_turn = &dp_turn[c->dev & 15];
 	HIPCHK(hipMemcpyAsync(c->dp_jobs.p, jobs, n * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
 	int32_t *d_off = c->dp_work.as<int32_t>();
 	int32_t *d_ids = d_off + off_tot + 16;
@@ -513,7 +521,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
 	if (c->dp_up_ev == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_up_ev, hipEventDisableTiming));
 	HIPCHK(hipEventRecord(c->dp_up_ev, c->st));   // the group streams start after the uploads
-	if (take_turns) turn.lock();                  // uploads are already on their way when the turn starts
+	if (take_turns) turn.lock(my_turn, turn_cap); // uploads are already on their way when the turn starts
 	t_turn0 = mm355_now_ms();
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
