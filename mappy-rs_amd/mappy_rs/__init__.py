@@ -12,7 +12,14 @@ Aligner that maps reads requires the HIP library and a visible MI355X -- there i
 """
 import collections.abc
 import ctypes as C
+import os
 import threading
+
+# ROCclr multiplexes all HIP streams over GPU_MAX_HW_QUEUES hardware queues (default 4); the pipelined map_batch keeps several contexts in
+# flight and measures best with 8 (bench.py sets the same).  Only effective if the HIP runtime has not been started yet.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np
 
 from . import _ffi
 
@@ -21,6 +28,7 @@ __all__ = ["Aligner", "Mapping"]
 _CIGAR_OPS = "MIDNSHP=X"
 
 # capacity constants of the reference (lib.rs:429-430, 950)
+SUB_BATCH_READS, SUB_BATCH_BASES = 4096, 32_000_000   # one GPU sub-batch of map_batch
 WORK_QUEUE_CAP = 50000
 RESULT_CHANNEL_CAP = 20000
 
@@ -29,7 +37,7 @@ class Mapping:
     """Result record; fields and aliases of mappy_rs::Mapping (lib.rs:109-154, 196-284)."""
 
     __slots__ = ("query_start", "query_end", "_strand", "target_name", "target_len", "target_start", "target_end",
-                 "match_len", "block_len", "mapq", "is_primary", "cigar", "NM", "MD", "cs")
+                 "match_len", "block_len", "mapq", "is_primary", "_cig", "NM", "MD", "cs")
 
     def __init__(self, query_start, query_end, strand, target_name, target_len, target_start, target_end, match_len,
                  block_len, mapq, is_primary, cigar, NM, MD, cs):
@@ -44,10 +52,19 @@ class Mapping:
         self.block_len = block_len
         self.mapq = mapq
         self.is_primary = is_primary
-        self.cigar = cigar
+        self._cig = cigar          # list of (length, op) or the packed uint32 words (length << 4 | op) until first read
         self.NM = NM
         self.MD = MD
         self.cs = cs
+
+    @property
+    def cigar(self):
+        """list of (length, op) tuples, as mappy-rs; unpacked on first access (the reference converts its Vec on access as well)"""
+        c = self._cig
+        if not isinstance(c, list):
+            c = list(zip((c >> 4).tolist(), (c & 0xf).tolist()))
+            self._cig = c
+        return c
 
     # mappy aliases (lib.rs:196-284)
     ctg = property(lambda s: s.target_name)
@@ -76,24 +93,45 @@ class Mapping:
                                           self.match_len, self.block_len, self.mapq, tp, "cg:Z:" + self.cigar_str))
 
     def __repr__(self):
-        return "Mapping(%s)" % ", ".join("%s=%r" % (k.lstrip("_"), getattr(self, k)) for k in self.__slots__)
+        return "Mapping(%s)" % ", ".join("%s=%r" % (k.lstrip("_"), getattr(self, "cigar" if k == "_cig" else k)) for k in self.__slots__)
 
     def __eq__(self, o):
-        return isinstance(o, Mapping) and all(getattr(self, k) == getattr(o, k) for k in self.__slots__)
+        return isinstance(o, Mapping) and all(getattr(self, "cigar" if k == "_cig" else k) == getattr(o, "cigar" if k == "_cig" else k)
+                                              for k in self.__slots__)
 
 
-def _hits_to_mappings(L, idx, hp, lo, hi):
-    out = []
+_HIT_DTYPE = np.dtype([(k, np.dtype(t)) for k, t in _ffi.Hit._fields_], align=True)
+
+
+def _batch_to_mappings(hp, n_reads, names):
+    """all hits of one mm355_hits_t -> list (per read) of list[Mapping] or RuntimeError.  One bulk copy per array; CIGARs stay packed
+    (unpacked when .cigar is first read), strings are sliced from one bytes object."""
     h = hp.contents
-    for i in range(lo, hi):
-        x = h.hits[i]
-        cig = [(h.cigar[x.cigar_off + j] >> 4, h.cigar[x.cigar_off + j] & 0xf) for j in range(x.n_cigar)]
-        cs = C.string_at(C.addressof(h.str.contents) + x.cs_off, x.cs_len).decode() if x.cs_len >= 0 else None
-        md = C.string_at(C.addressof(h.str.contents) + x.md_off, x.md_len).decode() if x.md_len >= 0 else None
-        nm = L.mm355_index_seq_name(idx, x.rid)
-        out.append(Mapping(x.query_start, x.query_end, x.strand, nm.decode() if nm is not None else None, x.target_len,
-                           x.target_start, x.target_end, x.match_len, x.block_len, x.mapq, bool(x.is_primary), cig, x.NM,
-                           md, cs))
+    nh = int(h.n_hits)
+    off = np.ctypeslib.as_array(h.hit_off, shape=(n_reads + 1,)).tolist()
+    status = np.ctypeslib.as_array(h.status, shape=(max(n_reads, 1),)).tolist()
+    if nh:
+        assert _HIT_DTYPE.itemsize == C.sizeof(_ffi.Hit)
+        rows = np.frombuffer(C.string_at(h.hits, nh * C.sizeof(_ffi.Hit)), dtype=_HIT_DTYPE).tolist()
+        cig = np.ctypeslib.as_array(h.cigar, shape=(max(int(h.n_cigar), 1),)).copy()
+        sbuf = C.string_at(h.str, int(h.n_str)) if h.n_str else b""
+    F = {k: i for i, (k, _t) in enumerate(_ffi.Hit._fields_)}
+    qs, qe, st, rid, tl, ts, te, ml, bl, mq, pr, nm, nc, co, cso, csl, mdo, mdl = (F[k] for k in (
+        "query_start", "query_end", "strand", "rid", "target_len", "target_start", "target_end", "match_len", "block_len", "mapq",
+        "is_primary", "NM", "n_cigar", "cigar_off", "cs_off", "cs_len", "md_off", "md_len"))
+    out = []
+    for i in range(n_reads):
+        if status[i] == _ffi.MM355_EEMPTY:
+            out.append(RuntimeError("Sequence is empty"))
+            continue
+        ms = []
+        for k in range(off[i], off[i + 1]):
+            x = rows[k]
+            cs = sbuf[x[cso]:x[cso] + x[csl]].decode() if x[csl] >= 0 else None
+            md = sbuf[x[mdo]:x[mdo] + x[mdl]].decode() if x[mdl] >= 0 else None
+            ms.append(Mapping(x[qs], x[qe], x[st], names[x[rid]], x[tl], x[ts], x[te], x[ml], x[bl], x[mq], bool(x[pr]),
+                              cig[x[co]:x[co] + x[nc]], x[nm], md, cs))
+        out.append(ms)
     return out
 
 
@@ -126,6 +164,8 @@ class Aligner:
         self._L = L
         self._idx = C.c_void_p()
         self._ctx = C.c_void_p()
+        self._wctx = []                      # contexts of the map_batch pipeline workers (one per host thread)
+        self._name_cache = None
         self._device = device
         self._n_threads = 0
         self._lock = threading.Lock()
@@ -215,26 +255,36 @@ class Aligner:
                 raise RuntimeError("mm355: " + self._L.mm355_strerror(rc).decode())
         return self._ctx
 
-    def _map_many(self, seqs, flags):
-        """one mm355_map_batch call; returns list of list[Mapping]"""
+    def _map_many(self, seqs, flags, ctx=None):
+        """one mm355_map_batch call; returns list of list[Mapping].  ctx: a pipeline worker's own context (no lock needed)"""
         L = self._L
         arr, lens, keep = _ffi.pack_reads(seqs)
         hp = C.POINTER(_ffi.Hits)()
-        with self._lock:
-            rc = L.mm355_map_batch(self._context(), C.byref(self._mo), len(seqs), arr, lens, flags, C.byref(hp))
+        if ctx is None:
+            with self._lock:
+                rc = L.mm355_map_batch(self._context(), C.byref(self._mo), len(seqs), arr, lens, flags, C.byref(hp))
+        else:
+            rc = L.mm355_map_batch(ctx, C.byref(self._mo), len(seqs), arr, lens, flags, C.byref(hp))
         if rc != 0:
             raise RuntimeError(L.mm355_strerror(rc).decode())
         try:
-            h = hp.contents
-            out = []
-            for i in range(len(seqs)):
-                if h.status[i] == _ffi.MM355_EEMPTY:
-                    out.append(RuntimeError("Sequence is empty"))
-                else:
-                    out.append(_hits_to_mappings(L, self._idx, hp, h.hit_off[i], h.hit_off[i + 1]))
-            return out
+            return _batch_to_mappings(hp, len(seqs), self._names())
         finally:
             L.mm355_free_hits(hp)
+
+    def _names(self):
+        if self._name_cache is None:
+            self._name_cache = [nm.decode() if nm is not None else None for nm in (self._L.mm355_index_seq_name(self._idx, i) for i in range(self.n_seq))]
+        return self._name_cache
+
+    def _worker_contexts(self, n):
+        while len(self._wctx) < n:
+            ctx = C.c_void_p()
+            rc = self._L.mm355_ctx_create(self._idx, self._device, C.byref(ctx))
+            if rc != 0:
+                raise RuntimeError(self._L.mm355_strerror(rc).decode())
+            self._wctx.append(ctx)
+        return self._wctx[:n]
 
     # ---- single read (lib.rs:473-514)
     def map(self, seq, seq2=None, cs=False, MD=False):
@@ -257,8 +307,8 @@ class Aligner:
 
     # ---- batch path (lib.rs:541-648, 771-906)
     def enable_threading(self, n_threads):
-        """In the reference this spawns N mm_map worker threads; here it arms the GPU batch path.
-        n_threads is kept for API parity (it bounds nothing: one context drives one GPU)."""
+        """In the reference this spawns N mm_map worker threads; here it arms the GPU batch path: map_batch drives up to
+        min(n_threads, 8) host threads, each with its own context (HIP streams + buffers) on the one GPU."""
         self._n_threads = int(n_threads)
 
     def map_batch(self, seqs, back_off=True):
@@ -283,19 +333,50 @@ class Aligner:
                                    "Is your fastq batch larger than 50000? Perhaps try `map_batch` with back_off=True?")
             items.append(item)
             reads.append(s)
-        results = []
-        # the whole iterable is consumed before the first result is yielded (lib.rs:845-903); batches bound device memory
-        step_bases, lo = 64_000_000, 0
+        # The whole iterable is consumed before the first result is yielded (lib.rs:845-903).  The reads then go through the GPU in
+        # sub-batches of a few thousand reads: `n_threads` host threads (enable_threading; at most 8 are useful) each drive their own
+        # context, so that the front kernels, the host tail and the extension rounds of different sub-batches overlap.
+        subs, lo = [], 0
         while lo < len(reads):
             hi, nb = lo, 0
-            while hi < len(reads) and (hi == lo or nb + len(reads[hi]) <= step_bases) and hi - lo < WORK_QUEUE_CAP:
+            while hi < len(reads) and (hi == lo or nb + len(reads[hi]) <= SUB_BATCH_BASES) and hi - lo < SUB_BATCH_READS:
                 nb += len(reads[hi]); hi += 1
-            maps = self._map_many(reads[lo:hi], _ffi.OUT_CS)          # cs=true, MD=false: lib.rs:589-590
+            subs.append((lo, hi))
+            lo = hi
+        n_workers = max(1, min(self._n_threads, 8, len(subs)))
+        out = [None] * len(subs)
+        if n_workers == 1:
+            for k, (a, b) in enumerate(subs):
+                out[k] = self._map_many(reads[a:b], _ffi.OUT_CS)      # cs=true, MD=false: lib.rs:589-590
+        else:
+            ctxs = self._worker_contexts(n_workers)
+            nxt = [0]
+            pick = threading.Lock()
+            errors = []
+
+            def work(ctx):
+                while True:
+                    with pick:
+                        k = nxt[0]; nxt[0] += 1
+                    if k >= len(subs) or errors:
+                        return
+                    a, b = subs[k]
+                    try:
+                        out[k] = self._map_many(reads[a:b], _ffi.OUT_CS, ctx)
+                    except Exception as e:   # surfaced after the join, like a worker panic in the reference
+                        errors.append(e)
+                        return
+            ths = [threading.Thread(target=work, args=(ctx,)) for ctx in ctxs]
+            for t in ths: t.start()
+            for t in ths: t.join()
+            if errors:
+                raise errors[0]
+        results = []
+        for (a, b), maps in zip(subs, out):
             for j, m in enumerate(maps):
                 if isinstance(m, Exception):
                     continue                                          # worker error => no result for that id (lib.rs:621-623)
-                results.append((m, items[lo + j]))
-            lo = hi
+                results.append((m, items[a + j]))
         return AlignmentBatchResultIter(results)
 
     def _stage_runner(self):
@@ -305,6 +386,7 @@ class Aligner:
     def __del__(self):
         try:
             if self._ctx: self._L.mm355_ctx_destroy(self._ctx)
+            for ctx in self._wctx: self._L.mm355_ctx_destroy(ctx)
             if self._idx: self._L.mm355_index_free(self._idx)
         except Exception:
             pass

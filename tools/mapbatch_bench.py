@@ -1,0 +1,18 @@
+"""throughput of the drop-in surface itself (Aligner.map_batch, Python Mapping objects included): python tools/mapbatch_bench.py [reads=32768] [threads=8]"""
+import sys, os, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "mappy-rs_amd"))
+import synthdata as S
+import mappy_rs
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+thr = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+g = S.ecoli_like(1); S.write_fasta("/tmp/mb.fa", g)
+reads, _ = S.make_reads(2, g, n, n50=8000)
+al = mappy_rs.Aligner("/tmp/mb.fa", preset="map-ont")
+al.enable_threading(thr)
+bases = sum(len(r) for r in reads)
+for rep in range(3):
+    t0 = time.time()
+    it = al.map_batch([{"seq": r, "id": i} for i, r in enumerate(reads)])
+    t1 = time.time()
+    nres = sum(1 for _ in it)
+    print("map_batch(%d reads, %.1f Mbases, %d threads): %.2f s -> %.1f Mbases/s (%d results)" % (n, bases / 1e6, thr, t1 - t0, bases / 1e6 / (t1 - t0), nres), flush=True)
