@@ -127,7 +127,13 @@ __device__ void wave_rs_level_walk(T *a, uint32_t beg, uint32_t end, int s, Key 
 	__syncthreads();
 	for (uint32_t k = lane; k < 256; k += WAVE) L->fend[k] = k < 255? L->fst[k + 1] : nfor;
 	__syncthreads();
-	if (lane == 0) {   // the only sequential part: one step per foreign element, on 1-byte labels
+	unsigned long long ne = 0;
+	for (uint32_t k = lane; k < 256; k += WAVE) ne += __popcll(__ballot(L->cnt[k] != 0));
+	if (ne == 2) {   // two non-empty buckets: closed form, see k_sort_level_mw
+		const uint32_t m = nfor >> 1;
+		for (uint32_t e = lane; e < nfor; e += WAVE) rank[e] = e < m? e : e - m;
+		for (uint32_t k = lane; k < 256; k += WAVE) L->abef[k] = (L->cnt[k] != 0 && L->bb[k] != 0)? m : 0;
+	} else if (lane == 0) {   // the only sequential part: one step per foreign element, on 1-byte labels
 		const bool in_lds = nfor <= lds_cap;
 		for (uint32_t k = 0; k < 256; ++k) {
 			L->abef[k] = L->arr[k];
@@ -592,7 +598,18 @@ __global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const So
 	__syncthreads();
 	if (tid < 256) L.fend[tid] = tid < 255? L.fst[tid + 1] : nfor;
 	__syncthreads();
-	if (tid == 0) {
+	// Two non-empty buckets k1 < k2 (the strand level of every read that maps to both strands -- the level with the most elements):
+	// every cycle is k1 -> k2 -> k1, so the i-th foreign element of either region is the i-th arrival at the other bucket, all arrivals
+	// at k2 precede its turn and none at k1 do.  No walk.
+	if (tid < 256) { const unsigned long long ne = __ballot(L.cnt[tid] != 0); if ((tid & 63) == 0) L.wtot[tid >> 6] = (uint32_t)__popcll(ne); }
+	__syncthreads();
+	const bool two = L.wtot[0] + L.wtot[1] + L.wtot[2] + L.wtot[3] == 2;
+	__syncthreads();
+	if (two) {
+		const uint32_t m = nfor >> 1;   // foreign elements per region
+		for (uint32_t e = tid; e < nfor; e += MW_NT) rank[e] = e < m? e : e - m;
+		if (tid < 256) L.abef[tid] = (L.cnt[tid] != 0 && L.bb[tid] != 0)? m : 0;   // bb != 0: the second of the two regions
+	} else if (tid == 0) {
 		const bool in_lds = nfor <= MW_LAB_CAP;
 		for (uint32_t k = 0; k < 256; ++k) {
 			L.abef[k] = L.arr[k];
