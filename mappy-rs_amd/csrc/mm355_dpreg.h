@@ -119,19 +119,19 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 	if (J > 0) { nx_ = lane_shr1(fx, X); nv_ = lane_shr1(fv, V); nx2_ = lane_shr1(fx2, X2); }
 	else { nx_ = lane_shr1_z(X); nv_ = lane_shr1_z(V); nx2_ = lane_shr1_z(X2); }   // lane 0 of block 0: t-1 = -1, always a boundary value (IS_LO below)
 	if (IS_LO) {   // x[st-1], v[st-1], x2[st-1] are boundary values when that cell was outside the previous anti-diagonal
-		const bool at = g.use_def && lane == g.lane_st;
+		const bool at = lane == g.lane_st;   // (lane_st = -1 when the neighbour's state is to be used: no uniform-bool x lane-mask AND)
 		nx_ = at? k.dx1 : nx_; nv_ = at? g.dv1 : nv_; nx2_ = at? k.dx21 : nx2_;
 	}
 	const uint32_t XT = __builtin_amdgcn_alignbit(X, nx_, 16), VT = __builtin_amdgcn_alignbit(V, nv_, 16), X2T = __builtin_amdgcn_alignbit(X2, nx2_, 16);
 	uint32_t yi = Y, y2i = Y2, ui = U;
 	if (IS_HI) {   // top row (query position 0, only ever in the last active block): y, y2 and u are the boundary values
-		const uint32_t hm = (g.r & 1)? 0xffff0000u : 0xffffu, m = (g.edge && J == g.jq && lane == g.lane_r)? hm : 0u;
+		const uint32_t hm = (g.r & 1)? 0xffff0000u : 0xffffu, m = (lane == (J == g.jq? g.lane_r : -1))? hm : 0u;   // lane_r = -1 without edge
 		yi = bfi(m, k.nqe, yi); y2i = bfi(m, k.nq2e2, y2i); ui = bfi(m, g.edge_u8, ui);
 	}
 	// every lane computes; the six state registers are then overwritten under an EXEC mask (lanes outside [st, en] keep theirs).
 	// The masked writes are one asm block: written as C++ under `if (act)`, or as selects, the compiler copies/selects all six.
 	const int tl = 128 * J + 2 * lane;
-	const bool act = tl >= g.st && tl <= g.en;
+	const bool act = (uint32_t)(tl - g.st) <= (uint32_t)(g.en - g.st);   // st <= tl <= en in one compare
 	const uint32_t z0 = SC;
 	uint32_t a = pk_add(XT, VT), b = pk_add(yi, ui), a2 = pk_add(X2T, VT), b2 = pk_add(y2i, ui);
 	const uint32_t zm = pk_max(pk_max(pk_max(pk_max(z0, a), b), a2), b2);
@@ -227,7 +227,7 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 	if ((r & 63) == 0) R.qv = r + lane < R.qlen? R.query[r + lane] : 0;   // query[r] enters at t = 0
 	g.qc_hi = rdlane(R.qv, r & 63) << 16;
 	g.jq = r >> 7;
-	g.lane_st = (st & 127) >> 1; g.lane_r = (r & 127) >> 1;
+	g.lane_st = g.use_def? (st & 127) >> 1 : -1; g.lane_r = g.edge? (r & 127) >> 1 : -1;
 	g.prow = (size_t)r * R.n_col - st;
 	const int jsh = (sce - 1) >> 7;
 	// 1. the query moves (descending: block J takes the last cell of block J-1 before that one moves); blocks beyond t = r hold zeros
