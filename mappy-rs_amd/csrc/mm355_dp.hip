@@ -521,7 +521,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
 	if (c->dp_up_ev == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_up_ev, hipEventDisableTiming));
 	HIPCHK(hipEventRecord(c->dp_up_ev, c->st));   // the group streams start after the uploads
-	if (take_turns) turn.lock(my_turn, turn_cap); // uploads are already on their way when the turn starts
+	// everything this round depends on (code-string gather, descriptor uploads) is finished BEFORE the turn is taken: the turn then holds
+	// nothing but extension kernels
+	if (take_turns) { HIPCHK(mm355_wait_stream(c->st)); turn.lock(my_turn, turn_cap); }
 	t_turn0 = mm355_now_ms();
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
