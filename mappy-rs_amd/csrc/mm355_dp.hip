@@ -536,9 +536,18 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			const DpClass &k = classes[g >> 1];
 			const int sidx = !few_streams? g : (g >= 8? 3 + (g - 8) : (g & 1)? 1 : g >= 4? 2 : 0);   // the eight-wave classes are latency chains: one stream each
 			hipStream_t gst;
-			if (c->dp_st[sidx] == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[sidx], hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[sidx], hipStreamNonBlocking)); }
+			// MM355_DP_GLOBAL_STREAMS=1: the extension streams are shared by all contexts of the device (only the context that holds the turn
+			// uses them), which keeps the number of streams competing for hardware queues small
+			static const bool global_st = [] { const char *e = getenv("MM355_DP_GLOBAL_STREAMS"); return e && atoi(e) != 0; }();
+			static hipStream_t g_st[16][16] = {};
+			static std::mutex g_st_mu;
+			hipStream_t *slot = global_st? &g_st[c->dev & 15][sidx] : &c->dp_st[sidx];
+			if (*slot == 0) {
+				std::lock_guard<std::mutex> lk(g_st_mu);
+				if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
+			}
 			if (c->dp_ev[g] == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming));
-			gst = c->dp_st[sidx];
+			gst = *slot;
 			HIPCHK(hipStreamWaitEvent(gst, c->dp_up_ev, 0));
 			if (c->dp_ev0[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev0[g]));
 			if (c->dp_ev1[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev1[g]));
@@ -568,7 +577,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// copies, overlaps the next context's round
 		// (only the wide register-kernel grids count: the few long alignments of the eight-wave classes are latency chains that
 		// leave the GPU almost empty; they keep running while the next context's round starts)
-		if (take_turns) { HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); mm355_trace_add(c, "dpk", t_turn0, mm355_now_ms()); }
+		if (take_turns) { const double tl1 = mm355_now_ms(); HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); const double tl2 = mm355_now_ms(); mm355_trace_add(c, "dpk", t_turn0, tl2); mm355_trace_add(c, "dpk_launch", t_turn0, tl1); }
 		for (int g = 0; g < DP_N_GROUP; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,

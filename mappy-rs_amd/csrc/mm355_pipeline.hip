@@ -6,6 +6,7 @@
 #include <string.h>
 #include <algorithm>
 #include <numeric>
+#include <mutex>
 #include "mm355_pipeline.h"
 
 // ------------------------------------------------------------------ options -> kernel parameters
@@ -61,6 +62,15 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		if (use_prio && hi < lo) HIPCHK(hipStreamCreateWithPriority(&c->st, hipStreamDefault, hi));
 		else HIPCHK(hipStreamCreate(&c->st));
 		c->prio_low = use_prio && hi < lo? lo : 0; c->prio_high = use_prio && hi < lo? hi : 0; c->use_prio = use_prio && hi < lo;
+		// The four streams of the wide extension classes are created here, back to back under a lock: the runtime hands out hardware
+		// queues round-robin at stream creation, and the classes of one context must not share a queue (they would run one after the
+		// other: +6 ms on a 16 ms round when contexts created their streams concurrently on first use).
+		static std::mutex mk;
+		std::lock_guard<std::mutex> lk(mk);
+		for (int i = 0; i < 4; ++i) {
+			if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, c->prio_low));
+			else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[i], hipStreamNonBlocking));
+		}
 	}
 	HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
 	if (mi->dev_resident) {   // built on this device: the table is already in HBM
