@@ -114,9 +114,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="ecoli")
-    ap.add_argument("--reads", type=int, default=262144, help="reads per step per GPU")
+    ap.add_argument("--reads", type=int, default=131072, help="reads per step per GPU")
     ap.add_argument("--streams", type=int, default=8, help="host threads per GPU, each driving its own contexts (HIP streams + buffers)")
-    ap.add_argument("--depth", type=int, default=8, help="sub-batches each stream maps one after the other within a step")
+    ap.add_argument("--depth", type=int, default=4, help="sub-batches each stream maps one after the other within a step")
     ap.add_argument("--scale", type=float, default=1.0, help="genome scale of the human workload")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
