@@ -52,6 +52,13 @@ def make_workload(name, n_reads, rank, scale=1.0):
         log("[bench] synthetic E. coli-like genome + %d reads in %.1fs" % (n_reads, time.time() - t0))
         return g, ["chrE"], reads, dict(workload="configs[1]: synthetic 4.64 Mbp E. coli-like genome (seed 1), map-ont k15 w10, "
                                                  "synthetic ONT reads N50~8kb 6% error (seed 2)", preset="map-ont")
+    if name == "ecoli-hifi":   # BASELINE configs[4] shape (HiFi reads, map-hifi k19 w19) on the E. coli-like genome
+        t0 = time.time()
+        g = S.make_genome(1, [4641652], gc=0.508, repeats=((5000, 7, 0.01), (1300, 20, 0.01)))
+        reads, _ = S.make_reads(rank_read_seed(rank) + 4, g, n_reads, n50=18000, sigma=0.3, lo=5000, hi=60000, sub=0.001, ins=0.0005, dele=0.0005)
+        log("[bench] synthetic E. coli-like genome + %d HiFi-like reads in %.1fs" % (n_reads, time.time() - t0))
+        return g, ["chrE"], reads, dict(workload="configs[4] shape: synthetic 4.64 Mbp E. coli-like genome (seed 1), map-hifi k19 w19, "
+                                                 "synthetic HiFi reads N50~18kb 0.2% error (seed 6)", preset="map-hifi")
     if name == "human":
         t0 = time.time()
         g, names = S.make_human_like(3, scale, log=log)
