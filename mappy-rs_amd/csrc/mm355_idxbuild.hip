@@ -121,6 +121,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 {
 	*out = 0;
 	if (n_seq <= 0) return MM355_EINVAL;
+	if (io->k <= 0 || io->k > 28 || io->w <= 0 || io->w >= 256) return MM355_EINVAL;   // U:sketch.c::mm_sketch asserts the same ranges (e.g. options never initialised with mm355_set_opt(NULL, ..))
 	if (io->flag & 1) return MM355_EUNSUP;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) return MM355_ENODEV;
@@ -145,7 +146,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 	int rc = 0;
 	uint64_t n = 0;
 	void *dS = 0;
-#define FAIL(code) do { rc = (code); goto done; } while (0)
+#define FAIL(code) do { rc = (code); if (getenv("MM355_VERBOSE")) fprintf(stderr, "[mm355] index build failed at %s:%d (%s)\n", __FILE__, __LINE__, hipGetErrorString(hipGetLastError())); goto done; } while (0)
 	if (hipMalloc(&dS, Sw * 4) != hipSuccess) FAIL(MM355_ENOMEM);
 	(void)hipMemsetAsync(dS, 0, Sw * 4, st);
 	if (d_seq.ensure((size_t)max_len + 64) || d_slots16.ensure(((size_t)max_len + 64) * 16) || d_cn.ensure((max_chunks + 1) * 4) || d_co.ensure((max_chunks + 1) * 4) ||
@@ -161,6 +162,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		hipLaunchKernelGGL(k_pack4, GRID((len >> 3) + 2, 256), dim3(256), 0, st, d_seq.as<uint8_t>(), len, mi->seq_off[i], (uint32_t*)dS);
 		hipLaunchKernelGGL(k_sketch_contig, GRID(nch, WAVE), dim3(WAVE), (size_t)mi->w * WAVE * sizeof(mm128), st, d_seq.as<uint8_t>(), (int)len, mi->w, mi->k, nch,
 		                   d_slots16.as<mm128>(), d_cn.as<int32_t>());
+		if (hipGetLastError() != hipSuccess) FAIL(MM355_EHIP);   // k_pack4 / k_sketch_contig launch
 		size_t tb = 0;
 		(void)rocprim::exclusive_scan(nullptr, tb, d_cn.as<uint32_t>(), d_co.as<uint32_t>(), 0u, (size_t)nch + 1, rocprim::plus<uint32_t>(), st);
 		if (d_tmp.ensure(tb + 256)) FAIL(MM355_ENOMEM);
@@ -168,9 +170,11 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		if (rocprim::exclusive_scan(d_tmp.p, tb, d_cn.as<uint32_t>(), d_co.as<uint32_t>(), 0u, (size_t)nch + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) FAIL(MM355_EHIP);
 		hipLaunchKernelGGL(k_gather_pairs, dim3((unsigned)nch), dim3(WAVE), 0, st, d_slots16.as<mm128>(), d_cn.as<int32_t>(), d_co.as<uint32_t>(), nch, (uint32_t)i,
 		                   d_keys.as<uint64_t>(), d_vals.as<uint64_t>(), n, cap, d_err.as<int>());
+		if (hipGetLastError() != hipSuccess) FAIL(MM355_EHIP);   // k_gather_pairs launch
 		uint32_t tot = 0;
 		if (hipMemcpyAsync(&tot, d_co.as<uint32_t>() + nch, 4, hipMemcpyDeviceToHost, st) != hipSuccess) FAIL(MM355_EHIP);
 		if (hipStreamSynchronize(st) != hipSuccess) FAIL(MM355_EHIP);
+		if (getenv("MM355_VERBOSE") && i < 4) fprintf(stderr, "[mm355] contig %d: len %lld, %d chunks, %u minimizers\n", i, (long long)len, nch, tot);
 		n += tot;
 		if (n > cap) FAIL(MM355_ENOMEM);
 	}
@@ -189,7 +193,8 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		size_t tb = 0;
 		(void)rocprim::radix_sort_pairs(nullptr, tb, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_vals.as<uint64_t>(), d_vals2.as<uint64_t>(), (size_t)n, 0u, (unsigned)(2 * mi->k), st);
 		if (d_tmp.ensure(tb + 256)) FAIL(MM355_ENOMEM);
-		if (rocprim::radix_sort_pairs(d_tmp.p, tb, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_vals.as<uint64_t>(), d_vals2.as<uint64_t>(), (size_t)n, 0u, (unsigned)(2 * mi->k), st) != hipSuccess) FAIL(MM355_EHIP);
+		{ hipError_t e = rocprim::radix_sort_pairs(d_tmp.p, tb, d_keys.as<uint64_t>(), d_keys2.as<uint64_t>(), d_vals.as<uint64_t>(), d_vals2.as<uint64_t>(), (size_t)n, 0u, (unsigned)(2 * mi->k), st);
+		  if (e != hipSuccess) { if (getenv("MM355_VERBOSE")) fprintf(stderr, "[mm355] radix_sort_pairs(n=%lld, tmp=%zu): %s\n", (long long)n, tb, hipGetErrorString(e)); FAIL(MM355_EHIP); } }
 		if (hipStreamSynchronize(st) != hipSuccess) FAIL(MM355_EHIP);
 		IB_LOG("radix sort");
 		d_keys.release(); d_vals.release();

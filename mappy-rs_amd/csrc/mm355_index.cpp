@@ -314,6 +314,7 @@ extern "C" int mm355_index_build(const mm355_idxopt_t *io, int n_seq, const char
 {
 	*out = 0;
 	if (n_seq <= 0) return MM355_EINVAL;
+	if (io->k <= 0 || io->k > 28 || io->w <= 0 || io->w >= 256) return MM355_EINVAL;   // U:sketch.c::mm_sketch asserts the same ranges
 	if (io->flag & 1) return MM355_EUNSUP;
 	mm355_index *mi = build_from_seqs(io, n_seq, seqs, lens, names, n_threads);
 	if (mi == 0) return MM355_EINVAL;

@@ -337,3 +337,48 @@ def test_full_size_properties(built, tmp_path):
         assert n_hits >= 8000 and n_right >= 0.97 * len(reads)                 # (5)
     finally:
         L.mm355_ctx_destroy(ctx)
+
+
+def test_repeat_rich_genome_device_index_parity(built, tmp_path):
+    """GRCh38-like miniature (24 contigs, SINE/LINE/satellite families, N runs; 12 Mbp): index built ON THE DEVICE from memory vs the
+    oracle's index from the FASTA; full records of repeat-rich reads -- thousands of anchors per read, equal-key ties, the block-level
+    and the segmented-sort paths -- must equal the oracle's"""
+    from mappy_rs import _ffi
+    import mappy_rs
+    L = _ffi.lib()
+    g, names = S.make_human_like(3, 0.004)
+    fa = str(tmp_path / "mini.fa")
+    S.write_fasta(fa, g, names)
+    reads, _ = S.make_reads(4, g, 160, n50=6000, lo=500)
+    io, mo = _ffi.IdxOpt(), _ffi.MapOpt()
+    L.mm355_set_opt(None, C.byref(io), C.byref(mo))                      # defaults first, then the preset (as mm_set_opt is used upstream)
+    _ffi.check(L.mm355_set_opt(b"map-ont", C.byref(io), C.byref(mo))); mo.flag |= 4
+    ptrs = (C.c_char_p * len(g))(*[C.cast(c.ctypes.data, C.c_char_p) for c in g])
+    lens = (C.c_int64 * len(g))(*[len(c) for c in g]); nm = (C.c_char_p * len(g))(*[n.encode() for n in names])
+    idx = C.c_void_p()
+    _ffi.check(L.mm355_index_build_device(C.byref(io), len(g), ptrs, lens, nm, 0, C.byref(idx)))
+    L.mm355_mapopt_update(C.byref(mo), idx)
+    orc = O.OracleAligner(fa, preset="map-ont")
+    ctx = C.c_void_p()
+    _ffi.check(L.mm355_ctx_create(idx, 0, C.byref(ctx)))
+    try:
+        rarr, rlens, keep = _ffi.pack_reads(reads)
+        hp = C.POINTER(_ffi.Hits)()
+        _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(reads), rarr, rlens, 1, C.byref(hp)))
+        got = mappy_rs._batch_to_mappings(hp, len(reads), names)
+        L.mm355_free_hits(hp)
+        st = _ffi.Stats(); L.mm355_get_stats(ctx, C.byref(st))
+        assert st.n_a / len(reads) > 800, "the miniature must be repeat-rich (anchors per read: %.0f)" % (st.n_a / len(reads))
+        n_hits = 0
+        for i in range(0, len(reads), 2):
+            exp = orc.map(reads[i], cs=True)
+            assert len(got[i]) == len(exp), (i, len(got[i]), len(exp))
+            for m, e in zip(got[i], exp):
+                assert (m.target_name, m.target_start, m.target_end, m.query_start, m.query_end, m.strand, m.mapq, m.is_primary, m.NM, m.cigar_str, m.cs) == \
+                       (e["target_name"], e["target_start"], e["target_end"], e["query_start"], e["query_end"], e["strand"], e["mapq"], e["is_primary"],
+                        e["NM"], e["cigar_str"], e["cs"]), i
+                n_hits += 1
+        assert n_hits > 60
+    finally:
+        L.mm355_ctx_destroy(ctx)
+        L.mm355_index_free(idx)
