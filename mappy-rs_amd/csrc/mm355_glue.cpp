@@ -786,6 +786,17 @@ static void est_err(const mm355_index *mi, int qlen, int n_regs, Reg *regs, cons
 	}
 }
 
+// ================================================================== stage 0 (MM_F_RMQ presets only: asm5/asm10/asm20)
+// U:map.c::mm_map_frag with MM_F_RMQ: the *primary* chainer is mg_lchain_rmq over all sorted anchors of the read (not
+// mg_lchain_dp).  Its AVL-tree walk is strictly sequential per read (tree shape decides ties), so it stays in this
+// host-resident tail like the long-join re-chain; rs.a holds the read's sorted anchors on entry.
+void mm355_glue_chain_rmq(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs)
+{
+	const float pen_gap = (float)(opt->chain_gap_scale * 0.01 * mi->k), pen_skip = (float)(opt->chain_skip_scale * 0.01 * mi->k);
+	rechain_rmq(opt->max_gap, opt->rmq_inner_dist, opt->bw, opt->max_chain_skip, opt->rmq_size_cap, opt->min_cnt, opt->min_chain_score,
+	            pen_gap, pen_skip, rs.a, rs.u);
+}
+
 // ================================================================== stage 1: after the chain kernels
 void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs)
 {

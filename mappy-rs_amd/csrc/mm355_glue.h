@@ -73,6 +73,8 @@ struct ReadState {
 
 struct GlueStats { int64_t n_rmq = 0, n_rounds = 0, n_jobs = 0; };
 
+// stage 0, MM_F_RMQ only: rs.a = the read's sorted anchors -> chained anchors + rs.u (U:lchain.c::mg_lchain_rmq as primary chainer)
+void mm355_glue_chain_rmq(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs);
 // stage 1 (after the chain kernels): re-chain (if triggered), regions, pre-DP selection; leaves rs.regs ready for DP
 void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs);
 // stage 2: advance the skeleton of one read as far as cached DP results allow; appends missing DP problems to `reqs`.

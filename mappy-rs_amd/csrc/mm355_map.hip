@@ -268,6 +268,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	std::vector<const char*> seqs(n_reads);
 	for (int64_t i = 0; i < n_reads; ++i) seqs[i] = (const char*)&c->hb.seq[c->hb.roff[i]];
 	const bool verbose = getenv("MM355_VERBOSE") != 0;
+	const bool rmq_chain = (mo->flag & MMF_RMQ) != 0;
 	double tv0 = now_ms(), tv_front, tv_pack, tv_pre, tv_steps = 0, tv_dp = 0, tv_fin, tv_asm;
 	{
 		double ts = now_ms();
@@ -276,8 +277,11 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		FRONT_STAGE("f:seeds", mm355_run_seeds(c, pr));
 		FRONT_STAGE("f:expand", mm355_run_expand(c, pr));
 		FRONT_STAGE("f:sort", mm355_run_sort(c));
-		FRONT_STAGE("f:chain", mm355_run_chain(c, pr));
-		FRONT_STAGE("f:backtrack", mm355_run_backtrack(c, pr));
+		if (rmq_chain) FRONT_STAGE("f:chain", mm355_run_chain_skip(c));   // asm presets: chained on the host from the sorted anchors
+		else {
+			FRONT_STAGE("f:chain", mm355_run_chain(c, pr));
+			FRONT_STAGE("f:backtrack", mm355_run_backtrack(c, pr));
+		}
 		FRONT_STAGE("f:codes", mm355_run_read_codes(c));
 #undef FRONT_STAGE
 	}
@@ -321,7 +325,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		r.u.assign(pu + uo[i], pu + uo[i + 1]);
 		r.a.assign(pa + vo[i], pa + vo[i + 1]);
 		r.mini_pos.assign(pm + mo_[i], pm + mo_[i + 1]); }
-		if (r.qlen > 0) mm355_glue_pre_align(mi, mo, r); else r.aligned = true;
+		if (r.qlen > 0) { if (rmq_chain) mm355_glue_chain_rmq(mi, mo, r); mm355_glue_pre_align(mi, mo, r); } else r.aligned = true;
 	});
 	double ms_host = now_ms() - t_host0;
 	tv_pre = now_ms() - tv0; trace_add(c, "pre", tv0, now_ms());

@@ -82,6 +82,7 @@ int mm355_run_expand(mm355_ctx *ctx, const DevParams &pr);
 int mm355_run_sort(mm355_ctx *ctx);
 int mm355_run_chain(mm355_ctx *ctx, const DevParams &pr);
 int mm355_run_backtrack(mm355_ctx *ctx, const DevParams &pr);
+int mm355_run_chain_skip(mm355_ctx *c);
 
 // time one launch group on the context's stream with HIP events (the stream the kernels are launched on)
 struct EvTimer {

@@ -324,6 +324,19 @@ int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
 	return 0;
 }
 
+// MM_F_RMQ presets: no device chaining -- every sorted anchor of the read goes to the host chainer (mm355_glue_chain_rmq)
+int mm355_run_chain_skip(mm355_ctx *c)
+{
+	HostBatch &hb = c->hb;
+	const int64_t n = hb.n_reads;
+	hb.n_u.assign(n, 0); hb.n_v = hb.n_a;
+	if (n) {
+		HIPCHK(hipMemsetAsync(c->n_u.p, 0, n * 4, c->st));
+		HIPCHK(hipMemcpyAsync(c->n_v.p, c->n_a.p, n * 4, hipMemcpyDeviceToDevice, c->st));
+	}
+	return check_err(c);
+}
+
 int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);

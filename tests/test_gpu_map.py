@@ -101,6 +101,27 @@ def test_map_parity_hifi(built, tmp_path):
     assert n_hits >= 40
 
 
+@pytest.mark.parametrize("preset", ["asm20", "asm10", "asm5", "ava-ont"])
+def test_map_parity_other_presets(built, tmp_path, preset):
+    """asm*: MM_F_RMQ makes mg_lchain_rmq the primary chainer (host-resident, from the device-sorted anchors), bw 1000 / bw_long 100000,
+    heavier gap costs; ava-ont: all chains kept, no long-join, bw 2000 (qname is NULL through the reference, so NO_DIAG/NO_DUAL are inert)"""
+    import mappy_rs
+    g = S.make_genome(81, [350000, 150000], repeats=((4000, 4, 0.01), (900, 12, 0.02)), n_runs=2)
+    fa = str(tmp_path / "p.fa")
+    S.write_fasta(fa, g, ["ctgA", "ctgB"])
+    div = {"asm5": 0.002, "asm10": 0.008, "asm20": 0.02, "ava-ont": 0.03}[preset]
+    reads, _ = S.make_reads(82, g, 48, n50=15000, lo=1500, sub=div, ins=div / 4, dele=div / 4)
+    rng = np.random.default_rng(83)
+    for _ in range(6):   # contigs with a large indel: several chains that the long-join / RMQ pass has to bridge
+        a0 = int(rng.integers(0, 300000))
+        c = np.concatenate([g[0][a0:a0 + 9000], g[0][a0 + 9000 + 2500:a0 + 20000]])
+        reads.append(S.codes_to_str(S.mutate(c, rng, div, div / 4, div / 4)))
+    al = mappy_rs.Aligner(fa, preset=preset)
+    orc = O.OracleAligner(fa, preset=preset)
+    n_hits, _ = check_reads(al, orc, reads)
+    assert n_hits >= 50
+
+
 def test_map_parity_option_overrides(ont):
     import mappy_rs
     kw = dict(preset="map-ont", best_n=2, min_chain_score=60, bw=300, scoring=(2, 5, 5, 3, 20, 1))
