@@ -1080,7 +1080,30 @@ static void fix_cigar(Reg *r, const uint8_t *qseq, const uint8_t *tseq, int *qsh
 static void gen_cs(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::string &s);
 static void gen_md(const Reg *r, const uint8_t *qseq, const uint8_t *tseq, std::string &s);
 
-static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int out_flags = 0)
+// U:align.c::mm_update_cigar_eqx (MM_F_EQX): every M becomes alternating runs of '=' (7) and 'X' (8); N vs N counts as '='
+static void cigar_eqx(Reg *r, const uint8_t *qseq, const uint8_t *tseq)
+{
+	std::vector<uint32_t> &cg = r->p->cigar, nc;
+	nc.reserve(cg.size() * 2);
+	uint32_t toff = 0, qoff = 0, l;
+	for (size_t k = 0; k < cg.size(); ++k) {
+		uint32_t op = cg[k] & 0xf, len = cg[k] >> 4;
+		if (op == 0) {
+			while (len > 0) {
+				for (l = 0; l < len && qseq[qoff + l] == tseq[toff + l]; ++l) {}
+				if (l > 0) { nc.push_back(l << 4 | 7); len -= l; toff += l; qoff += l; }
+				for (l = 0; l < len && qseq[qoff + l] != tseq[toff + l]; ++l) {}
+				if (l > 0) { nc.push_back(l << 4 | 8); len -= l; toff += l; qoff += l; }
+			}
+		} else {
+			if (op == 1) qoff += len; else if (op == 2 || op == 3) toff += len;
+			nc.push_back(cg[k]);
+		}
+	}
+	cg.swap(nc);
+}
+
+static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int out_flags, bool eqx)
 {
 	int32_t qshift, tshift, toff = 0, qoff = 0;
 	double s = 0.0, max = 0.0;
@@ -1145,6 +1168,7 @@ static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const
 	ProfScope pf4(PF_X4);
 	if (out_flags & MM355_OUT_CS) { p->cs.clear(); gen_cs(r, qseq, tseq, p->cs); }
 	if (out_flags & MM355_OUT_MD) { p->md.clear(); gen_md(r, qseq, tseq, p->md); }
+	if (eqx) cigar_eqx(r, qseq, tseq);   // after cs/MD: both read M, '=' and 'X' alike (U:format.c::write_cs_core / write_MD_core)
 }
 
 static int *collect_long_gaps(int as1, int cnt1, const mm128 *a, int min_gap, int *n_, std::vector<int> &K)
@@ -1466,7 +1490,7 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 		r->p = new Extra(tmp);
 		tseq.resize((size_t)(re1 - rs1) + 1);
 		getseq(mi, (uint32_t)rid, rs1, re1, tseq.data()); }
-		update_extra(r, rs.qc[r->rev].data() + qs1, tseq.data(), mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags);
+		update_extra(r, rs.qc[r->rev].data() + qs1, tseq.data(), mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags, (opt->flag & MMF_EQX) != 0);
 	}
 	return true;
 }
@@ -1541,7 +1565,7 @@ static int align1_inv(const mm355_index *mi, const mm355_mapopt_t *opt, int read
 	else { r_inv->qe = r2->qs - q_off; r_inv->qs = r_inv->qe - (ez.max_q + 1); }
 	r_inv->rs = r1->re + t_off;
 	r_inv->re = r_inv->rs + ez.max_t + 1;
-	update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags);
+	update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags, (opt->flag & MMF_EQX) != 0);
 	return 1;
 }
 

@@ -165,7 +165,41 @@ static void mm_fix_cigar(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *tseq
 	}
 }
 
-static void mm_update_extra(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int log_gap)
+/* U:align.c::mm_update_cigar_eqx (MM_F_EQX): every M becomes alternating runs of '=' (7) and 'X' (8); N vs N counts as '='.
+ * Upstream rewrites in place when every M is a single '=' run and rebuilds the array otherwise -- the resulting CIGAR is the same. */
+static void mm_update_cigar_eqx(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *tseq)
+{
+	uint32_t k, l, n_new = 0, toff = 0, qoff = 0, *nc;
+	mmo_extra_t *p = r->p, *np;
+	uint32_t capacity;
+	if (p == 0) return;
+	nc = (uint32_t*)malloc(((size_t)(r->qe - r->qs) + p->n_cigar + 1) * 4); /* at most one op per query base + the non-M ops */
+	for (k = 0; k < p->n_cigar; ++k) {
+		uint32_t op = p->cigar[k]&0xf, len = p->cigar[k]>>4;
+		if (op == MM_CIGAR_MATCH) {
+			while (len > 0) {
+				for (l = 0; l < len && qseq[qoff + l] == tseq[toff + l]; ++l) {}
+				if (l > 0) { nc[n_new++] = l << 4 | 7; len -= l; toff += l; qoff += l; }
+				for (l = 0; l < len && qseq[qoff + l] != tseq[toff + l]; ++l) {}
+				if (l > 0) { nc[n_new++] = l << 4 | 8; len -= l; toff += l; qoff += l; }
+			}
+		} else {
+			if (op == MM_CIGAR_INS) qoff += len;
+			else if (op == MM_CIGAR_DEL || op == MM_CIGAR_N_SKIP) toff += len;
+			nc[n_new++] = p->cigar[k];
+		}
+	}
+	capacity = n_new + sizeof(mmo_extra_t)/4;
+	kroundup32(capacity);
+	np = (mmo_extra_t*)calloc(capacity, 4);
+	memcpy(np, p, sizeof(mmo_extra_t));
+	np->capacity = capacity; np->n_cigar = n_new;
+	memcpy(np->cigar, nc, (size_t)n_new * 4);
+	free(nc); free(p);
+	r->p = np;
+}
+
+static void mm_update_extra(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int is_eqx, int log_gap)
 {
 	uint32_t k, l;
 	int32_t qshift, tshift, toff = 0, qoff = 0;
@@ -213,6 +247,7 @@ static void mm_update_extra(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *t
 	}
 	p->dp_max = (int32_t)(max + .499);
 	assert(qoff == r->qe - r->qs && toff == r->re - r->rs);
+	if (is_eqx) mm_update_cigar_eqx(r, qseq, tseq); /* here: the shifts of qseq/tseq are local to this function */
 }
 
 static void mm_append_cigar(mmo_reg1_t *r, uint32_t n_cigar, uint32_t *cigar)
@@ -549,7 +584,7 @@ static void mm_align1(const mmo_mapopt_t *opt, const mmo_idx_t *mi, int qlen, ui
 	assert(re1 - rs1 <= re0 - rs0);
 	if (r->p) {
 		mmo_idx_getseq(mi, rid, rs1, re1, tseq);
-		mm_update_extra(r, &qseq0[r->rev][qs1], tseq, mat, opt->q, opt->e, !(opt->flag & MM_F_SR));
+		mm_update_extra(r, &qseq0[r->rev][qs1], tseq, mat, opt->q, opt->e, !!(opt->flag & MM_F_EQX), !(opt->flag & MM_F_SR));
 	}
 
 	free(tseq);
@@ -603,7 +638,7 @@ static int mm_align1_inv(const mmo_mapopt_t *opt, const mmo_idx_t *mi, int qlen,
 	}
 	r_inv->rs = r1->re + t_off;
 	r_inv->re = r_inv->rs + ez->max_t + 1;
-	mm_update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, opt->q, opt->e, !(opt->flag & MM_F_SR));
+	mm_update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, opt->q, opt->e, !!(opt->flag & MM_F_EQX), !(opt->flag & MM_F_SR));
 	ret = 1;
 end_align1_inv:
 	free(tseq);

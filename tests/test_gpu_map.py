@@ -122,6 +122,18 @@ def test_map_parity_other_presets(built, tmp_path, preset):
     assert n_hits >= 50
 
 
+def test_map_parity_eqx(ont):
+    """extra_flags=MM_F_EQX: '='/'X' CIGAR (U:align.c::mm_update_cigar_eqx)"""
+    import mappy_rs
+    al = mappy_rs.Aligner(ont["fa"], preset="map-ont", extra_flags=0x4000000)
+    orc = O.OracleAligner(ont["fa"], preset="map-ont", extra_flags=0x4000000)
+    reads, _ = S.make_reads(73, ont["g"], 40, n50=4000, lo=500)
+    reads.append("N" * 30 + S.codes_to_str(ont["g"][0][7000:9000]) + "N" * 10)
+    n_hits, _ = check_reads(al, orc, reads)
+    got = al.map(reads[0])
+    assert n_hits >= 40 and "=" in got[0].cigar_str and "M" not in got[0].cigar_str and any(op == 8 for _, op in got[0].cigar)
+
+
 def test_map_parity_option_overrides(ont):
     import mappy_rs
     kw = dict(preset="map-ont", best_n=2, min_chain_score=60, bw=300, scoring=(2, 5, 5, 3, 20, 1))

@@ -131,6 +131,43 @@ def test_map_all_contigs_and_revcomp(al, golden_dir):
         assert len(h) == 1 and h[0]["strand"] == -1 and (h[0]["target_start"], h[0]["target_end"]) == (0, 400)
 
 
+def test_eqx_cigar(golden_dir):
+    """MM_F_EQX (extra_flags=0x4000000, U:align.c::mm_update_cigar_eqx): M is split into '=' / 'X' runs that agree with the
+    sequences; merged back they give the default CIGAR, and every other field is unchanged"""
+    import re
+    fn = os.path.join(golden_dir, "test.mmi")
+    plain, eqx = O.OracleAligner(fn), O.OracleAligner(fn, extra_flags=0x4000000)
+    rng = np.random.default_rng(5)
+    q = list(ENTERO)
+    for pos in rng.choice(len(q) - 40, 9, replace=False) + 20:          # substitutions
+        q[pos] = "ACGT"[("ACGT".index(q[pos]) + 1 + int(rng.integers(0, 3))) % 4]
+    q = "".join(q[:150]) + "TT" + "".join(q[150:260]) + "".join(q[263:])   # an insertion and a deletion
+    a, b = plain.map(q, cs=True, MD=True), eqx.map(q, cs=True, MD=True)
+    assert len(a) == len(b) == 1
+    a, b = a[0], b[0]
+    assert "X" in b["cigar_str"] and "=" in b["cigar_str"] and "M" not in b["cigar_str"]
+    merged, run = [], 0
+    for n, op in re.findall(r"(\d+)([MIDN=X])", b["cigar_str"]):
+        if op in "=X": run += int(n)
+        else:
+            if run: merged.append("%dM" % run); run = 0
+            merged.append(n + op)
+    if run: merged.append("%dM" % run)
+    assert "".join(merged) == a["cigar_str"]
+    for k in a:
+        if k not in ("cigar", "cigar_str"): assert a[k] == b[k], k
+    t = plain.seq(b["target_name"], b["target_start"], b["target_end"])
+    qs = q[b["query_start"]:b["query_end"]]
+    ti = qi = 0
+    for n, op in b["cigar"]:
+        if op == 7: assert t[ti:ti + n] == qs[qi:qi + n]
+        if op == 8: assert all(x != y for x, y in zip(t[ti:ti + n], qs[qi:qi + n]))
+        if op in (0, 7, 8): ti += n; qi += n
+        elif op == 1: qi += n
+        elif op == 2: ti += n
+    assert ti == len(t) and qi == len(qs)
+
+
 def test_errors(al):
     with pytest.raises(RuntimeError, match="Sequence is empty"):
         al.map("")
