@@ -134,6 +134,15 @@ def test_map_parity_eqx(ont):
     assert n_hits >= 40 and "=" in got[0].cigar_str and "M" not in got[0].cigar_str and any(op == 8 for _, op in got[0].cigar)
 
 
+def test_unsupported_flags_fail_loudly(ont):
+    """options outside the long-read path are refused, never mapped with different semantics"""
+    import mappy_rs
+    for fl in (0x80, 0x100, 0x200, 0x1000, 0x100000, 0x200000, 0x400000, 0x100000000):   # SPLICE, SPLICE_FOR/REV, SR, FOR/REV_ONLY, HEAP_SORT, QSTRAND
+        al = mappy_rs.Aligner(ont["fa"], preset="map-ont", extra_flags=fl)
+        with pytest.raises(RuntimeError, match="outside the long-read hot path"):
+            al.map(S.codes_to_str(ont["g"][0][1000:3000]))
+
+
 def test_map_parity_option_overrides(ont):
     import mappy_rs
     kw = dict(preset="map-ont", best_n=2, min_chain_score=60, bw=300, scoring=(2, 5, 5, 3, 20, 1))
