@@ -122,6 +122,65 @@ def test_map_parity_other_presets(built, tmp_path, preset):
     assert n_hits >= 50
 
 
+def test_map_parity_ultra_long_reads(built, tmp_path):
+    """150 kb - 1 Mb reads (ultra-long ONT) and a 430 kb read with an inverted 130 kb block: the block-level sort, the wave-per-segment
+    chainer over very long segments, z-drop splits of one huge chain, and the large-target extension classes"""
+    import mappy_rs
+    g = S.make_genome(91, [1500000], repeats=((6000, 5, 0.01), (1500, 15, 0.02)), n_runs=2)
+    fa = str(tmp_path / "ul.fa")
+    S.write_fasta(fa, g, ["chrU"])
+    rng = np.random.default_rng(92)
+    reads = []
+    for L in (150000, 300000, 650000, 1000000):
+        a0 = int(rng.integers(0, 1500000 - L))
+        reads.append(S.codes_to_str(S.mutate(g[0][a0:a0 + L], rng, 0.024, 0.016, 0.02)))
+    comp = lambda c: np.where(c < 4, 3 - c, 4).astype(np.uint8)[::-1]
+    c = np.concatenate([g[0][100000:260000], comp(g[0][700000:830000]), g[0][262000:400000]])
+    reads.append(S.codes_to_str(S.mutate(c, rng, 0.03, 0.02, 0.02)))
+    al = mappy_rs.Aligner(fa, preset="map-ont")
+    orc = O.OracleAligner(fa, preset="map-ont")
+    n_hits, _ = check_reads(al, orc, reads)
+    assert n_hits >= 7
+
+
+def test_map_parity_adversarial_inputs(built, tmp_path):
+    """low-complexity reference and reads (homopolymer, di-/heptanucleotide repeats: masses of equal sort keys and over-represented
+    minimizers), IUPAC / lower-case / N-rich reads, thousands of small contigs, duplicate and tiny reads, tandem-duplicated loci"""
+    import mappy_rs
+    rng = np.random.default_rng(7)
+    low = [S.random_codes(rng, 20000), np.zeros(30000, np.uint8), np.tile(np.array([0, 1], np.uint8), 10000),
+           np.tile(np.array([0, 1, 2, 3, 3, 1, 0], np.uint8), 4000), S.random_codes(rng, 20000)]
+    g = [np.concatenate(low), S.random_codes(rng, 200000)]
+    fa = str(tmp_path / "adv1.fa")
+    S.write_fasta(fa, g, ["lc", "rnd"])
+    lc = [S.codes_to_str(S.mutate(g[0][a:a + L], rng, 0.02, 0.01, 0.01))
+          for a, L in ((15000, 12000), (19000, 25000), (45000, 15000), (55000, 20000), (60000, 30000), (70000, 40000), (0, 118000))]
+    lc += ["A" * 50000, "AC" * 12000, "ACGTTCA" * 3000]
+    base = S.codes_to_str(g[1][1000:9000])
+    odd = [base.lower(), base[:3000] + "RYKMSWN" * 5 + base[3035:], "".join(c if rng.random() > 0.02 else "N" for c in base),
+           base[:200] + "N" * 3000 + base[3200:], "NNNN" + base[4:60], base[:4000].lower() + base[4000:]]
+    dup = [base[:5000]] * 64 + [base[:n] for n in (1, 14, 15, 16, 24, 25, 26, 39, 40, 41, 64, 100)]
+    loc = g[1][50000:56000]
+    tandem = [S.codes_to_str(S.mutate(np.concatenate([loc, loc, loc]), rng, 0.02, 0.01, 0.01)),
+              S.codes_to_str(S.mutate(np.concatenate([g[1][20000:26000], g[1][23000:30000]]), rng, 0.02, 0.01, 0.01))]
+    al, orc = mappy_rs.Aligner(fa, preset="map-ont"), O.OracleAligner(fa, preset="map-ont")
+    n_hits, _ = check_reads(al, orc, lc + odd + dup + tandem)
+    assert n_hits >= 70
+    kw = dict(preset="map-ont", k=13, w=5, min_chain_score=20, best_n=10)
+    check_reads(mappy_rs.Aligner(fa, **kw), O.OracleAligner(fa, **kw), lc[:7])
+    check_reads(mappy_rs.Aligner(fa, preset="map-hifi"), O.OracleAligner(fa, preset="map-hifi"), tandem + odd[:3])
+    # thousands of small contigs (rid-rich index), reads within one contig and reads joining two
+    gs = [S.random_codes(rng, int(L)) for L in rng.integers(300, 900, 6000)]
+    fa3 = str(tmp_path / "adv3.fa")
+    S.write_fasta(fa3, gs, ["c%d" % i for i in range(len(gs))])
+    r3 = [S.codes_to_str(S.mutate(gs[int(rng.integers(0, len(gs)))], rng, 0.02, 0.01, 0.01)) for _ in range(150)]
+    for _ in range(30):
+        i, j = (int(x) for x in rng.integers(0, len(gs), 2))
+        r3.append(S.codes_to_str(S.mutate(np.concatenate([gs[i], gs[j]]), rng, 0.02, 0.01, 0.01)))
+    n_hits, _ = check_reads(mappy_rs.Aligner(fa3, preset="map-ont"), O.OracleAligner(fa3, preset="map-ont"), r3)
+    assert n_hits >= 170
+
+
 def test_map_parity_eqx(ont):
     """extra_flags=MM_F_EQX: '='/'X' CIGAR (U:align.c::mm_update_cigar_eqx)"""
     import mappy_rs

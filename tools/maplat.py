@@ -11,3 +11,14 @@ for r in reads[20:]:
     n += len(al.map(r, cs=True))
 dt = time.time() - t0
 print("Aligner.map: %.2f ms per read (%d reads, %.1f Mbases/s)" % (dt / 280 * 1e3, 280, sum(len(r) for r in reads[20:]) / dt / 1e6))
+# device time of the stages for the last reads (HIP events around each stage's launches)
+import ctypes as C
+from mappy_rs import _ffi
+acc = {}
+for r in reads[20:120]:
+    al.map(r)
+    st = _ffi.Stats(); al._L.mm355_get_stats(al._ctx, C.byref(st))
+    for f, _ in st._fields_:
+        if f.startswith("ms_") and not f.endswith("group"): acc[f] = acc.get(f, 0.0) + getattr(st, f)
+    acc["n_launch_dp"] = acc.get("n_launch_dp", 0) + st.n_launch_dp
+print("per read: " + "  ".join("%s %.3f" % (k, v / 100) for k, v in acc.items()))
