@@ -19,6 +19,12 @@ int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi)
 	if (mo->max_chain_iter > 8000 || mo->max_chain_iter < 1) return MM355_EUNSUP;    // LDS mark window of k_chain
 	if (mi->w > 64 || mi->k > 28 || mi->k < 1) return MM355_EUNSUP;
 	if (mo->sdust_thres > 0) return MM355_EUNSUP;
+	{   // U:ksw2_extd2_sse.c: "if (-min_sc > 2 * (q + e)) return;" -- the kernel then returns an empty result which U:align.c::mm_align1
+		// dereferences (r->p->dp_score with r->p == NULL: the reference crashes or adds KSW_NEG_INF).  No defined result to reproduce.
+		const int b = mo->b > 0? mo->b : -mo->b, amb = mo->sc_ambi > 0? mo->sc_ambi : -mo->sc_ambi;
+		const int ge1 = mo->q + mo->e, ge2 = mo->q2 + mo->e2;
+		if ((b > amb? b : amb) > 2 * (ge1 < ge2? ge1 : ge2)) return MM355_EINVAL;
+	}
 	return 0;
 }
 

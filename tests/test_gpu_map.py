@@ -202,6 +202,24 @@ def test_unsupported_flags_fail_loudly(ont):
             al.map(S.codes_to_str(ont["g"][0][1000:3000]))
 
 
+def test_option_fuzz_parity(built, tmp_path):
+    """random option sets (presets, k/w, thresholds, scoring tuples, extra_flags) x 24 reads each, bit-exact against the oracle"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("optfuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "optfuzz.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    n_cfg, n_hits, n_bad = fz.run(5, 14, str(tmp_path / "fz.fa"))
+    assert n_bad == 0 and n_hits > 300
+
+
+def test_scoring_outside_ksw2_domain_is_refused(ont):
+    """mismatch (or ambiguity) penalty > 2*(q+e): ksw_extd2_sse returns without aligning and mm_align1 dereferences a NULL r->p upstream
+    -- there is no defined result to be identical to, so the option set is refused instead of crashing"""
+    import mappy_rs
+    al = mappy_rs.Aligner(ont["fa"], preset="map-ont", scoring=(5, 11, 3, 1, 7, 1))
+    with pytest.raises(RuntimeError):
+        al.map(S.codes_to_str(ont["g"][0][1000:3000]))
+
+
 def test_map_parity_option_overrides(ont):
     import mappy_rs
     kw = dict(preset="map-ont", best_n=2, min_chain_score=60, bw=300, scoring=(2, 5, 5, 3, 20, 1))
