@@ -1,5 +1,5 @@
 """option fuzzing of the whole path against the oracle: random presets / k / w / chaining and DP thresholds / scoring tuples / extra_flags,
-24 reads per configuration (ordinary + chimeric).  python tools/optfuzz.py [seed=1] [n_configs=30]   (needs the GPU)"""
+24 reads per configuration (ordinary + chimeric).  python tools/optfuzz.py [seed=1] [n_configs=30] [noisy]   (needs the GPU)"""
 import os
 import sys
 
@@ -37,7 +37,7 @@ def random_config(rng):
     return kw
 
 
-def run(seed, n_configs, fa_path, verbose=False):
+def run(seed, n_configs, fa_path, verbose=False, noisy=False):
     """returns (configurations run, hits compared, mismatching reads)"""
     import mappy_rs
     import synthdata as S
@@ -49,7 +49,8 @@ def run(seed, n_configs, fa_path, verbose=False):
     tot_hits = tot_bad = 0
     for ci in range(n_configs):
         kw = random_config(rng)
-        reads, _ = S.make_reads(int(rng.integers(1, 1 << 30)), g, 20, n50=5000, lo=300)
+        if noisy: reads, _ = S.make_reads(int(rng.integers(1, 1 << 30)), g, 20, n50=9000, lo=300, sub=0.06, ins=0.04, dele=0.05)   # 15 % error
+        else: reads, _ = S.make_reads(int(rng.integers(1, 1 << 30)), g, 20, n50=5000, lo=300)
         for _ in range(4):
             a0, b0 = int(rng.integers(0, 250000)), int(rng.integers(0, 100000))
             c = np.concatenate([g[0][a0:a0 + 2500], comp(g[1][b0:b0 + 2000]), g[0][a0 + 4000:a0 + 6000]])
@@ -75,4 +76,4 @@ if __name__ == "__main__":
     for p in (root, os.path.join(root, "mappy-rs_amd"), os.path.join(root, "tests")): sys.path.insert(0, p)
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-    print("configs %d, hits %d, mismatching reads %d" % run(seed, n, "/tmp/optfuzz.fa", verbose=True))
+    print("configs %d, hits %d, mismatching reads %d" % run(seed, n, "/tmp/optfuzz.fa", verbose=True, noisy=len(sys.argv) > 3 and sys.argv[3] == "noisy"))
