@@ -233,8 +233,14 @@ def main():
         return sum(r[0] for r in res), sum(r[1] for r in res), agg_st
 
     def barrier():
+        # both sides of the timed region: every stream of this rank's GPU drained (the library runs on its own HIP streams, which
+        # torch.cuda.synchronize() would not see unless it synchronises the device -- hipDeviceSynchronize does), then the ranks meet
+        _ffi.check(L.mm355_device_synchronize(local_rank))
         if dist is not None:
+            import torch
+            torch.cuda.synchronize()
             dist.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()

@@ -179,6 +179,7 @@ int mm355_stage_dp(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_jobs, c
 
 int mm355_get_stats(mm355_ctx_t *ctx, mm355_stats_t *st);   /* counters/timers of the last call on ctx */
 int mm355_device_count(void);
+int mm355_device_synchronize(int device_id);                /* drains every stream of the device (hipDeviceSynchronize): bench.py brackets its timed region with it */
 const char *mm355_strerror(int code);
 const char *mm355_version(void);
 

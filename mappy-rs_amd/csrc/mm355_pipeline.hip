@@ -51,6 +51,13 @@ extern "C" int mm355_device_count(void)
 	return n;
 }
 
+extern "C" int mm355_device_synchronize(int device_id)
+{
+	HIPCHK(hipSetDevice(device_id));
+	HIPCHK(hipDeviceSynchronize());
+	return 0;
+}
+
 extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ctx_t **out)
 {
 	*out = 0;

@@ -83,7 +83,7 @@ EXPORTS = [
     "mm355_index_info", "mm355_index_seq_name", "mm355_index_seq_len", "mm355_index_name2id", "mm355_index_getseq",
     "mm355_index_get", "mm355_index_stat", "mm355_ctx_create", "mm355_ctx_destroy", "mm355_map_batch",
     "mm355_free_hits", "mm355_batch_upload", "mm355_batch_select", "mm355_map_resident", "mm355_stage_sketch", "mm355_stage_anchors", "mm355_stage_chain", "mm355_stage_chains",
-    "mm355_stage_dp", "mm355_get_stats", "mm355_device_count", "mm355_strerror", "mm355_version",
+    "mm355_stage_dp", "mm355_get_stats", "mm355_device_count", "mm355_device_synchronize", "mm355_strerror", "mm355_version",
 ]
 
 _LIB = None
@@ -100,6 +100,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, i64p, i32p = C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)
     L.mm355_set_opt.argtypes = [C.c_char_p, C.POINTER(IdxOpt), C.POINTER(MapOpt)]
+    L.mm355_device_synchronize.argtypes = [C.c_int]
     L.mm355_mapopt_update.argtypes = [C.POINTER(MapOpt), vp]
     L.mm355_index_load.argtypes = [C.c_char_p, C.POINTER(IdxOpt), C.c_int, C.POINTER(vp)]
     L.mm355_index_build.argtypes = [C.POINTER(IdxOpt), C.c_int, C.POINTER(C.c_char_p), i64p, C.POINTER(C.c_char_p), C.c_int, C.POINTER(vp)]
