@@ -368,6 +368,12 @@ __device__ inline void heapdown_u64(uint32_t i, uint32_t n, uint64_t *l)
 	l[i] = tmp;
 }
 
+// U:map.c::skip_seed (qname is NULL through the reference, so only the strand filters remain): 1 = the hit becomes an anchor
+__device__ __forceinline__ uint32_t mm355_keep_strand(int64_t flag, bool forward)
+{
+	return forward? !(flag & MMF_REV_ONLY) : !(flag & MMF_FOR_ONLY);
+}
+
 __global__ __launch_bounds__(WAVE) void k_seed_select(DevIndex ix, DevParams pr, DevBatch bt, DevSeeds sd)
 {
 	MM355_LATENCY_KERNEL();
@@ -445,9 +451,18 @@ __global__ __launch_bounds__(WAVE) void k_seed_select(DevIndex ix, DevParams pr,
 			} else rep_en = en;
 		} else {
 			const uint32_t c = sn[j];
+			uint32_t c_eff = c;
+			if (pr.flag & (MMF_FOR_ONLY | MMF_REV_ONLY)) {   // U:map.c::skip_seed: hits of the excluded strand produce no anchor
+				const uint64_t v = sd.sv[off + j];
+				c_eff = 0;
+				for (uint32_t kq = 0; kq < c; ++kq) {
+					const uint64_t rk = c == 1? v : ix.pos[v + kq];
+					c_eff += mm355_keep_strand(pr.flag, (rk & 1) == (q_pos & 1));
+				}
+			}
 			hl[n_kept] = j; soff[n_kept] = n_a;
 			mini_pos[n_kept] = (uint64_t)q_span << 32 | q_pos >> 1;
-			n_a += c; ++n_kept;
+			n_a += c_eff; ++n_kept;
 			if (c > 1) multi += c;
 		}
 	}
@@ -474,8 +489,15 @@ __global__ __launch_bounds__(256) void k_seed_expand(DevIndex ix, DevParams pr, 
 		const mm128 m = mz[j];
 		const uint32_t c = sd.sn[off + j];
 		const uint64_t v = sd.sv[off + j];
-		const uint64_t rk = c == 1? v : ix.pos[v + kq];
 		const uint32_t q_pos = (uint32_t)m.y, q_span = (uint32_t)(m.x & 0xff);
+		uint64_t rk = c == 1? v : ix.pos[v + kq];
+		if ((pr.flag & (MMF_FOR_ONLY | MMF_REV_ONLY)) && c > 1) {   // kq counts the hits of the admitted strand only (k_seed_select)
+			uint32_t seen = 0;
+			for (uint32_t kk = 0; kk < c; ++kk) {
+				rk = ix.pos[v + kk];
+				if (mm355_keep_strand(pr.flag, (rk & 1) == (q_pos & 1)) && seen++ == kq) break;
+			}
+		}
 		const uint32_t rpos = (uint32_t)rk >> 1;
 		bool tandem = (j > 0 && (mz[j-1].x >> 8) == (m.x >> 8)) || (j < nmz - 1 && (mz[j+1].x >> 8) == (m.x >> 8));
 		mm128 o;

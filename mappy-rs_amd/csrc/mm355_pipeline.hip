@@ -14,7 +14,6 @@ int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi)
 {
 	if (mi->flag & 1) return MM355_EUNSUP;                                           // HPC index
 	if (mo->flag & (MMF_SPLICE | 0x100LL | 0x200LL | MMF_SR | MMF_QSTRAND | MMF_HEAP_SORT)) return MM355_EUNSUP;   // 0x100/0x200: SPLICE_FOR/REV imply SPLICE (U:options.c::mm_mapopt_update)
-	if (mo->flag & (MMF_FOR_ONLY | MMF_REV_ONLY)) return MM355_EUNSUP;               // skip_seed() variants: next round
 	if (!(mo->flag & MMF_CIGAR)) return MM355_EUNSUP;                                // the reference always sets it (lib.rs:339)
 	if (mo->max_chain_iter > 8000 || mo->max_chain_iter < 1) return MM355_EUNSUP;    // LDS mark window of k_chain
 	if (mi->w > 64 || mi->k > 28 || mi->k < 1) return MM355_EUNSUP;

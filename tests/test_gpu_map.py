@@ -181,6 +181,18 @@ def test_map_parity_adversarial_inputs(built, tmp_path):
     assert n_hits >= 170
 
 
+@pytest.mark.parametrize("flag", [0x100000, 0x200000, 0x300000])
+def test_map_parity_strand_restricted(ont, flag):
+    """MM_F_FOR_ONLY / MM_F_REV_ONLY (U:map.c::skip_seed): seed hits of the excluded strand produce no anchors; both = nothing maps"""
+    import mappy_rs
+    al = mappy_rs.Aligner(ont["fa"], preset="map-ont", extra_flags=flag)
+    orc = O.OracleAligner(ont["fa"], preset="map-ont", extra_flags=flag)
+    reads, _ = S.make_reads(74, ont["g"], 60, n50=4000, lo=500)
+    n_hits, _ = check_reads(al, orc, reads)
+    strands = {m.strand for r in reads[:30] for m in al.map(r)}
+    assert strands == ({1} if flag == 0x100000 else {-1} if flag == 0x200000 else set()) and (n_hits > 15) == (flag != 0x300000)
+
+
 def test_map_parity_eqx(ont):
     """extra_flags=MM_F_EQX: '='/'X' CIGAR (U:align.c::mm_update_cigar_eqx)"""
     import mappy_rs
@@ -196,7 +208,7 @@ def test_map_parity_eqx(ont):
 def test_unsupported_flags_fail_loudly(ont):
     """options outside the long-read path are refused, never mapped with different semantics"""
     import mappy_rs
-    for fl in (0x80, 0x100, 0x200, 0x1000, 0x100000, 0x200000, 0x400000, 0x100000000):   # SPLICE, SPLICE_FOR/REV, SR, FOR/REV_ONLY, HEAP_SORT, QSTRAND
+    for fl in (0x80, 0x100, 0x200, 0x1000, 0x400000, 0x100000000):   # SPLICE, SPLICE_FOR/REV, SR, HEAP_SORT, QSTRAND
         al = mappy_rs.Aligner(ont["fa"], preset="map-ont", extra_flags=fl)
         with pytest.raises(RuntimeError, match="outside the long-read hot path"):
             al.map(S.codes_to_str(ont["g"][0][1000:3000]))

@@ -7,8 +7,8 @@ import numpy as np
 
 FIELDS = ("target_name", "target_start", "target_end", "query_start", "query_end", "strand", "target_len", "match_len", "block_len", "mapq",
           "is_primary", "NM", "cs", "MD")
-# NO_LJOIN, ALL_CHAINS, NO_END_FLT, HARD_MLEVEL, EQX, NO_INV
-FLAGS = (0x400, 0x800000, 0x10000000, 0x20000000, 0x4000000, 0x200000000)
+# NO_LJOIN, ALL_CHAINS, NO_END_FLT, HARD_MLEVEL, EQX, NO_INV, FOR_ONLY, REV_ONLY
+FLAGS = (0x400, 0x800000, 0x10000000, 0x20000000, 0x4000000, 0x200000000, 0x100000, 0x200000)
 
 
 def random_config(rng):
