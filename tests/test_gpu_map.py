@@ -400,6 +400,26 @@ def test_committed_golden_vectors_on_gpu(built, golden_dir):
                             "cigar_str", "cs", "MD", "match_len", "block_len"))
 
 
+def test_committed_preset_vectors_on_gpu(built, golden_dir, tmp_path):
+    """the HIP path reproduces the committed hits of the other presets / extra_flags (oracle_presets_small.json) without running the oracle"""
+    import importlib.util
+    import json
+    import mappy_rs
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(golden_dir, "oracle_presets_small.json")))
+    g, reads = mg.presets_inputs()
+    assert reads == want["reads"]
+    fa = str(tmp_path / "p.fa")
+    S.write_fasta(fa, g, ["pA", "pB"])
+    for label, kw in mg.PRESET_CASES:
+        al = mappy_rs.Aligner(fa, **kw)
+        res = al._map_many(reads, 3)
+        for got, w in zip(res, want["cases"][label]):
+            assert [tuple(getattr(m, k) for k in mg.HIT_KEYS) for m in got] == [tuple(h[k] for k in mg.HIT_KEYS) for h in w], label
+
+
 def test_full_size_properties(built, tmp_path):
     """BASELINE configs[1] shape at bench size (E. coli-like genome, 8192 ONT-like reads): properties that need no oracle --
     (1) the hits of a read do not depend on which other reads share its batch, (2) a second run is identical, (3) every CIGAR spans

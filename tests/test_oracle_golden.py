@@ -201,3 +201,20 @@ def test_committed_stage_vectors(golden_dir):
     assert len(got["reads"]) == len(want["reads"])
     for g, w in zip(got["reads"], want["reads"]):
         assert g == w
+
+
+def test_committed_preset_vectors(golden_dir):
+    """the oracle reproduces its committed hits for the other presets / extra_flags (tests/golden/oracle_presets_small.json)"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(golden_dir, "oracle_presets_small.json")))
+    got = mg.build_presets()
+    assert got["genome_sha"] == want["genome_sha"] and got["reads"] == want["reads"]
+    assert sorted(got["cases"]) == sorted(want["cases"]) and len(want["cases"]) == len(mg.PRESET_CASES)
+    for label in want["cases"]:
+        assert got["cases"][label] == want["cases"][label], label
+    assert any("X" in h["cigar_str"] for hits in want["cases"]["map-ont+EQX"] for h in hits)
+    assert {h["strand"] for hits in want["cases"]["map-ont+REV_ONLY+NO_LJOIN"] for h in hits} == {-1}
