@@ -193,6 +193,26 @@ def test_map_parity_strand_restricted(ont, flag):
     assert strands == ({1} if flag == 0x100000 else {-1} if flag == 0x200000 else set()) and (n_hits > 15) == (flag != 0x300000)
 
 
+@pytest.mark.parametrize("preset", ["map-ont", "asm20"])
+def test_map_parity_large_gaps(built, tmp_path, preset):
+    """6 - 19 kb of unrelated sequence, or a deletion of that size, in the middle of a 16 kb read: long-join re-chaining across the gap,
+    gap fills with one very long side (the eight-wave / HBM-state extension classes), the max_sw_mat rule, z-drop splits"""
+    import mappy_rs
+    rng = np.random.default_rng(5)
+    g = [S.random_codes(rng, 400000)]
+    fa = str(tmp_path / "sw.fa")
+    S.write_fasta(fa, g, ["c"])
+    reads = []
+    for gap in (6000, 9000, 10500, 11000, 12000, 15000, 19000):
+        a0 = 50000 + gap * 3
+        c = np.concatenate([g[0][a0:a0 + 8000], S.random_codes(rng, gap), g[0][a0 + 8000 + gap:a0 + 16000 + gap]])
+        reads.append(S.codes_to_str(S.mutate(c, rng, 0.01, 0.005, 0.005)))
+        c = np.concatenate([g[0][a0:a0 + 8000], g[0][a0 + 8000 + gap:a0 + 16000 + gap]])
+        reads.append(S.codes_to_str(S.mutate(c, rng, 0.01, 0.005, 0.005)))
+    n_hits, _ = check_reads(mappy_rs.Aligner(fa, preset=preset), O.OracleAligner(fa, preset=preset), reads)
+    assert n_hits >= 21
+
+
 def test_map_parity_eqx(ont):
     """extra_flags=MM_F_EQX: '='/'X' CIGAR (U:align.c::mm_update_cigar_eqx)"""
     import mappy_rs
