@@ -51,6 +51,23 @@ __global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSe
 	chunk_n[t] = sketch_chunk(bt.seq + off, len, ix.w, ix.k, cs, ce, sd.mz + off + cs, ring + threadIdx.x, WAVE);
 }
 
+// Small batches (a single read is ~20 chunks): one chunk per WAVE, lane 0 only.  With a lane per chunk the wave executes the union
+// of every lane's branches -- both ring rescans on almost every base -- which is what a full grid amortises and a 20-chunk grid
+// does not: alone in its wave a chunk only pays for the rescans it needs (~5x shorter latency), and the chunks spread over the CUs.
+__global__ __launch_bounds__(WAVE) void k_sketch_sparse(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
+{
+	MM355_LATENCY_KERNEL();
+	extern __shared__ mm128 ring[];
+	const int t = blockIdx.x;
+	if (t >= n_chunks || threadIdx.x != 0) return;
+	const int r = chunk_read[t], cs = chunk_start[t];
+	const int len = bt.rlen[r];
+	const int64_t off = bt.roff[r];
+	int ce = cs + SK_CHUNK;
+	if (ce > len) ce = len;
+	chunk_n[t] = sketch_chunk(bt.seq + off, len, ix.w, ix.k, cs, ce, sd.mz + off + cs, ring, 1);
+}
+
 // packs the per-chunk outputs of a read to the front of its slot range (in place; destination never passes the source)
 __global__ __launch_bounds__(WAVE) void k_sketch_compact(DevBatch bt, DevSeeds sd, const int64_t *read_chunk0, const int32_t *chunk_n)
 {
@@ -1163,9 +1180,15 @@ void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, c
 {
 	if (bt.n_reads == 0) return;
 	if (n_chunks > 0) {
-		int blocks = (n_chunks + WAVE - 1) / WAVE;
-		size_t lds = (size_t)ix.w * WAVE * sizeof(mm128);
-		hipLaunchKernelGGL(k_sketch, dim3(blocks), dim3(WAVE), lds, st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+		const char *e = getenv("MM355_SKETCH_SPARSE_MAX");   // read per launch: the parity tests force either form
+		const int sparse_max = e? atoi(e) : 2048;             // chunks
+		if (n_chunks <= sparse_max) {
+			hipLaunchKernelGGL(k_sketch_sparse, dim3(n_chunks), dim3(WAVE), (size_t)ix.w * sizeof(mm128), st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+		} else {
+			int blocks = (n_chunks + WAVE - 1) / WAVE;
+			size_t lds = (size_t)ix.w * WAVE * sizeof(mm128);
+			hipLaunchKernelGGL(k_sketch, dim3(blocks), dim3(WAVE), lds, st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+		}
 	}
 	hipLaunchKernelGGL(k_sketch_compact, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, sd, read_chunk0, chunk_n);
 }

@@ -33,7 +33,9 @@ def world(built, tmp_path_factory):
     sr.close()
 
 
-def test_sketch_parity(world):
+@pytest.mark.parametrize("sparse_max", ["0", "1000000000"])
+def test_sketch_parity(world, monkeypatch, sparse_max):
+    monkeypatch.setenv("MM355_SKETCH_SPARSE_MAX", sparse_max)
     got = world["sr"].sketch(world["reads"])
     for rd, g in zip(world["reads"], got):
         exp = world["orc"].sketch(rd)
@@ -116,11 +118,13 @@ def test_hifi_preset_parity(built, tmp_path):
     sr.close()
 
 
-def test_chunked_sketch_adversarial(built, tmp_path):
+@pytest.mark.parametrize("sparse_max", ["0", "1000000000"])   # lane-per-chunk grid / one chunk per wave (small batches)
+def test_chunked_sketch_adversarial(built, tmp_path, monkeypatch, sparse_max):
     """the chunked sketch kernel must equal the sequential machine on inputs that stress its warm-up proof:
     even k (symmetric k-mers are skipped without advancing the ring), N every few bases, long N runs, homopolymers,
     palindromic repeats, and reads around the chunk size"""
     import mappy_rs
+    monkeypatch.setenv("MM355_SKETCH_SPARSE_MAX", sparse_max)
     rng = np.random.default_rng(11)
     g = S.make_genome(71, [60000], repeats=())
     fa = str(tmp_path / "s.fa")
