@@ -638,7 +638,7 @@ extern "C" int mm355_stage_dp(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t 
 {
 	if (c == 0 || mo == 0) return MM355_EINVAL;
 	HIPCHK(hipSetDevice(c->dev));
-	memset(&c->stats, 0, sizeof(c->stats));
+	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	HIPCHK(hipMemsetAsync(c->counters.p, 0, 256, c->st));
 	if (c->dp_q.ensure((size_t)n_q + 64) || c->dp_t.ensure((size_t)n_t + 64)) return MM355_ENOMEM;
 	if (n_q) HIPCHK(hipMemcpyAsync(c->dp_q.p, qcodes, n_q, hipMemcpyHostToDevice, c->st));

@@ -256,7 +256,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	const mm355_index *mi = c->mi;
 	DevParams pr = mm355_make_params(mo, mi);
 	const int64_t n_reads = c->hb.n_reads;
-	memset(&c->stats, 0, sizeof(c->stats));
+	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	c->n_arena = 0;
 	c->stats.n_reads = n_reads; c->stats.n_bases = c->hb.n_bases;
 	HIPCHK(hipMemsetAsync(c->counters.p, 0, 256, c->st));
@@ -314,6 +314,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		if (tm) HIPCHK(hipMemcpyAsync(pm, d_pm, (size_t)tm * 8, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(mm355_wait_stream(c->st));
 	}
+	mm355_timers_resolve(c);   // the stream is idle here: the stage timers of the front turn into milliseconds without waiting
 	tv_pack = now_ms() - tv0; trace_add(c, "pack", tv0, now_ms()); tv0 = now_ms();
 	const double t_host0 = now_ms();
 	const int nt = host_threads();

@@ -66,6 +66,7 @@ struct mm355_ctx {
 	DBuf rq;       // per-read query codes fwd|rev
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
+	std::vector<hipEvent_t> tev; std::vector<double*> tacc; int n_tpend = 0;   // lazy stage timers (EvTimer)
 	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[16] = {}, dp_ev0[16] = {}, dp_ev1[16] = {};
 	HostBatch hb;
 };
@@ -85,12 +86,29 @@ int mm355_run_backtrack(mm355_ctx *ctx, const DevParams &pr);
 int mm355_run_chain_skip(mm355_ctx *c);
 
 // time one launch group on the context's stream with HIP events (the stream the kernels are launched on)
-struct EvTimer {
+// Stage timers.  EvTimer records a pair of events around the launches of a stage and does NOT synchronise: the pairs are turned into
+// milliseconds by mm355_timers_resolve() once the call has synchronised its stream anyway (end of mm355_map_resident, the stage entry
+// points, mm355_get_stats) -- a host synchronisation per stage costs a single-read call ~0.3 ms.  EvTimer2 is the synchronising form
+// (extension rounds: the round ends with a synchronisation in any case).
+struct EvTimer2 {
 	mm355_ctx *c; double *acc;
-	EvTimer(mm355_ctx *c_, double *a) : c(c_), acc(a) { (void)hipEventRecord(c->ev0, c->st); }
-	~EvTimer() { float ms = 0; (void)hipEventRecord(c->ev1, c->st); (void)hipEventSynchronize(c->ev1); (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *acc += ms; }
+	EvTimer2(mm355_ctx *c_, double *a) : c(c_), acc(a) { (void)hipEventRecord(c->ev0, c->st); }
+	~EvTimer2() { float ms = 0; (void)hipEventRecord(c->ev1, c->st); (void)hipEventSynchronize(c->ev1); (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *acc += ms; }
 };
-typedef EvTimer EvTimer2;
+void mm355_timers_resolve(mm355_ctx *c);
+struct EvTimer {
+	mm355_ctx *c; int slot;
+	EvTimer(mm355_ctx *c_, double *a) : c(c_)
+	{
+		if (c->n_tpend >= 48) mm355_timers_resolve(c);
+		slot = c->n_tpend++;
+		while ((int)c->tev.size() < 2 * (slot + 1)) { hipEvent_t e = 0; (void)hipEventCreate(&e); c->tev.push_back(e); }
+		if ((int)c->tacc.size() <= slot) c->tacc.resize(slot + 1);
+		c->tacc[slot] = a;
+		(void)hipEventRecord(c->tev[2 * slot], c->st);
+	}
+	~EvTimer() { (void)hipEventRecord(c->tev[2 * slot + 1], c->st); }
+};
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)
 

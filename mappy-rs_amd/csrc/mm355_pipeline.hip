@@ -50,6 +50,15 @@ extern "C" int mm355_device_count(void)
 	return n;
 }
 
+void mm355_timers_resolve(mm355_ctx *c)
+{
+	for (int i = 0; i < c->n_tpend; ++i) {
+		float ms = 0;
+		if (hipEventSynchronize(c->tev[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, c->tev[2 * i], c->tev[2 * i + 1]) == hipSuccess) *c->tacc[i] += ms;
+	}
+	c->n_tpend = 0;
+}
+
 extern "C" int mm355_device_synchronize(int device_id)
 {
 	HIPCHK(hipSetDevice(device_id));
@@ -95,7 +104,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		c->dix.seq_off = c->ix_off.as<uint64_t>(); c->dix.seq_len = c->ix_len.as<uint32_t>();
 		c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
 		if (c->counters.ensure(256) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
-		memset(&c->stats, 0, sizeof(c->stats));
+		c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 		*out = c;
 		return 0;
 	}
@@ -112,7 +121,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	c->dix.seq_off = c->ix_off.as<uint64_t>(); c->dix.seq_len = c->ix_len.as<uint32_t>();
 	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
 	if (c->counters.ensure(256) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
-	memset(&c->stats, 0, sizeof(c->stats));
+	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	*out = c;
 	return 0;
 }
@@ -133,13 +142,14 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 	if (c->aux_st) (void)hipStreamDestroy(c->aux_st);
 	if (c->aux_ev) (void)hipEventDestroy(c->aux_ev);
 	if (c->aux_ev2) (void)hipEventDestroy(c->aux_ev2);
+	for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
 	if (c->st) (void)hipStreamDestroy(c->st);
 	delete c;
 }
 
-extern "C" int mm355_get_stats(mm355_ctx_t *c, mm355_stats_t *st) { if (c == 0) return MM355_EINVAL; *st = c->stats; return 0; }
+extern "C" int mm355_get_stats(mm355_ctx_t *c, mm355_stats_t *st) { if (c == 0) return MM355_EINVAL; mm355_timers_resolve(c); *st = c->stats; return 0; }
 
 static DevBatch dev_batch(mm355_ctx *c)
 {
@@ -369,7 +379,7 @@ static int stage_prologue(mm355_ctx *c, const mm355_mapopt_t *mo, int64_t n_read
 {
 	if (c == 0) return MM355_EINVAL;
 	if (mo) { int rc = mm355_check_opts(mo, c->mi); if (rc) return rc; *pr = mm355_make_params(mo, c->mi); }
-	memset(&c->stats, 0, sizeof(c->stats));
+	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	return mm355_run_pack(c, n_reads, seqs, lens);
 }
 
