@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void k_pack_chains(int n_reads, const int64_t 
 #include <deque>
 #include <functional>
 #include <memory>
-struct PJob { std::atomic<int64_t> next{0}; int64_t n = 0; std::function<void(int64_t, int)> f; std::atomic<int> pending{0}; std::atomic<int> tid{1}; };
+struct PJob { std::atomic<int64_t> next{0}; int64_t n = 0; std::function<void(int64_t, int)> f; std::atomic<int> pending{0}; std::atomic<int> tid{1};
+              std::mutex dm; std::condition_variable dcv; };   // the caller sleeps on dcv until the helpers that started have finished
 class HostPool {
 public:
 	// intentionally leaked: destroying a condition variable with parked workers at process exit would block in pthread_cond_destroy
@@ -55,7 +56,11 @@ public:
 			std::lock_guard<std::mutex> lk(m);
 			for (auto it = q.begin(); it != q.end();) { if (it->get() == j.get()) { it = q.erase(it); j->pending.fetch_sub(1); } else ++it; }
 		}
-		while (j->pending.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+		for (int spin = 0; spin < 200 && j->pending.load(std::memory_order_acquire) > 0; ++spin) std::this_thread::yield();   // the usual case: a few microseconds
+		if (j->pending.load(std::memory_order_acquire) > 0) {   // a helper is inside a long item: sleep instead of burning the CPU share
+			std::unique_lock<std::mutex> lk(j->dm);
+			j->dcv.wait(lk, [&]() { return j->pending.load(std::memory_order_acquire) <= 0; });
+		}
 	}
 private:
 	HostPool() {
@@ -72,7 +77,7 @@ private:
 			{ std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&]() { return !q.empty(); }); j = q.front(); q.pop_front(); }
 			const int tid = j->tid.fetch_add(1);
 			for (;;) { int64_t i = j->next.fetch_add(1); if (i >= j->n) break; j->f(i, tid); }
-			j->pending.fetch_sub(1, std::memory_order_release);
+			if (j->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(j->dm); j->dcv.notify_all(); }
 		}
 	}
 	std::vector<std::thread> th; std::mutex m; std::condition_variable cv; std::deque<std::shared_ptr<PJob>> q;
