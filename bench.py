@@ -20,6 +20,29 @@ import os as _os
 # per-read front kernels of one context queue behind the extension grids of another.  8 queues measured best (16+ lets the
 # extension rounds interleave again).  Must be set before the HIP runtime starts.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
+def _host_pool_threads():
+    """size of the library's shared host pool (MM355_HOST_THREADS) for this rank: the CPUs this process may use (cgroup quota or
+    affinity mask) divided by the ranks of the node, minus the threads that sit in the HIP runtime; 16 (the library default, one
+    GPU's CPU share on the bench boxes) when the rank is alone.  Over-subscribing a CPU quota stalls every thread of the cgroup."""
+    local_world = int(_os.environ.get("LOCAL_WORLD_SIZE", _os.environ.get("WORLD_SIZE", "1")))
+    if local_world <= 1:
+        return 16
+    try:
+        cpus = float(len(_os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        cpus = float(_os.cpu_count() or 16)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cpus = min(cpus, float(q) / float(per))
+    except (OSError, ValueError):
+        pass
+    return max(6, min(16, int(cpus / local_world) - 4))
+
+
+_os.environ.setdefault("MM355_HOST_THREADS", str(_host_pool_threads()))
 import ctypes as C
 import json
 import os
