@@ -111,10 +111,22 @@ void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1)
 static void trace_add(const void *ctx, const char *phase, double t0, double t1) { mm355_trace_add(ctx, phase, t0, t1); }
 hipError_t mm355_wait_stream(hipStream_t st)
 {
-	// default: the runtime's own wait (hipStreamSynchronize); MM355_BLOCKING_WAIT=1 sleeps on a blocking-sync event instead (no measurable
-	// throughput difference on the bench box; interrupt-driven waits were erratic on some hosts)
-	static const bool blocking = [] { const char *e = getenv("MM355_BLOCKING_WAIT"); return e && atoi(e) != 0; }();
-	if (!blocking) return hipStreamSynchronize(st);
+	// Default (MM355_BLOCKING_WAIT unset or 2): poll hipStreamQuery -- a few hundred quick queries (waits of a fraction of a millisecond
+	// stay low-latency), then naps of 40 us.  hipStreamSynchronize (=0) spins on a core for the whole wait: with 8 context threads that is
+	// half of a 16-CPU share burnt while the shared host pool needs it (+7 % throughput on the bench boxes, less run-to-run spread);
+	// a blocking-sync event (=1) sleeps in the driver and wakes too slowly for the ~15 short waits of a sub-batch (-5 %).
+	static const int mode = [] { const char *e = getenv("MM355_BLOCKING_WAIT"); return e? atoi(e) : 2; }();
+	if (mode == 0) return hipStreamSynchronize(st);
+	if (mode == 2) {
+		static const int spins = [] { const char *e = getenv("MM355_WAIT_SPINS"); return e? atoi(e) : 300; }();
+		static const int nap = [] { const char *e = getenv("MM355_WAIT_NAP_US"); return e? atoi(e) : 40; }();
+		for (int i = 0;; ++i) {
+			hipError_t q = hipStreamQuery(st);
+			if (q == hipSuccess) return hipSuccess;
+			if (q != hipErrorNotReady) return q;
+			if (i < spins) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(nap));
+		}
+	}
 	static thread_local hipEvent_t ev = 0;   // one per calling thread (leaked with it); valid for any stream of the current device
 	static thread_local int ev_dev = -1;
 	int dev = 0; (void)hipGetDevice(&dev);

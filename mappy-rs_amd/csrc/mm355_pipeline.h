@@ -93,7 +93,7 @@ int mm355_run_chain_skip(mm355_ctx *c);
 struct EvTimer2 {
 	mm355_ctx *c; double *acc;
 	EvTimer2(mm355_ctx *c_, double *a) : c(c_), acc(a) { (void)hipEventRecord(c->ev0, c->st); }
-	~EvTimer2() { float ms = 0; (void)hipEventRecord(c->ev1, c->st); (void)hipEventSynchronize(c->ev1); (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *acc += ms; }
+	~EvTimer2() { float ms = 0; (void)hipEventRecord(c->ev1, c->st); (void)mm355_wait_stream(c->st); (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *acc += ms; }
 };
 void mm355_timers_resolve(mm355_ctx *c);
 struct EvTimer {
@@ -114,6 +114,6 @@ struct EvTimer {
 
 int mm355_fast_sort(mm355_ctx *c, int64_t tot, int n_reads, std::vector<uint8_t> &h_flag);
 int mm355_fast_sort_fix(mm355_ctx *c, int n_reads);   // after the literal sort of the flagged reads: restore every position outside equal-key runs
-hipError_t mm355_wait_stream(hipStream_t st);   // hipStreamSynchronize, or with MM355_BLOCKING_WAIT=1 a sleep on a blocking-sync event
+hipError_t mm355_wait_stream(hipStream_t st);   // polls hipStreamQuery with short naps (MM355_BLOCKING_WAIT=0: hipStreamSynchronize, =1: blocking-sync event)
 void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1);   // MM355_TRACE timeline (no-op when unset)
 double mm355_now_ms();
