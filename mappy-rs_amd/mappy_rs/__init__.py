@@ -336,10 +336,13 @@ class Aligner:
         # The whole iterable is consumed before the first result is yielded (lib.rs:845-903).  The reads then go through the GPU in
         # sub-batches of a few thousand reads: `n_threads` host threads (enable_threading; at most 8 are useful) each drive their own
         # context, so that the front kernels, the host tail and the extension rounds of different sub-batches overlap.
+        # sub-batch size: at most SUB_BATCH_READS, but small inputs are cut finer so that every worker gets about two sub-batches
+        # (16384 reads: 1024 per sub-batch maps 20 % faster than 4096, 4096 reads 50 % faster)
+        sb_reads = min(SUB_BATCH_READS, max(1024, -(-len(reads) // (2 * max(1, min(self._n_threads, 8))))))
         subs, lo = [], 0
         while lo < len(reads):
             hi, nb = lo, 0
-            while hi < len(reads) and (hi == lo or nb + len(reads[hi]) <= SUB_BATCH_BASES) and hi - lo < SUB_BATCH_READS:
+            while hi < len(reads) and (hi == lo or nb + len(reads[hi]) <= SUB_BATCH_BASES) and hi - lo < sb_reads:
                 nb += len(reads[hi]); hi += 1
             subs.append((lo, hi))
             lo = hi
