@@ -100,7 +100,7 @@ int mm355_index_load(const char *path, const mm355_idxopt_t *io, int n_threads, 
 int mm355_index_build(const mm355_idxopt_t *io, int n_seq, const char *const *seqs, const int64_t *lens,
                       const char *const *names, int n_threads, mm355_index_t **out);
 /* same index, built on GPU `device` (sketch + radix sort + table fill in HBM; replaces the FASTA branch of
- * mm_idx_reader_read for large references).  The table stays resident on that device: contexts must use the same one. */
+ * mm_idx_reader_read for large references).  The table stays resident on that device; other devices get peer copies (mm355_upload). */
 int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, const uint8_t *const *seqs, const int64_t *lens,
                              const char *const *names, int device, mm355_index_t **out);
 void mm355_index_free(mm355_index_t *idx);
@@ -114,8 +114,14 @@ int mm355_index_getseq(const mm355_index_t *idx, uint32_t rid, uint32_t st, uint
 int mm355_index_get(const mm355_index_t *idx, uint64_t minier, uint64_t *vals, int cap);
 int mm355_index_stat(const mm355_index_t *idx, int64_t *n_minimizers, int64_t *n_distinct, int64_t *table_bytes, int64_t *pos_bytes);
 
+/* --- multi-GPU: the reference shares ONE read-only mm_idx_t between its N worker threads (lib.rs:541-546, `self.aligner.clone()`
+ * per thread); the GPU analogue is one replica of the index in the HBM of every device, shared by all contexts of that device.
+ * mm355_upload replicates the index to the listed devices (H2D from the host image; a device-built index is copied device-to-device);
+ * idempotent.  mm355_ctx_create replicates lazily when its device has no replica yet.  No collective is involved. --- */
+int mm355_upload(mm355_index_t *idx, const int *device_ids, int n);
+
 /* --- device context (one per host thread / GPU): replaces mm_tbuf_init/destroy --- */
-int mm355_ctx_create(const mm355_index_t *idx, int device_id, mm355_ctx_t **out);   /* uploads the index to HBM once */
+int mm355_ctx_create(const mm355_index_t *idx, int device_id, mm355_ctx_t **out);   /* uses (or creates) the replica of device_id */
 void mm355_ctx_destroy(mm355_ctx_t *ctx);
 
 /* --- the hot path: replaces mm_map (+ mm_gen_cs / mm_gen_MD) for a whole batch of reads.
@@ -146,6 +152,9 @@ typedef struct {
 	 * size classes: targets <= 128, 256, 512, 1024 (k_ksw_reg<1|2|4|8, exact>), <= 4096, <= 12288, larger (k_ksw_extd2<512>) */
 	double ms_dp_group[16];
 	int64_t dp_cells_group[16], n_launch_group[16];
+	int64_t n_ext_rounds;                        /* extension rounds of the last call (the reference has no bound on them) */
+	int64_t n_sort_fast_reads, n_sort_tie_reads; /* anchor sort: reads sorted by the segmented radix sort / of those, reads with equal keys
+	                                                whose equal-key runs went through the literal radix_sort_128x emulation */
 } mm355_stats_t;
 
 /* sketch: minimizers of each read (mm_sketch). mz_off[n_reads+1] host array is filled; mz = (x,y) pairs */

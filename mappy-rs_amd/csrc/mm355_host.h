@@ -4,8 +4,12 @@
 #include <string>
 #include <vector>
 #include <unordered_map>
+#include <mutex>
 #include "../../include/mm355.h"
 #include "mm355_core.h"
+
+// HBM copy of the index on one device (flat table, pos[], 4-bit S, contig offsets/lengths).  Every context of that device shares it.
+struct mm355_replica { int dev = -1; void *slots = 0, *pos = 0, *S = 0, *seq_off = 0, *seq_len = 0; };
 
 struct mm355_index {
 	int32_t b, w, k, flag;
@@ -23,7 +27,13 @@ struct mm355_index {
 	bool dev_resident = false; int dev_id = -1;
 	void *d_slots = 0, *d_pos = 0, *d_S = 0; uint64_t n_pos = 0;
 	std::vector<uint32_t> top_counts;   // largest occurrence counts, descending (for mm_idx_cal_max_occ)
+	// per-device replicas (mm355_upload / first mm355_ctx_create on a device); the index itself stays immutable for the mapping path
+	mutable std::mutex rep_mu;
+	mutable std::vector<mm355_replica> replicas;
 };
+// finds the replica of `dev`, creating it when absent: H2D from the host image, or a peer copy from the device the index was built on
+int mm355_index_replica(const mm355_index *mi, int dev, mm355_replica *out);
+void mm355_index_free_replicas(mm355_index *mi);
 
 // lookup on the host image of the flat table (used by tests of the table itself; the product looks up on the device)
 inline uint32_t mm355_host_get(const mm355_index *mi, uint64_t minier, uint64_t *val)

@@ -101,9 +101,8 @@ __global__ void k_fill_pos(const uint64_t *vals, const uint32_t *run_id, const u
 	if (len[r] > 1) pos[moff[r] + (i - starts[r])] = vals[i];
 }
 
-void mm355_index_free_device(mm355_index *mi)
+static void free_build_buffers(mm355_index *mi)   // a failed build: nothing was registered as a replica yet
 {
-	if (!mi->dev_resident) return;
 	(void)hipSetDevice(mi->dev_id);
 	if (mi->d_slots) (void)hipFree(mi->d_slots);
 	if (mi->d_pos) (void)hipFree(mi->d_pos);
@@ -258,11 +257,18 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 	IB_LOG("S to host");
 	mi->d_S = dS; dS = 0;
 	mi->dev_resident = true; mi->dev_id = device;
+	{   // the build device holds the first replica; other devices get peer copies (mm355_upload / mm355_ctx_create)
+		mm355_replica rp; rp.dev = device; rp.slots = mi->d_slots; rp.pos = mi->d_pos; rp.S = mi->d_S;
+		if (hipMalloc(&rp.seq_off, (size_t)n_seq * 8) != hipSuccess || hipMalloc(&rp.seq_len, (size_t)n_seq * 4) != hipSuccess) { if (rp.seq_off) (void)hipFree(rp.seq_off); mi->dev_resident = false; FAIL(MM355_ENOMEM); }
+		(void)hipMemcpy(rp.seq_off, mi->seq_off.data(), (size_t)n_seq * 8, hipMemcpyHostToDevice);
+		(void)hipMemcpy(rp.seq_len, mi->seq_len.data(), (size_t)n_seq * 4, hipMemcpyHostToDevice);
+		mi->replicas.push_back(rp);
+	}
 done:
 	d_seq.release(); d_slots16.release(); d_cn.release(); d_co.release(); d_keys.release(); d_vals.release(); d_keys2.release(); d_vals2.release(); d_tmp.release(); d_err.release();
 	if (dS) (void)hipFree(dS);
 	(void)hipStreamDestroy(st);
-	if (rc) { mi->dev_resident = mi->d_slots || mi->d_pos; mi->dev_id = device; mm355_index_free_device(mi); delete mi; return rc; }
+	if (rc) { mi->dev_id = device; free_build_buffers(mi); delete mi; return rc; }
 	*out = mi;
 	return 0;
 }

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <thread>
 #include <atomic>
+#include <zlib.h>
 #include "mm355_host.h"
 
 #define mm_seq4_set(s, i, c) ((s)[(i)>>3] |= (uint32_t)(c) << (((i)&7)<<2))
@@ -68,7 +69,7 @@ extern "C" int mm355_set_opt(const char *preset, mm355_idxopt_t *io, mm355_mapop
 		mo->bw = mo->bw_long = 2000; mo->occ_dist = 0;
 		return 0;
 	}
-	if (p.compare(0, 3, "asm") == 0) {
+	if (p == "asm5" || p == "asm10" || p == "asm20") {
 		io->flag = 0; io->k = 19; io->w = 19;
 		mo->bw = 1000; mo->bw_long = 100000; mo->max_gap = 10000;
 		mo->flag |= MMF_RMQ;
@@ -79,8 +80,11 @@ extern "C" int mm355_set_opt(const char *preset, mm355_idxopt_t *io, mm355_mapop
 		else return MM355_EINVAL;
 		return 0;
 	}
-	if (p == "map-pb" || p == "map10k" || p == "ava-pb") { io->flag |= 1; io->k = 19; return MM355_EUNSUP; } // HPC sketches: not on this path
-	return MM355_EUNSUP;   // sr / splice / cdna presets are outside the long-read hot path
+	// known minimap2 2.26 presets that are outside the long-read hot path (HPC sketches, short reads, spliced): nothing is modified, the
+	// caller gets MM355_EUNSUP and must refuse (mappy_rs.Aligner raises)
+	static const char *const unsup[] = { "map-pb", "map10k", "ava-pb", "sr", "short", "splice", "splice:hq", "cdna", 0 };
+	for (int i = 0; unsup[i]; ++i) if (p == unsup[i]) return MM355_EUNSUP;
+	return MM355_EINVAL;   // unknown name: options untouched, as U:options.c::mm_set_opt's -1 (the reference ignores it, lib.rs:336)
 }
 
 int32_t mm355_index_cal_max_occ(const mm355_index *mi, float f)
@@ -174,6 +178,8 @@ static mm355_index *load_mmi(FILE *fp)
 	if (fread(x, 4, 5, fp) != 5) return 0;
 	mm355_index *mi = new mm355_index();
 	mi->w = x[0], mi->k = x[1], mi->b = x[2], mi->n_seq = x[3], mi->flag = x[4];
+	// a corrupt header must not drive the 1<<b bucket loop or the sketch kernels: U:sketch.c asserts 0 < w < 256, 0 < k <= 28; b <= 2k
+	if (x[0] < 1 || x[0] > 255 || x[1] < 1 || x[1] > 28 || x[2] > 28 || x[2] > 2 * x[1]) { delete mi; return 0; }
 	uint64_t sum_len = 0;
 	for (uint32_t i = 0; i < mi->n_seq; ++i) {
 		uint8_t l; uint32_t len; char nm[256];
@@ -265,22 +271,39 @@ static mm355_index *build_from_seqs(const mm355_idxopt_t *io, int n_seq, const c
 	return mi;
 }
 
-static mm355_index *build_from_fastx(FILE *fp, const mm355_idxopt_t *io, int n_threads)
+// FASTA/FASTQ, plain or gzip-compressed (U:bseq.c reads through zlib's gzFile, which passes plain files through unchanged)
+static mm355_index *build_from_fastx(const char *path, const mm355_idxopt_t *io, int n_threads)
 {
+	gzFile gz = gzopen(path, "rb");
+	if (gz == 0) return 0;
+	(void)gzbuffer(gz, 1 << 20);
 	std::vector<std::string> names, seqs;
-	char *line = 0; size_t m_line = 0; ssize_t n;
-	bool in_qual = false, is_fq = false; size_t l_qual = 0;
-	while ((n = getline(&line, &m_line, fp)) >= 0) {
-		while (n > 0 && (line[n-1] == '\n' || line[n-1] == '\r')) line[--n] = 0;
+	std::string line;
+	std::vector<char> buf(1 << 16);
+	bool in_qual = false, is_fq = false, eof = false; size_t l_qual = 0;
+	while (!eof) {
+		line.clear();
+		for (;;) {   // one line of any length
+			if (gzgets(gz, buf.data(), (int)buf.size()) == 0) { eof = true; break; }
+			const size_t l = strlen(buf.data());
+			line.append(buf.data(), l);
+			if (l > 0 && buf[l - 1] == '\n') break;
+		}
+		if (eof && line.empty()) break;
+		size_t n = line.size();
+		while (n > 0 && (line[n-1] == '\n' || line[n-1] == '\r')) --n;
+		line.resize(n);
 		if (in_qual) { l_qual += n; if (l_qual >= seqs.back().size()) in_qual = false; continue; }
-		if (line[0] == '>' || (line[0] == '@' && (names.empty() || is_fq))) {
+		if (n > 0 && (line[0] == '>' || (line[0] == '@' && (names.empty() || is_fq)))) {
 			is_fq = line[0] == '@';
-			char *p = line + 1; while (*p && *p != ' ' && *p != '\t') ++p; *p = 0;
-			names.emplace_back(line + 1); seqs.emplace_back();
-		} else if (line[0] == '+' && is_fq) { in_qual = !seqs.empty() && seqs.back().size() > 0; l_qual = 0; }
-		else if (!names.empty()) { for (ssize_t i = 0; i < n; ++i) if (line[i] > ' ') seqs.back().push_back(line[i]); }
+			size_t e = 1; while (e < n && line[e] != ' ' && line[e] != '\t') ++e;
+			names.emplace_back(line, 1, e - 1); seqs.emplace_back();
+		} else if (n > 0 && line[0] == '+' && is_fq) { in_qual = !seqs.empty() && seqs.back().size() > 0; l_qual = 0; }
+		else if (!names.empty()) { for (size_t i = 0; i < n; ++i) if (line[i] > ' ') seqs.back().push_back(line[i]); }
 	}
-	free(line);
+	int zerr = 0; (void)gzerror(gz, &zerr);
+	gzclose(gz);
+	if (zerr != Z_OK && zerr != Z_STREAM_END) return 0;   // truncated / corrupt gzip stream: no garbage index
 	if (names.empty()) return 0;
 	std::vector<const char*> sp, np; std::vector<int64_t> ln;
 	for (size_t i = 0; i < names.size(); ++i) { sp.push_back(seqs[i].data()); np.push_back(names[i].c_str()); ln.push_back((int64_t)seqs[i].size()); }
@@ -301,8 +324,13 @@ extern "C" int mm355_index_load(const char *path, const mm355_idxopt_t *io, int 
 	rewind(fp);
 	mm355_index *mi = 0;
 	if (n == 4 && strncmp(magic, "MMI\2", 4) == 0) mi = load_mmi(fp);
-	else if (n > 0) { if (io->flag & 1) { fclose(fp); return MM355_EUNSUP; } mi = build_from_fastx(fp, io, n_threads); }
-	fclose(fp);
+	else if (n > 0) {
+		fclose(fp); fp = 0;
+		if (io->flag & 1) return MM355_EUNSUP;
+		if (io->k <= 0 || io->k > 28 || io->w <= 0 || io->w >= 256) return MM355_EINVAL;
+		mi = build_from_fastx(path, io, n_threads);
+	}
+	if (fp) fclose(fp);
 	if (mi == 0 || mi->n_seq == 0) { delete mi; return MM355_EIO; }
 	if (mi->flag & 1) { delete mi; return MM355_EUNSUP; }   // HPC index
 	finish_index(mi);
@@ -323,8 +351,7 @@ extern "C" int mm355_index_build(const mm355_idxopt_t *io, int n_seq, const char
 	return 0;
 }
 
-void mm355_index_free_device(mm355_index *mi);
-extern "C" void mm355_index_free(mm355_index_t *mi) { if (mi && mi->dev_resident) mm355_index_free_device(mi); delete mi; }
+extern "C" void mm355_index_free(mm355_index_t *mi) { if (mi) mm355_index_free_replicas(mi); delete mi; }
 
 extern "C" int mm355_index_info(const mm355_index_t *mi, int32_t *k, int32_t *w, int32_t *b, int32_t *flag, uint32_t *n_seq)
 {

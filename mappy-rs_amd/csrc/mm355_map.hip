@@ -349,8 +349,10 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	tv_pre = now_ms() - tv0; trace_add(c, "pre", tv0, now_ms());
 	int n_rounds = 0;
 	std::vector<std::vector<uint32_t>> arenas;   // CIGAR arenas of all extension launches of this batch
-	// extension rounds: every pending problem of every read goes into the same launches
-	for (int round = 0; round < 64; ++round) {
+	// extension rounds: every pending problem of every read goes into the same launches.  No cap on the number of rounds (the reference
+	// has none: every z-drop split of a long divergent read costs a round or two); progress is guaranteed because a round with open reads
+	// and no request is reported as an error below.
+	for (int round = 0;; ++round) {
 		const double th0 = now_ms();
 		std::vector<std::vector<DpReq>> treq(nt);
 		std::atomic<int64_t> n_open(0);
@@ -404,7 +406,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	tv_asm = now_ms() - tv0; trace_add(c, "asm", tv0, now_ms());
 	if (verbose) fprintf(stderr, "[mm355] map_resident: front %.1f ms | pack+d2h %.1f | pre_align %.1f | align_steps %.1f | dp rounds(%d) %.1f (kernel %.1f) | finish %.1f | assemble %.1f | total %.1f\n",
 	                     tv_front, tv_pack, tv_pre, tv_steps, n_rounds, tv_dp, c->stats.ms_dp, tv_fin, tv_asm, now_ms() - t_start);
-	c->stats.ms_host = ms_host;
+	c->stats.ms_host = ms_host; c->stats.n_ext_rounds = n_rounds;
 	c->stats.ms_total = now_ms() - t_start;
 	if (verbose) mm355_prof_dump(n_reads);
 	*out = H;

@@ -48,7 +48,6 @@ struct mm355_ctx {
 	int dev = 0;
 	hipStream_t st = 0;
 	DevIndex dix;
-	DBuf ix_slots, ix_pos, ix_S, ix_off, ix_len;
 	// per-batch device buffers
 	DBuf heavy, seq, roff, rlen, order, ck_read, ck_start, ck_n, ck_r0;
 	int64_t n_chunks = 0;

@@ -13,6 +13,7 @@
 int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi)
 {
 	if (mi->flag & 1) return MM355_EUNSUP;                                           // HPC index
+	if (mi->flag & 2) return MM355_EUNSUP;                                           // MM_I_NO_SEQ with MM_F_CIGAR (always set, lib.rs:339): "No sequence in this index" (lib.rs:710-714)
 	if (mo->flag & (MMF_SPLICE | 0x100LL | 0x200LL | MMF_SR | MMF_QSTRAND | MMF_HEAP_SORT)) return MM355_EUNSUP;   // 0x100/0x200: SPLICE_FOR/REV imply SPLICE (U:options.c::mm_mapopt_update)
 	if (!(mo->flag & MMF_CIGAR)) return MM355_EUNSUP;                                // the reference always sets it (lib.rs:339)
 	if (mo->max_chain_iter > 8000 || mo->max_chain_iter < 1) return MM355_EUNSUP;    // LDS mark window of k_chain
@@ -94,31 +95,12 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		}
 	}
 	HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
-	if (mi->dev_resident) {   // built on this device: the table is already in HBM
-		if (mi->dev_id != device_id) { delete c; return MM355_EINVAL; }
-		if (c->ix_off.ensure(mi->n_seq * 8) || c->ix_len.ensure(mi->n_seq * 4)) { delete c; return MM355_ENOMEM; }
-		HIPCHK(hipMemcpy(c->ix_off.p, mi->seq_off.data(), mi->n_seq * 8, hipMemcpyHostToDevice));
-		HIPCHK(hipMemcpy(c->ix_len.p, mi->seq_len.data(), mi->n_seq * 4, hipMemcpyHostToDevice));
-		c->dix.slots = (const mm355_slot*)mi->d_slots; c->dix.line_mask = mi->n_lines - 1;
-		c->dix.pos = (const uint64_t*)mi->d_pos; c->dix.S = (const uint32_t*)mi->d_S;
-		c->dix.seq_off = c->ix_off.as<uint64_t>(); c->dix.seq_len = c->ix_len.as<uint32_t>();
-		c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
-		if (c->counters.ensure(256) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
-		c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
-		*out = c;
-		return 0;
-	}
-	// index -> HBM (replicated per GPU; no collective is ever needed)
-	size_t sb = mi->slots.size() * sizeof(mm355_slot), pb = std::max<size_t>(mi->pos.size(), 1) * 8, Sb = std::max<size_t>(mi->S.size(), 1) * 4;
-	if (c->ix_slots.ensure(sb) || c->ix_pos.ensure(pb) || c->ix_S.ensure(Sb + 16) || c->ix_off.ensure(mi->n_seq * 8) || c->ix_len.ensure(mi->n_seq * 4)) { delete c; return MM355_ENOMEM; }
-	HIPCHK(hipMemcpy(c->ix_slots.p, mi->slots.data(), sb, hipMemcpyHostToDevice));
-	if (!mi->pos.empty()) HIPCHK(hipMemcpy(c->ix_pos.p, mi->pos.data(), mi->pos.size() * 8, hipMemcpyHostToDevice));
-	if (!mi->S.empty()) HIPCHK(hipMemcpy(c->ix_S.p, mi->S.data(), mi->S.size() * 4, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(c->ix_off.p, mi->seq_off.data(), mi->n_seq * 8, hipMemcpyHostToDevice));
-	HIPCHK(hipMemcpy(c->ix_len.p, mi->seq_len.data(), mi->n_seq * 4, hipMemcpyHostToDevice));
-	c->dix.slots = c->ix_slots.as<mm355_slot>(); c->dix.line_mask = mi->n_lines - 1;
-	c->dix.pos = c->ix_pos.as<uint64_t>(); c->dix.S = c->ix_S.as<uint32_t>();
-	c->dix.seq_off = c->ix_off.as<uint64_t>(); c->dix.seq_len = c->ix_len.as<uint32_t>();
+	// the index replica of this device (shared by all its contexts; created on first use: H2D from the host image or a peer copy)
+	mm355_replica rp;
+	{ int rc = mm355_index_replica(mi, device_id, &rp); if (rc) { delete c; return rc; } }
+	c->dix.slots = (const mm355_slot*)rp.slots; c->dix.line_mask = mi->n_lines - 1;
+	c->dix.pos = (const uint64_t*)rp.pos; c->dix.S = (const uint32_t*)rp.S;
+	c->dix.seq_off = (const uint64_t*)rp.seq_off; c->dix.seq_len = (const uint32_t*)rp.seq_len;
 	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
 	if (c->counters.ensure(256) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
@@ -126,11 +108,77 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	return 0;
 }
 
+// ------------------------------------------------------------------ index replicas (one per device)
+int mm355_index_replica(const mm355_index *mi, int dev, mm355_replica *out)
+{
+	std::lock_guard<std::mutex> lk(mi->rep_mu);
+	for (const mm355_replica &r : mi->replicas) if (r.dev == dev) { *out = r; return 0; }
+	int prev = 0; (void)hipGetDevice(&prev);
+	HIPCHK(hipSetDevice(dev));
+	mm355_replica rp; rp.dev = dev;
+	const size_t sb = (size_t)mi->n_lines * MM355_SLOTS_PER_LINE * sizeof(mm355_slot);
+	const size_t np = mi->dev_resident? (size_t)mi->n_pos : mi->pos.size(), pb = (np + 2) * 8;
+	uint64_t sum_len = mi->n_seq? mi->seq_off[mi->n_seq - 1] + mi->seq_len[mi->n_seq - 1] : 0;
+	const size_t Sw = (sum_len + 7) / 8 + 2, Sb = Sw * 4;
+	auto fail = [&](int code) { if (rp.slots) (void)hipFree(rp.slots); if (rp.pos) (void)hipFree(rp.pos); if (rp.S) (void)hipFree(rp.S);
+	                            if (rp.seq_off) (void)hipFree(rp.seq_off); if (rp.seq_len) (void)hipFree(rp.seq_len); (void)hipSetDevice(prev); return code; };
+	if (hipMalloc(&rp.slots, sb) != hipSuccess || hipMalloc(&rp.pos, pb) != hipSuccess || hipMalloc(&rp.S, Sb + 16) != hipSuccess ||
+	    hipMalloc(&rp.seq_off, (size_t)mi->n_seq * 8 + 8) != hipSuccess || hipMalloc(&rp.seq_len, (size_t)mi->n_seq * 4 + 8) != hipSuccess) return fail(MM355_ENOMEM);
+	if (hipMemset(rp.S, 0, Sb + 16) != hipSuccess) return fail(MM355_EHIP);
+	if (mi->dev_resident) {   // table and pos[] exist only in HBM of the build device: device-to-device over xGMI (or through the host if peers are not connected)
+		const mm355_replica *src = 0;
+		for (const mm355_replica &r : mi->replicas) if (r.dev == mi->dev_id) src = &r;
+		if (src == 0) return fail(MM355_EINVAL);
+		if (hipMemcpyPeer(rp.slots, dev, src->slots, src->dev, sb) != hipSuccess) return fail(MM355_EHIP);
+		if (np && hipMemcpyPeer(rp.pos, dev, src->pos, src->dev, np * 8) != hipSuccess) return fail(MM355_EHIP);
+	} else {
+		if (hipMemcpy(rp.slots, mi->slots.data(), sb, hipMemcpyHostToDevice) != hipSuccess) return fail(MM355_EHIP);
+		if (np && hipMemcpy(rp.pos, mi->pos.data(), np * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(MM355_EHIP);
+	}
+	if (!mi->S.empty() && hipMemcpy(rp.S, mi->S.data(), std::min(Sb, mi->S.size() * 4), hipMemcpyHostToDevice) != hipSuccess) return fail(MM355_EHIP);
+	if (hipMemcpy(rp.seq_off, mi->seq_off.data(), (size_t)mi->n_seq * 8, hipMemcpyHostToDevice) != hipSuccess ||
+	    hipMemcpy(rp.seq_len, mi->seq_len.data(), (size_t)mi->n_seq * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MM355_EHIP);
+	mi->replicas.push_back(rp);
+	(void)hipSetDevice(prev);
+	*out = rp;
+	return 0;
+}
+
+void mm355_index_free_replicas(mm355_index *mi)
+{
+	std::lock_guard<std::mutex> lk(mi->rep_mu);
+	int prev = 0; (void)hipGetDevice(&prev);
+	for (mm355_replica &r : mi->replicas) {
+		(void)hipSetDevice(r.dev);
+		if (r.slots) (void)hipFree(r.slots); if (r.pos) (void)hipFree(r.pos); if (r.S) (void)hipFree(r.S);
+		if (r.seq_off) (void)hipFree(r.seq_off); if (r.seq_len) (void)hipFree(r.seq_len);
+	}
+	if (!mi->replicas.empty()) (void)hipSetDevice(prev);
+	mi->replicas.clear();
+	mi->d_slots = mi->d_pos = mi->d_S = 0;
+}
+
+// replicates the index into the HBM of every listed device (idempotent); contexts of those devices then share the replica
+extern "C" int mm355_upload(mm355_index_t *mi, const int *device_ids, int n)
+{
+	if (mi == 0) return MM355_ENOIDX;
+	if (n < 0 || (n > 0 && device_ids == 0)) return MM355_EINVAL;
+	int nd = 0;
+	if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0) return MM355_ENODEV;
+	for (int i = 0; i < n; ++i) {
+		if (device_ids[i] < 0 || device_ids[i] >= nd) return MM355_ENODEV;
+		mm355_replica rp;
+		int rc = mm355_index_replica(mi, device_ids[i], &rp);
+		if (rc) return rc;
+	}
+	return 0;
+}
+
 extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 {
 	if (c == 0) return;
 	(void)hipSetDevice(c->dev);
-	DBuf *bufs[] = { &c->ix_slots, &c->ix_pos, &c->ix_S, &c->ix_off, &c->ix_len, &c->sort_tasks, &c->sort_tmp, &c->sort_flag, &c->tie_list, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
+	DBuf *bufs[] = { &c->sort_tasks, &c->sort_tmp, &c->sort_flag, &c->tie_list, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
 		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
@@ -315,6 +363,7 @@ int mm355_run_sort(mm355_ctx *c)
 			for (int i = 0; i < n_reads; ++i) if (flag[i]) tl.push_back(i);
 			std::stable_sort(tl.begin(), tl.end(), [&](int32_t x, int32_t y) { return c->hb.n_a[x] > c->hb.n_a[y]; });
 			n_list = (int)tl.size(); n_heavy = 0;
+			c->stats.n_sort_fast_reads += n_reads; c->stats.n_sort_tie_reads += n_list;
 			for (int i = 0; i < n_list && c->hb.n_a[tl[i]] > mm355_sort_heavy_threshold(); ++i) ++n_heavy;
 			if (n_list) {
 				if (c->tie_list.ensure((size_t)n_list * 4 + 64)) return MM355_ENOMEM;

@@ -10,10 +10,13 @@ each call minimap2's mm_map (lib.rs:541-636), this module hands whole batches to
 mandatory: importing works without a GPU (so the API can be inspected), but creating an
 Aligner that maps reads requires the HIP library and a visible MI355X -- there is no CPU path.
 """
+import collections
 import collections.abc
 import ctypes as C
 import os
+import queue
 import threading
+import time
 
 # ROCclr multiplexes all HIP streams over GPU_MAX_HW_QUEUES hardware queues (default 4); the pipelined map_batch keeps several contexts in
 # flight and measures best with 8 (bench.py sets the same).  Only effective if the HIP runtime has not been started yet.
@@ -23,7 +26,7 @@ import numpy as np
 
 from . import _ffi
 
-__all__ = ["Aligner", "Mapping"]
+__all__ = ["Aligner", "Mapping", "shard_by_bases"]
 
 _CIGAR_OPS = "MIDNSHP=X"
 
@@ -135,45 +138,136 @@ def _batch_to_mappings(hp, n_reads, names):
     return out
 
 
-class AlignmentBatchResultIter:
-    """Iterator returned by map_batch (lib.rs:923-991): yields (list[Mapping], original_dict)."""
+def shard_by_bases(lengths, n_shards):
+    """a batch is cut into `n_shards` CONTIGUOUS shards balanced by cumulative bases (not by read count): a read belongs to
+    the shard that contains the midpoint of its span on the cumulative-bases axis.  Returns n_shards+1 boundaries b with shard
+    s = items[b[s]:b[s+1]]; every item belongs to exactly one shard."""
+    n_shards = max(1, int(n_shards))
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n = len(lengths)
+    if n == 0:
+        return [0] * (n_shards + 1)
+    cum = np.cumsum(lengths)
+    total = max(1, int(cum[-1]))
+    mid2 = 2 * cum - lengths                      # twice the midpoint, exact in integers
+    shard = np.minimum(n_shards - 1, (mid2 * n_shards) // (2 * total))
+    return [int(np.searchsorted(shard, s, side="left")) for s in range(n_shards)] + [n]
 
-    def __init__(self, results):
-        self._results = results
-        self._i = 0
+
+class _Channel:
+    """bounded multi-producer channel (crossbeam `bounded(20000)`, lib.rs:950): producers block while it is full, the consumer blocks
+    while it is empty; both waits release the GIL."""
+
+    def __init__(self, cap):
+        self.cap = cap
+        self.d = collections.deque()
+        self.cv = threading.Condition()
+
+    def put_many(self, items, cancel):
+        """appends the entries in order, waiting whenever the channel is full; False when `cancel` was set while waiting"""
+        i, n = 0, len(items)
+        with self.cv:
+            while i < n:
+                while len(self.d) >= self.cap:
+                    if cancel.is_set():
+                        return False
+                    self.cv.wait(0.2)
+                room = self.cap - len(self.d)
+                self.d.extend(items[i:i + room])
+                i += room
+                self.cv.notify_all()
+        return True
+
+    def get(self):
+        with self.cv:
+            while not self.d:
+                self.cv.wait()
+            x = self.d.popleft()
+            if len(self.d) == self.cap - 1:
+                self.cv.notify_all()      # a producer may be waiting for room
+            return x
+
+    def __len__(self):
+        return len(self.d)
+
+
+class AlignmentBatchResultIter:
+    """Iterator returned by map_batch (lib.rs:923-991): yields (list[Mapping], dict) in COMPLETION order.
+
+    Mirrors the reference's plumbing: workers push results into a bounded channel (20 000 entries, lib.rs:950) and `__next__`
+    blocks on it (`rx.recv()`, lib.rs:973) -- here with the GIL released.  A full channel blocks the workers: a slow consumer holds
+    back the GPU pipeline instead of growing memory (back-pressure).  `Finished` arrives after every worker is done (lib.rs:804-815)."""
+
+    _FINISHED = object()
+
+    def __init__(self):
+        self._ch = _Channel(RESULT_CHANNEL_CAP)
+        self._done = False
+        self._cancel = threading.Event()      # workers stop taking sub-batches (worker error, validation error, abandoned iterator)
+        self._abandoned = threading.Event()   # nobody will ever read the channel again
+        self._errors = []
+        self.n_sub_batches = 0
+        self.t_sub_done = []      # wall-clock time each sub-batch left the GPU pipeline (tests / latency diagnostics)
+        self.t_first_yield = None
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        if self._i >= len(self._results):
+        if self._done:
             raise StopIteration("Finished")
-        r = self._results[self._i]
-        self._results[self._i] = None
-        self._i += 1
+        r = self._ch.get()
+        if r is AlignmentBatchResultIter._FINISHED:
+            self._done = True
+            if self._errors:
+                raise self._errors[0]
+            raise StopIteration("Finished")
+        if self.t_first_yield is None:
+            self.t_first_yield = time.perf_counter()
         return r
+
+    def close(self):
+        """stop mapping what has not been started yet; results already produced are dropped"""
+        self._cancel.set()
+        self._abandoned.set()
+
+    def __del__(self):
+        self.close()
 
 
 class Aligner:
-    """mappy-compatible aligner (lib.rs:288-671) whose mapping path runs on one MI355X."""
+    """mappy-compatible aligner (lib.rs:288-671) whose mapping path runs on MI355X GPUs.
+
+    `device` / `devices` are the only additions to the reference's constructor: the GPU (or list of GPUs of one node) that map
+    this Aligner's reads.  With several devices the index is replicated into each one's HBM (mm355_upload) and `map_batch` deals
+    its sub-batches to the contexts of all of them -- the GPU analogue of the reference's N worker threads over one shared index
+    (lib.rs:541-636).  Reads are independent: no collective."""
 
     def __init__(self, fn_idx_in=None, preset=None, k=None, w=None, min_cnt=None, min_chain_score=None,
                  min_dp_score=None, bw=None, best_n=None, n_threads=3, fn_idx_out=None, max_frag_len=None,
-                 extra_flags=None, seq=None, scoring=None, device=0):
+                 extra_flags=None, seq=None, scoring=None, device=0, devices=None):
         L = _ffi.lib()
         self._L = L
         self._idx = C.c_void_p()
         self._ctx = C.c_void_p()
-        self._wctx = []                      # contexts of the map_batch pipeline workers (one per host thread)
+        self._wctx = {}                      # device -> free contexts of the map_batch pipeline workers (one per host thread)
         self._name_cache = None
-        self._device = device
+        self._devices = [int(d) for d in devices] if devices is not None else [int(device)]
+        if not self._devices:
+            raise ValueError("`devices` must name at least one GPU")
+        self._device = self._devices[0]
         self._n_threads = 0
         self._lock = threading.Lock()
         io, mo = _ffi.IdxOpt(), _ffi.MapOpt()
         L.mm355_set_opt(None, C.byref(io), C.byref(mo))
-        self._preset_rc = 0
         if preset is not None:
-            self._preset_rc = L.mm355_set_opt(str(preset).encode(), C.byref(io), C.byref(mo))
+            rc = L.mm355_set_opt(str(preset).encode(), C.byref(io), C.byref(mo))
+            # The reference ignores mm_set_opt's return value (lib.rs:336): an unknown name leaves the defaults in place, silently, and so
+            # does this mirror (MM355_EINVAL).  A preset minimap2 knows but this path does not implement (sr, splice, map-pb ...) must not be
+            # mapped with other parameters behind the caller's back: refuse.
+            if rc == _ffi.MM355_EUNSUP:
+                raise NotImplementedError("preset %r is not implemented by the MI355X mapping path (long-read presets only: map-ont, "
+                                          "map-hifi, asm5/asm10/asm20, ava-ont)" % (preset,))
         mo.flag |= 4                       # MM_F_CIGAR, lib.rs:339
         io.batch_size |= 0x7fffffffffffffff  # lib.rs:340
         if k is not None: io.k = k
@@ -203,6 +297,11 @@ class Aligner:
         if rc != 0 or not self._idx:
             raise RuntimeError("Did not create or open an index")
         L.mm355_mapopt_update(C.byref(mo), self._idx)
+        if len(self._devices) > 1:         # replicate now, so that the first map_batch does not pay for it
+            arr = (C.c_int32 * len(self._devices))(*self._devices)
+            rc = L.mm355_upload(self._idx, arr, len(self._devices))
+            if rc != 0:
+                raise RuntimeError("mm355: " + L.mm355_strerror(rc).decode())
 
     # ---- properties (lib.rs:439-470, 651-670)
     def _info(self):
@@ -229,9 +328,11 @@ class Aligner:
         return [self._L.mm355_index_seq_name(self._idx, i).decode() for i in range(self.n_seq)]
 
     def seq(self, name, start=0, end=0x7fffffff):
-        """lib.rs:464-470 with the rules of lib.rs:706-766: None on any error."""
+        """lib.rs:464-470 with the rules of lib.rs:706-766: None on any error (incl. "No sequence in this index", lib.rs:710-714)."""
         L = self._L
         if not self._idx:
+            return None
+        if (self._mo.flag & 4) and (self._info()[3] & 2):      # MM_F_CIGAR && MM_I_NO_SEQ
             return None
         rid = L.mm355_index_name2id(self._idx, name.encode())
         if rid < 0:
@@ -277,14 +378,23 @@ class Aligner:
             self._name_cache = [nm.decode() if nm is not None else None for nm in (self._L.mm355_index_seq_name(self._idx, i) for i in range(self.n_seq))]
         return self._name_cache
 
-    def _worker_contexts(self, n):
-        while len(self._wctx) < n:
-            ctx = C.c_void_p()
-            rc = self._L.mm355_ctx_create(self._idx, self._device, C.byref(ctx))
-            if rc != 0:
-                raise RuntimeError(self._L.mm355_strerror(rc).decode())
-            self._wctx.append(ctx)
-        return self._wctx[:n]
+    def _ctx_acquire(self, slot):
+        """a free worker context on GPU devices[slot % n_devices] (created on demand; contexts are pooled per device and never shared
+        between two running workers, also not between two overlapping map_batch calls)"""
+        dev = self._devices[slot % len(self._devices)]
+        with self._lock:
+            free = self._wctx.setdefault(dev, [])
+            if free:
+                return dev, free.pop()
+        ctx = C.c_void_p()
+        rc = self._L.mm355_ctx_create(self._idx, dev, C.byref(ctx))
+        if rc != 0:
+            raise RuntimeError(self._L.mm355_strerror(rc).decode())
+        return dev, ctx
+
+    def _ctx_release(self, dev_ctx):
+        with self._lock:
+            self._wctx.setdefault(dev_ctx[0], []).append(dev_ctx[1])
 
     # ---- single read (lib.rs:473-514)
     def map(self, seq, seq2=None, cs=False, MD=False):
@@ -303,84 +413,121 @@ class Aligner:
         """canned record of lib.rs:675-693 (binding-overhead probe)"""
         if seq2 is not None:
             raise NotImplementedError("Using `seq2` is not implemented")
-        return [Mapping(0, 0, 1, "No_op", 0, 0, 0, 0, 0, 0, True, [], 0, None, None)]
+        return [Mapping(0, 1000, 1, "Hello", 101010, 10, 1010, 1000, 1000, 60, True, [], 0, None, "Cigar string")]
 
     # ---- batch path (lib.rs:541-648, 771-906)
     def enable_threading(self, n_threads):
         """In the reference this spawns N mm_map worker threads; here it arms the GPU batch path: map_batch drives up to
-        min(n_threads, 8) host threads, each with its own context (HIP streams + buffers) on the one GPU."""
+        min(n_threads, 8) host threads per GPU, each with its own context (HIP streams + buffers)."""
         self._n_threads = int(n_threads)
 
     def map_batch(self, seqs, back_off=True):
+        """lib.rs:639-648, 771-906.  The iterable is consumed completely before the iterator is returned (lib.rs:845-903), but -- as in the
+        reference, whose workers pop the queue while `_map_batch` is still pushing -- mapping starts as soon as the first sub-batch of reads
+        has been taken from it, and results stream out of the returned iterator in completion order while later sub-batches are still on the
+        GPU (lib.rs:793-839: collector thread -> bounded channel -> `__next__`)."""
         if self._n_threads == 0:
             raise RuntimeError("Multi threading not enabled on this instance. Please call `.enable_threading()`")
         # accepted iterables: list / tuple / iterator / generator / sequence -- not dict, not str (lib.rs:782-792, 910-920)
         if isinstance(seqs, (dict, str, bytes)) or not (isinstance(seqs, (list, tuple, collections.abc.Sequence)) or
                                                         isinstance(seqs, collections.abc.Iterator)):
             raise TypeError("Unsupported batch type, pass a list, iter, generator or tuple")
-        items, reads = [], []
-        for n_pending, item in enumerate(seqs):
-            if not isinstance(item, dict):
-                raise TypeError("Element in iterable is not a dictionary")
-            if "seq" not in item:
-                raise KeyError("AHHH Key \U0001F5DD️  not found in iterated dictionary")
-            s = item["seq"]
-            if not isinstance(s, str):
-                raise ValueError("`seq` must be a string")
-            # capacity rule made deterministic (SURVEY 8b): without back-off more than 50 000 pending items is an error
-            if not back_off and n_pending >= WORK_QUEUE_CAP:
-                raise RuntimeError("Internal error adding data to work queue, without backoff. "
-                                   "Is your fastq batch larger than 50000? Perhaps try `map_batch` with back_off=True?")
-            items.append(item)
-            reads.append(s)
-        # The whole iterable is consumed before the first result is yielded (lib.rs:845-903).  The reads then go through the GPU in
-        # sub-batches of a few thousand reads: `n_threads` host threads (enable_threading; at most 8 are useful) each drive their own
-        # context, so that the front kernels, the host tail and the extension rounds of different sub-batches overlap (DESIGN.md 6).
-        # sub-batch size: at most SUB_BATCH_READS, but small inputs are cut finer so that every worker gets about two sub-batches
-        # (16384 reads: 1024 per sub-batch maps 20 % faster than 4096, 4096 reads 50 % faster)
-        sb_reads = min(SUB_BATCH_READS, max(1024, -(-len(reads) // (2 * max(1, min(self._n_threads, 8))))))
-        subs, lo = [], 0
-        while lo < len(reads):
-            hi, nb = lo, 0
-            while hi < len(reads) and (hi == lo or nb + len(reads[hi]) <= SUB_BATCH_BASES) and hi - lo < sb_reads:
-                nb += len(reads[hi]); hi += 1
-            subs.append((lo, hi))
-            lo = hi
-        n_workers = max(1, min(self._n_threads, 8, len(subs)))
-        out = [None] * len(subs)
-        if n_workers == 1:
-            for k, (a, b) in enumerate(subs):
-                out[k] = self._map_many(reads[a:b], _ffi.OUT_CS)      # cs=true, MD=false: lib.rs:589-590
-        else:
-            ctxs = self._worker_contexts(n_workers)
-            nxt = [0]
-            pick = threading.Lock()
-            errors = []
+        res = AlignmentBatchResultIter()
+        max_workers = max(1, min(self._n_threads, 8)) * len(self._devices)
+        try:
+            n_known = len(seqs)
+        except TypeError:
+            n_known = None
+        # sub-batch size: at most SUB_BATCH_READS; small inputs are cut finer so that every worker gets about two sub-batches (16384 reads:
+        # 1024 per sub-batch maps 20 % faster than 4096).  Unknown length (iterators): ramp up, so that the first results leave early.
+        sb_fixed = None if n_known is None else min(SUB_BATCH_READS, max(1024, -(-n_known // (2 * max_workers))))
 
-            def work(ctx):
+        def sb_size(k):
+            return sb_fixed if sb_fixed is not None else min(SUB_BATCH_READS, 512 << min(3, k // max_workers))
+
+        work = collections.deque()          # sub-batches (reads, items) waiting for a worker
+        cv = threading.Condition()
+        state = {"closed": False, "n_sub": 0}
+        workers = []
+        self._names()                       # fill the name cache before the workers read it
+
+        def worker(slot):
+            ctx = None
+            try:
+                ctx = self._ctx_acquire(slot)
                 while True:
-                    with pick:
-                        k = nxt[0]; nxt[0] += 1
-                    if k >= len(subs) or errors:
+                    with cv:
+                        while not work and not state["closed"] and not res._cancel.is_set():
+                            cv.wait(0.2)
+                        if res._cancel.is_set() or not work:
+                            return
+                        reads, items = work.popleft()
+                    maps = self._map_many(reads, _ffi.OUT_CS, ctx[1])         # cs=true, MD=false: lib.rs:589-590
+                    res.t_sub_done.append(time.perf_counter())
+                    # a worker error on one read => no result for that id (lib.rs:621-623)
+                    out = [(m, it) for m, it in zip(maps, items) if not isinstance(m, Exception)]
+                    if not res._ch.put_many(out, res._cancel):
                         return
-                    a, b = subs[k]
-                    try:
-                        out[k] = self._map_many(reads[a:b], _ffi.OUT_CS, ctx)
-                    except Exception as e:   # surfaced after the join, like a worker panic in the reference
-                        errors.append(e)
-                        return
-            ths = [threading.Thread(target=work, args=(ctx,)) for ctx in ctxs]
-            for t in ths: t.start()
-            for t in ths: t.join()
-            if errors:
-                raise errors[0]
-        results = []
-        for (a, b), maps in zip(subs, out):
-            for j, m in enumerate(maps):
-                if isinstance(m, Exception):
-                    continue                                          # worker error => no result for that id (lib.rs:621-623)
-                results.append((m, items[a + j]))
-        return AlignmentBatchResultIter(results)
+            except Exception as e:   # surfaced by the iterator when it finishes, like a worker panic in the reference
+                res._errors.append(e)
+                res._cancel.set()
+            finally:
+                if ctx is not None:
+                    self._ctx_release(ctx)
+
+        def dispatch(reads, items):
+            with cv:
+                work.append((reads, items))
+                state["n_sub"] += 1
+                cv.notify()
+            if len(workers) < max_workers and len(workers) < state["n_sub"]:
+                t = threading.Thread(target=worker, args=(len(workers),), daemon=True)
+                workers.append(t)
+                t.start()
+
+        def close_and_join():
+            with cv:
+                state["closed"] = True
+                cv.notify_all()
+            for t in workers:
+                t.join()
+
+        cur_reads, cur_items, cur_bases = [], [], 0
+        try:
+            for n_pending, item in enumerate(seqs):
+                if not isinstance(item, dict):
+                    raise TypeError("Element in iterable is not a dictionary")
+                if "seq" not in item:
+                    raise KeyError("AHHH Key \U0001F5DD️  not found in iterated dictionary")
+                s = item["seq"]
+                if not isinstance(s, str):
+                    raise ValueError("`seq` must be a string")
+                # capacity rule made deterministic (SURVEY 8b): without back-off more than 50 000 pending items is an error
+                if not back_off and n_pending >= WORK_QUEUE_CAP:
+                    raise RuntimeError("Internal error adding data to work queue, without backoff. "
+                                       "Is your fastq batch larger than 50000? Perhaps try `map_batch` with back_off=True?")
+                if cur_reads and (len(cur_reads) >= sb_size(state["n_sub"]) or cur_bases + len(s) > SUB_BATCH_BASES):
+                    dispatch(cur_reads, cur_items)
+                    cur_reads, cur_items, cur_bases = [], [], 0
+                cur_reads.append(s)
+                cur_items.append(dict(item))      # the reference hands back its own copy of the dict (lib.rs:849-855, 977-979)
+                cur_bases += len(s)
+            if cur_reads:
+                dispatch(cur_reads, cur_items)
+        except BaseException:
+            res.close()                           # nothing is yielded: the workers stop after their current sub-batch
+            close_and_join()
+            raise
+        res.n_sub_batches = state["n_sub"]
+
+        def finalize():                           # the reference's collector thread: `Finished` once every worker is done (lib.rs:804-815)
+            close_and_join()
+            while not res._ch.put_many([AlignmentBatchResultIter._FINISHED], res._abandoned):
+                if res._abandoned.is_set():
+                    return
+
+        threading.Thread(target=finalize, daemon=True).start()
+        return res
 
     def _stage_runner(self):
         """per-stage access to the same kernels (parity tests, kernel bench)"""
@@ -389,7 +536,8 @@ class Aligner:
     def __del__(self):
         try:
             if self._ctx: self._L.mm355_ctx_destroy(self._ctx)
-            for ctx in self._wctx: self._L.mm355_ctx_destroy(ctx)
+            for ctxs in self._wctx.values():
+                for ctx in ctxs: self._L.mm355_ctx_destroy(ctx)
             if self._idx: self._L.mm355_index_free(self._idx)
         except Exception:
             pass

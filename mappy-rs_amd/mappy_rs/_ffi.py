@@ -64,7 +64,8 @@ class Stats(C.Structure):
                 ("ms_sketch", C.c_double), ("ms_seed", C.c_double), ("ms_sort", C.c_double), ("ms_chain", C.c_double),
                 ("ms_backtrack", C.c_double), ("ms_dp", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double),
                 ("ms_seed_lookup", C.c_double), ("ms_seed_expand", C.c_double), ("n_launch_seed", C.c_int64), ("n_launch_dp", C.c_int64),
-                ("ms_dp_group", C.c_double * 16), ("dp_cells_group", C.c_int64 * 16), ("n_launch_group", C.c_int64 * 16)]
+                ("ms_dp_group", C.c_double * 16), ("dp_cells_group", C.c_int64 * 16), ("n_launch_group", C.c_int64 * 16),
+                ("n_ext_rounds", C.c_int64), ("n_sort_fast_reads", C.c_int64), ("n_sort_tie_reads", C.c_int64)]
 
 
 class DpJob(C.Structure):
@@ -81,7 +82,7 @@ class DpRes(C.Structure):
 EXPORTS = [
     "mm355_set_opt", "mm355_mapopt_update", "mm355_index_load", "mm355_index_build", "mm355_index_build_device", "mm355_index_free",
     "mm355_index_info", "mm355_index_seq_name", "mm355_index_seq_len", "mm355_index_name2id", "mm355_index_getseq",
-    "mm355_index_get", "mm355_index_stat", "mm355_ctx_create", "mm355_ctx_destroy", "mm355_map_batch",
+    "mm355_index_get", "mm355_index_stat", "mm355_upload", "mm355_ctx_create", "mm355_ctx_destroy", "mm355_map_batch",
     "mm355_free_hits", "mm355_batch_upload", "mm355_batch_select", "mm355_map_resident", "mm355_stage_sketch", "mm355_stage_anchors", "mm355_stage_chain", "mm355_stage_chains",
     "mm355_stage_dp", "mm355_get_stats", "mm355_device_count", "mm355_device_synchronize", "mm355_strerror", "mm355_version",
 ]
@@ -115,6 +116,7 @@ def lib():
     L.mm355_index_getseq.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.mm355_index_get.argtypes = [vp, C.c_uint64, vp, C.c_int]
     L.mm355_index_stat.argtypes = [vp, i64p, i64p, i64p, i64p]
+    L.mm355_upload.argtypes = [vp, i32p, C.c_int]
     L.mm355_ctx_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.mm355_ctx_destroy.argtypes = [vp]
     L.mm355_map_batch.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, C.POINTER(C.c_char_p), i32p, C.c_int, C.POINTER(C.POINTER(Hits))]

@@ -225,6 +225,7 @@ void mmo_sketch(const char *str, int len, int w, int k, uint32_t rid, int is_hpc
 /* ---- index.c (U:index.c) ---- */
 mmo_idx_t *mmo_idx_load(const char *fn, const mmo_idxopt_t *io);   /* .mmi or FASTA, decided by magic */
 mmo_idx_t *mmo_idx_build_mem(int w, int k, int b, int flag, int n_seq, const char **seqs, const int *lens, const char **names);
+mmo_idx_t *mmo_idx_build_mem_mt(int w, int k, int b, int flag, int n_seq, const char **seqs, const int *lens, const char **names, int n_threads);
 void mmo_idx_destroy(mmo_idx_t *mi);
 const uint64_t *mmo_idx_get(const mmo_idx_t *mi, uint64_t minier, int *n);
 int mmo_idx_getseq(const mmo_idx_t *mi, uint32_t rid, uint32_t st, uint32_t en, uint8_t *seq);

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <assert.h>
+#include <pthread.h>
 #include "mmo.h"
 
 #define MM_IDX_MAGIC "MMI\2"
@@ -338,6 +339,113 @@ mmo_idx_t *mmo_idx_build_mem(int w, int k, int b, int flag, int n_seq, const cha
 	for (i = 0; i < n_seq; ++i)
 		idx_add_seq(mi, &sum_len, &m_S, names? names[i] : 0, seqs[i], lens[i]);
 	idx_finish(mi);
+	return mi;
+}
+
+/* Threaded build (U:index.c::mm_idx_gen runs its pipeline with kt_for over the sequences of a mini-batch for mm_sketch and kt_for
+ * over the buckets for worker_post; same two parallel loops here, with plain pthreads).  A worker sketches whole sequences and
+ * files the minimizers into its OWN per-bucket lists; the bucket loop concatenates the workers' lists of a bucket and runs
+ * bucket_post on it.  The index does not depend on the insertion order: worker_post sorts a bucket by minimizer and each
+ * position run by position.  Used by bench.py's cpu_baseline on the GRCh38-scale genome (a single-threaded build of 3.1 Gbp
+ * does not fit the bench's time budget); seqs[i] may be ASCII or raw codes 0..4 (seq_nt4_table maps both). */
+typedef struct {
+	mmo_idx_t *mi; int n_seq, n_threads, tid;
+	const char **seqs; const int *lens;
+	volatile int *next_seq; volatile int *next_bucket;
+	mm128_v *local;            /* [1<<b] lists of this worker */
+	mm128_v **all_local;       /* [n_threads] */
+} bld_worker_t;
+
+static void *bld_sketch_worker(void *arg)
+{
+	bld_worker_t *w = (bld_worker_t*)arg;
+	mmo_idx_t *mi = w->mi;
+	int mask = (1<<mi->b) - 1;
+	for (;;) {
+		int i = __sync_fetch_and_add(w->next_seq, 1);
+		mm128_v a = {0,0,0};
+		size_t j;
+		if (i >= w->n_seq) break;
+		if (w->lens[i] <= 0) continue;
+		if (!(mi->flag & MM_I_NO_SEQ)) {   /* pack S; sequences may share a 32-bit word at their border: atomic OR on the first and last word */
+			uint64_t o0 = mi->seq[i].offset, o1 = o0 + (uint64_t)w->lens[i], o;
+			for (o = o0; o < o1; ++o) {
+				int c = mmo_seq_nt4_table[(uint8_t)w->seqs[i][o - o0]];
+				uint32_t v = (uint32_t)c << ((o&7)<<2);
+				if ((o>>3) == (o0>>3) || (o>>3) == ((o1-1)>>3)) __sync_fetch_and_or(&mi->S[o>>3], v);
+				else mi->S[o>>3] |= v;
+			}
+		}
+		mmo_sketch(w->seqs[i], w->lens[i], mi->w, mi->k, (uint32_t)i, mi->flag&MM_I_HPC, &a);
+		for (j = 0; j < a.n; ++j) {
+			mm128_v *p = &w->local[a.a[j].x>>8&mask];
+			if (p->n == p->m) {
+				p->m = p->m? p->m<<1 : 8;
+				p->a = (mm128_t*)realloc(p->a, p->m * sizeof(mm128_t));
+			}
+			p->a[p->n++] = a.a[j];
+		}
+		free(a.a);
+	}
+	return 0;
+}
+
+static void *bld_post_worker(void *arg)
+{
+	bld_worker_t *w = (bld_worker_t*)arg;
+	mmo_idx_t *mi = w->mi;
+	for (;;) {
+		int i = __sync_fetch_and_add(w->next_bucket, 1), t;
+		size_t tot = 0;
+		mmo_bucket_t *b;
+		if (i >= 1<<mi->b) break;
+		b = &mi->B[i];
+		for (t = 0; t < w->n_threads; ++t) tot += w->all_local[t][i].n;
+		if (tot == 0) continue;
+		b->a.a = (mm128_t*)malloc(tot * sizeof(mm128_t)); b->a.m = tot; b->a.n = 0;
+		for (t = 0; t < w->n_threads; ++t) {
+			mm128_v *p = &w->all_local[t][i];
+			if (p->n) memcpy(b->a.a + b->a.n, p->a, p->n * sizeof(mm128_t));
+			b->a.n += p->n;
+			free(p->a); p->a = 0; p->n = p->m = 0;
+		}
+		bucket_post(mi, b);
+	}
+	return 0;
+}
+
+mmo_idx_t *mmo_idx_build_mem_mt(int w, int k, int b, int flag, int n_seq, const char **seqs, const int *lens, const char **names, int n_threads)
+{
+	mmo_idx_t *mi = idx_init(w, k, b, flag);
+	uint64_t sum_len = 0;
+	volatile int next_seq = 0, next_bucket = 0;
+	int i, t;
+	pthread_t *th;
+	bld_worker_t *ws;
+	mm128_v **locals;
+	if (n_threads < 1) n_threads = 1;
+	mi->seq = (mmo_idx_seq_t*)calloc(n_seq > 0? n_seq : 1, sizeof(mmo_idx_seq_t));
+	for (i = 0; i < n_seq; ++i) {
+		mi->seq[i].name = (mi->flag & MM_I_NO_NAME) || names == 0 || names[i] == 0? 0 : strdup(names[i]);
+		mi->seq[i].len = lens[i], mi->seq[i].offset = sum_len, mi->seq[i].is_alt = 0;
+		sum_len += lens[i];
+	}
+	mi->n_seq = n_seq;
+	if (!(mi->flag & MM_I_NO_SEQ)) mi->S = (uint32_t*)calloc((sum_len + 7) / 8 + 1, 4);
+	th = (pthread_t*)calloc(n_threads, sizeof(pthread_t));
+	ws = (bld_worker_t*)calloc(n_threads, sizeof(bld_worker_t));
+	locals = (mm128_v**)calloc(n_threads, sizeof(mm128_v*));
+	for (t = 0; t < n_threads; ++t) {
+		locals[t] = (mm128_v*)calloc((size_t)1<<mi->b, sizeof(mm128_v));
+		ws[t].mi = mi; ws[t].n_seq = n_seq; ws[t].n_threads = n_threads; ws[t].tid = t; ws[t].seqs = seqs; ws[t].lens = lens;
+		ws[t].next_seq = &next_seq; ws[t].next_bucket = &next_bucket; ws[t].local = locals[t]; ws[t].all_local = locals;
+	}
+	for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, bld_sketch_worker, &ws[t]);
+	for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+	for (t = 0; t < n_threads; ++t) pthread_create(&th[t], 0, bld_post_worker, &ws[t]);
+	for (t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+	for (t = 0; t < n_threads; ++t) free(locals[t]);
+	free(locals); free(ws); free(th);
 	return mi;
 }
 

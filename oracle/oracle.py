@@ -105,6 +105,9 @@ def lib():
         L.mmo_idx_build_mem.restype = C.POINTER(Idx)
         L.mmo_idx_build_mem.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
                                         C.POINTER(C.c_int), C.POINTER(C.c_char_p)]
+        L.mmo_idx_build_mem_mt.restype = C.POINTER(Idx)
+        L.mmo_idx_build_mem_mt.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_int), C.POINTER(C.c_char_p), C.c_int]
         L.mmo_idx_destroy.argtypes = [C.POINTER(Idx)]
         L.mmo_idx_get.restype = C.POINTER(C.c_uint64)
         L.mmo_idx_get.argtypes = [C.POINTER(Idx), C.c_uint64, C.POINTER(C.c_int)]
@@ -149,7 +152,7 @@ class OracleAligner:
 
     def __init__(self, fn_idx_in=None, preset=None, k=None, w=None, min_cnt=None, min_chain_score=None,
                  min_dp_score=None, bw=None, best_n=None, max_frag_len=None, extra_flags=None, scoring=None,
-                 seqs=None, names=None):
+                 seqs=None, names=None, codes=None, n_threads=1):
         L = lib()
         self.io, self.mo = IdxOpt(), MapOpt()
         L.mmo_set_opt(None, C.byref(self.io), C.byref(self.mo))
@@ -172,7 +175,14 @@ class OracleAligner:
                 self.mo.q2, self.mo.e2 = scoring[4:6]
                 if len(scoring) >= 7:
                     self.mo.sc_ambi = scoring[6]
-        if seqs is not None:
+        if codes is not None:      # contigs as numpy uint8 code arrays (0..4), no copy; threaded build (mmo_idx_build_mem_mt)
+            n = len(codes)
+            keep = [np.ascontiguousarray(c, dtype=np.uint8) for c in codes]
+            arr = (C.c_void_p * n)(*[c.ctypes.data for c in keep])
+            lens = (C.c_int * n)(*[len(c) for c in keep])
+            nm = (C.c_char_p * n)(*[(names[i] if names else "ref%d" % i).encode() for i in range(n)])
+            self.idx = L.mmo_idx_build_mem_mt(self.io.w, self.io.k, self.io.bucket_bits, self.io.flag, n, arr, lens, nm, int(n_threads))
+        elif seqs is not None:
             n = len(seqs)
             bs = [s if isinstance(s, bytes) else s.encode() for s in seqs]
             arr = (C.c_char_p * n)(*bs)

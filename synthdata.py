@@ -232,3 +232,54 @@ def make_reads_codes(seed, contigs, n_reads, n50=10000, sigma=0.75, lo=500, hi=1
         out.append(mutate(seg, rng, sub, ins, dele).tobytes())
         truth.append((ci, st, st + L, strand))
     return out, truth
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ONE read set that any number of ranks can shard: the set is a sequence of fixed-size blocks, block b drawn from its own
+# PCG64 stream (seed, b), so a rank can list the lengths of every read cheaply and synthesise only the blocks its shard overlaps.
+READ_BLOCK = 4096
+
+
+def block_lengths(seed, block, n50=10000, sigma=0.75, lo=500, hi=100000):
+    """lengths of the READ_BLOCK reads of block `block` (the first draw of the block's stream)"""
+    return read_lengths(_rng([int(seed), int(block)]), READ_BLOCK, n50, sigma, lo, hi)
+
+
+def read_set_lengths(seed, n_reads, **kw):
+    """lengths of reads 0..n_reads-1 of the read set `seed` (nominal lengths, before clipping to the contig and before indel errors)"""
+    nb = (n_reads + READ_BLOCK - 1) // READ_BLOCK
+    if nb == 0:
+        return np.zeros(0, np.int64)
+    return np.concatenate([block_lengths(seed, b, **kw) for b in range(nb)])[:n_reads]
+
+
+def make_read_block(seed, block, contigs, n50=10000, sigma=0.75, lo=500, hi=100000, sub=0.024, ins=0.016, dele=0.020, as_codes=True):
+    """the READ_BLOCK reads of block `block`: list of code bytes (0..4) or ASCII strings, plus the truth tuples"""
+    rng = _rng([int(seed), int(block)])
+    lens = np.array([len(c) for c in contigs], dtype=np.int64)
+    lengths = read_lengths(rng, READ_BLOCK, n50, sigma, lo, hi)
+    cis = rng.choice(len(contigs), size=READ_BLOCK, p=lens / lens.sum())
+    out, truth = [], []
+    for i in range(READ_BLOCK):
+        ci = int(cis[i])
+        L = int(min(lengths[i], lens[ci]))
+        st = int(rng.integers(0, lens[ci] - L + 1))
+        seg = contigs[ci][st:st + L]
+        strand = 1
+        if rng.random() < 0.5:
+            strand = -1
+            seg = np.where(seg < 4, 3 - seg, 4).astype(np.uint8)[::-1]
+        rd = mutate(seg, rng, sub, ins, dele)
+        out.append(rd.tobytes() if as_codes else codes_to_str(rd))
+        truth.append((ci, st, st + L, strand))
+    return out, truth
+
+
+def read_set_slice(seed, lo_idx, hi_idx, contigs, **kw):
+    """reads lo_idx..hi_idx-1 of the read set `seed` (only the overlapping blocks are synthesised)"""
+    out = []
+    for b in range(lo_idx // READ_BLOCK, (hi_idx + READ_BLOCK - 1) // READ_BLOCK):
+        rd, _ = make_read_block(seed, b, contigs, **kw)
+        b0 = b * READ_BLOCK
+        out.extend(rd[max(lo_idx, b0) - b0:min(hi_idx, b0 + READ_BLOCK) - b0])
+    return out

@@ -1,0 +1,120 @@
+"""BASELINE.json configs[2] (GRCh38-scale, map-ont) and configs[4] (GRCh38-scale, map-hifi) on the GPU.
+ * full size (3.09 Gbp synthetic genome, index built on the device): the size-independent properties of tests/_props.py;
+ * mid scale (155 Mbp: mid_occ in the hundreds, thousands of anchors per read): bit-exact parity with the oracle, and the code paths
+   that only anchor-rich reads reach must actually have run (segmented sort + tie emulation, the eight-wave extension classes incl. the
+   HBM-state one) -- asserted from mm355_get_stats."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+import synthdata as S
+from _props import check_properties
+
+HIFI = dict(n50=18000, sigma=0.14, lo=5000, hi=60000, sub=0.0005, ins=0.00075, dele=0.00075)
+ONT = dict(n50=10000, sigma=0.75, lo=500, hi=100000)
+
+
+def build_device_index(L, _ffi, g, names, preset):
+    io, mo = _ffi.IdxOpt(), _ffi.MapOpt()
+    L.mm355_set_opt(None, C.byref(io), C.byref(mo))
+    _ffi.check(L.mm355_set_opt(preset.encode(), C.byref(io), C.byref(mo))); mo.flag |= 4
+    ptrs = (C.c_char_p * len(g))(*[C.cast(c.ctypes.data, C.c_char_p) for c in g])
+    lens = (C.c_int64 * len(g))(*[len(c) for c in g]); nm = (C.c_char_p * len(g))(*[n.encode() for n in names])
+    idx = C.c_void_p()
+    _ffi.check(L.mm355_index_build_device(C.byref(io), len(g), ptrs, lens, nm, 0, C.byref(idx)))
+    L.mm355_mapopt_update(C.byref(mo), idx)
+    return idx, mo
+
+
+@pytest.fixture(scope="module")
+def human_full(built):
+    return S.make_human_like(3, 1.0)
+
+
+@pytest.fixture(scope="module")
+def human_mid(built):
+    return S.make_human_like(3, 0.05)
+
+
+@pytest.mark.parametrize("preset,seed,kw,n", [("map-ont", 4, ONT, 3072), ("map-hifi", 6, HIFI, 1024)])
+def test_full_size_human_properties(human_full, preset, seed, kw, n):
+    from mappy_rs import _ffi
+    L = _ffi.lib()
+    g, names = human_full
+    reads, truth = S.make_read_block(seed, 0, g, **kw)
+    reads, truth = reads[:n], truth[:n]
+    idx, mo = build_device_index(L, _ffi, g, names, preset)
+    ctx = C.c_void_p()
+    _ffi.check(L.mm355_ctx_create(idx, 0, C.byref(ctx)))
+    try:
+        assert mo.mid_occ > 100, mo.mid_occ                      # a GRCh38-scale occurrence threshold (383 for map-ont on this genome)
+        n_hits, n_right = check_properties(L, ctx, mo, reads, truth, [0, 500, 503, n // 2, n])
+        assert n_hits >= 0.95 * n and n_right >= 0.93 * n, (n_hits, n_right)
+        st = _ffi.Stats(); L.mm355_get_stats(ctx, C.byref(st))
+        if preset == "map-ont":
+            assert st.n_a / st.n_reads > 2048                    # anchor-rich: the segmented-sort path
+    finally:
+        L.mm355_ctx_destroy(ctx)
+        L.mm355_index_free(idx)
+
+
+def _sv_reads(g, rng):
+    """reads with a long diverged stretch between two clean flanks: the long-join gap fill is an extension problem with a target > 12288
+    bases (the HBM-state class of k_ksw_extd2<512>)"""
+    out = []
+    for ci in (0, 3, 7):
+        c = g[ci]
+        st = int(rng.integers(len(c) // 8, len(c) // 4))
+        seg = c[st:st + 34000].copy()
+        if (seg == 4).any():
+            continue
+        mid = S.mutate(seg[9000:24000], rng, 0.30, 0.02, 0.02)
+        rd = np.concatenate([S.mutate(seg[:9000], rng, 0.01, 0.005, 0.005), mid, S.mutate(seg[24000:], rng, 0.01, 0.005, 0.005)])
+        out.append(rd.tobytes())
+        out.append(np.where(rd < 4, 3 - rd, 4).astype(np.uint8)[::-1].tobytes())
+    return out
+
+
+@pytest.mark.parametrize("preset,seed,kw", [("map-ont", 4, ONT), ("map-hifi", 6, HIFI)])
+def test_mid_scale_human_parity(human_mid, preset, seed, kw):
+    from mappy_rs import _ffi
+    import mappy_rs
+    L = _ffi.lib()
+    g, names = human_mid
+    reads, _ = S.make_read_block(seed, 1, g, **kw)
+    reads = reads[:96] + _sv_reads(g, np.random.default_rng(77))
+    idx, mo = build_device_index(L, _ffi, g, names, preset)
+    orc = O.OracleAligner(codes=g, names=names, preset=preset, n_threads=16)
+    assert orc.mo.mid_occ == mo.mid_occ and mo.mid_occ >= 100, (orc.mo.mid_occ, mo.mid_occ)
+    ctx = C.c_void_p()
+    _ffi.check(L.mm355_ctx_create(idx, 0, C.byref(ctx)))
+    try:
+        rarr, rlens, keep = _ffi.pack_reads(reads)
+        hp = C.POINTER(_ffi.Hits)()
+        _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(reads), rarr, rlens, 1, C.byref(hp)))
+        got = mappy_rs._batch_to_mappings(hp, len(reads), names)
+        L.mm355_free_hits(hp)
+        st = _ffi.Stats(); L.mm355_get_stats(ctx, C.byref(st))
+        n_hits = 0
+        for i, rd in enumerate(reads):
+            exp = orc.map(rd, cs=True)
+            assert len(got[i]) == len(exp), (i, len(got[i]), len(exp))
+            for m, e in zip(got[i], exp):
+                assert (m.target_name, m.target_start, m.target_end, m.query_start, m.query_end, m.strand, m.mapq, m.is_primary, m.NM, m.cigar_str, m.cs) == \
+                       (e["target_name"], e["target_start"], e["target_end"], e["query_start"], e["query_end"], e["strand"], e["mapq"], e["is_primary"],
+                        e["NM"], e["cigar_str"], e["cs"]), i
+                n_hits += 1
+        assert n_hits >= 90
+        groups = list(st.n_launch_group)
+        assert sum(groups[8:12]) > 0, groups                       # eight-wave classes (targets 1k..12k) ran
+        assert groups[12] + groups[13] > 0, groups                 # ... and the HBM-state class (targets > 12288)
+        if preset == "map-ont":
+            assert st.n_a / st.n_reads >= 2048, st.n_a / st.n_reads   # anchor-rich batch: segmented radix sort for all reads ...
+            assert st.n_sort_fast_reads == len(reads) and st.n_sort_tie_reads > 0, (st.n_sort_fast_reads, st.n_sort_tie_reads)   # ... + literal tie emulation
+    finally:
+        L.mm355_ctx_destroy(ctx)
+        L.mm355_index_free(idx)

@@ -553,3 +553,99 @@ def test_repeat_rich_genome_device_index_parity(built, tmp_path):
     finally:
         L.mm355_ctx_destroy(ctx)
         L.mm355_index_free(idx)
+
+
+def test_many_zdrop_splits_need_more_than_64_rounds(built, tmp_path):
+    """ADVICE r1 / VERDICT r1: the extension loop used to stop after 64 rounds and emit unaligned regions silently.  A read that is
+    co-linear with the reference but carries ~90 diverged blocks forces a z-drop split per block (each costs a round or two); the result
+    must still equal the oracle's, and the stats must show that more than 64 rounds ran."""
+    from mappy_rs import _ffi
+    import mappy_rs
+    rng = np.random.default_rng(123)
+    g = S.make_genome(61, [400000], repeats=())
+    c = g[0]
+    seg = c[20000:20000 + 140000].copy()
+    for b in range(90):                                   # 700 random bases every 1500: no anchors inside, a z-drop in every gap fill
+        p0 = 800 + b * 1500
+        seg[p0:p0 + 700] = S.random_codes(rng, 700, 0.5)
+    rd = S.codes_to_str(S.mutate(seg, rng, 0.01, 0.003, 0.003))
+    fa = str(tmp_path / "z.fa")
+    S.write_fasta(fa, g, ["chrZ"])
+    al = mappy_rs.Aligner(fa, preset="map-ont")
+    orc = O.OracleAligner(fa, preset="map-ont")
+    ctx = C.c_void_p()
+    _ffi.check(al._L.mm355_ctx_create(al._idx, 0, C.byref(ctx)))
+    try:
+        rarr, rlens, keep = _ffi.pack_reads([rd])
+        hp = C.POINTER(_ffi.Hits)()
+        _ffi.check(al._L.mm355_map_batch(ctx, C.byref(al._mo), 1, rarr, rlens, 3, C.byref(hp)))
+        got = mappy_rs._batch_to_mappings(hp, 1, al._names())[0]
+        al._L.mm355_free_hits(hp)
+        st = _ffi.Stats(); al._L.mm355_get_stats(ctx, C.byref(st))
+        exp = orc.map(rd, cs=True, MD=True)
+        assert len(got) == len(exp) and len(exp) > 40, (len(got), len(exp))
+        for m, e in zip(got, exp):
+            assert rec(m) == orec(e)
+        assert st.n_ext_rounds > 64, st.n_ext_rounds
+    finally:
+        al._L.mm355_ctx_destroy(ctx)
+
+
+def test_no_seq_index_is_refused(built, golden_dir, tmp_path):
+    """MM_I_NO_SEQ index with MM_F_CIGAR (always set): no target sequence to extend against -> error, never garbage"""
+    import mappy_rs
+    from test_oracle_golden import ENTERO
+    mmi = bytearray(open(os.path.join(golden_dir, "test.mmi"), "rb").read())
+    mmi[20:24] = (2).to_bytes(4, "little")
+    f = tmp_path / "noseq.mmi"; f.write_bytes(bytes(mmi[:-((4 * 400 + 7) // 8 * 4)]))
+    al = mappy_rs.Aligner(str(f))
+    with pytest.raises(RuntimeError):
+        al.map(ENTERO)
+
+
+def test_map_batch_streams_results(ont):
+    """SURVEY 8 f3 / lib.rs:793-839: results leave the iterator while later sub-batches are still being mapped; every input yields exactly
+    one tuple carrying a COPY of its dict; completion order may differ from input order"""
+    import time
+    al = ont["al"]
+    reads, _ = S.make_reads(57, ont["g"], 6000, n50=2500, lo=200)
+    items = [{"seq": r, "id": i} for i, r in enumerate(reads)]
+    al.enable_threading(2)
+    it = al.map_batch(iter(items))                    # unknown length: ramped sub-batches
+    first = next(it)
+    t_first = time.perf_counter()
+    rest = list(it)
+    assert it.n_sub_batches >= 4
+    assert t_first < max(it.t_sub_done), "the first result must be available before the last sub-batch has been mapped"
+    out = [first] + rest
+    assert sorted(d["id"] for _, d in out) == list(range(len(items)))
+    assert all(d is not items[d["id"]] and d == items[d["id"]] for _, d in out)
+    # same records as the single-call path
+    by_id = {d["id"]: m for m, d in out}
+    ref = al._map_many(reads[:64], 1)
+    for i in range(64):
+        assert [rec(m) for m in by_id[i]] == [rec(m) for m in ref[i]]
+    with pytest.raises(StopIteration):
+        next(it)
+    # a worker-side failure surfaces from the iterator; a validation failure raises from map_batch itself and leaves the aligner usable
+    with pytest.raises(ValueError, match="`seq` must be a string"):
+        al.map_batch(items[:3000] + [{"seq": 5}])
+    assert len(list(al.map_batch(items[:10]))) == 10
+
+
+def test_multi_device_api_on_one_gpu(ont):
+    """Aligner(devices=[...]) / mm355_upload: replicas are per device and shared by the contexts of that device (exercised with the one GPU
+    of this box; the N-GPU dealing logic itself is covered on CPU by tests/test_multi_gpu_logic.py)"""
+    import mappy_rs
+    from mappy_rs import _ffi
+    al = mappy_rs.Aligner(ont["fa"], preset="map-ont", devices=[0])
+    L = al._L
+    arr = (C.c_int32 * 1)(0)
+    assert L.mm355_upload(al._idx, arr, 1) == 0 and L.mm355_upload(al._idx, arr, 1) == 0      # idempotent
+    bad = (C.c_int32 * 1)(L.mm355_device_count())
+    assert L.mm355_upload(al._idx, bad, 1) == _ffi.MM355_ENODEV
+    reads, _ = S.make_reads(58, ont["g"], 300, n50=3000, lo=200)
+    al.enable_threading(3)
+    got = {d["i"]: m for m, d in al.map_batch([{"seq": r, "i": i} for i, r in enumerate(reads)])}
+    ref = ont["al"]._map_many(reads, 1)
+    assert all([rec(m) for m in got[i]] == [rec(m) for m in ref[i]] for i in range(len(reads)))

@@ -71,7 +71,74 @@ def test_option_presets_match_oracle(ffi):
         assert (io.k, io.w, io.flag, io.bucket_bits) == (oio.k, oio.w, oio.flag, oio.bucket_bits)
         for name, _ in ffi.MapOpt._fields_:
             assert getattr(mo, name) == getattr(omo, name), (preset, name)
-    assert L.mm355_set_opt(b"sr", C.byref(io), C.byref(mo)) == ffi.MM355_EUNSUP
+    before = bytes(mo), bytes(io)
+    for known in (b"sr", b"splice", b"splice:hq", b"map-pb", b"ava-pb", b"map10k", b"short", b"cdna"):
+        assert L.mm355_set_opt(known, C.byref(io), C.byref(mo)) == ffi.MM355_EUNSUP
+    for unknown in (b"map-ontt", b"asm7", b""):
+        assert L.mm355_set_opt(unknown, C.byref(io), C.byref(mo)) == ffi.MM355_EINVAL    # U:options.c::mm_set_opt returns -1
+    assert (bytes(mo), bytes(io)) == before                                               # ... and leaves the options untouched
+
+
+def test_unsupported_presets_raise(ffi, golden_dir):
+    """a preset minimap2 knows but this path does not implement must not be mapped with other parameters"""
+    import mappy_rs
+    mmi = os.path.join(golden_dir, "test.mmi")
+    for preset in ("sr", "splice", "map-pb", "ava-pb", "splice:hq"):
+        with pytest.raises(NotImplementedError, match="not implemented by the MI355X mapping path"):
+            mappy_rs.Aligner(mmi, preset=preset)
+    al = mappy_rs.Aligner(mmi, preset="no-such-preset")      # the reference ignores mm_set_opt's -1 (lib.rs:336): defaults stay
+    assert al._mo.bw == 500 and al._mo.flag & 4 and al.k == 15
+    assert mappy_rs.Aligner(mmi, preset="map-hifi")._mo.max_gap == 10000
+
+
+def test_map_no_op_record(ffi, golden_dir):
+    """lib.rs:675-693"""
+    import mappy_rs
+    al = mappy_rs.Aligner(os.path.join(golden_dir, "test.mmi"))
+    (m,) = al.map_no_op("ACGT")
+    assert (m.query_start, m.query_end, m.strand, m.target_name, m.target_len, m.target_start, m.target_end, m.match_len, m.block_len,
+            m.mapq, m.is_primary, m.cigar, m.NM, m.MD, m.cs) == (0, 1000, 1, "Hello", 101010, 10, 1010, 1000, 1000, 60, True, [], 0, None, "Cigar string")
+    with pytest.raises(NotImplementedError, match="Using `seq2` is not implemented"):
+        al.map_no_op("ACGT", seq2="A")
+
+
+def test_gzip_fasta_and_corrupt_inputs(ffi, golden_dir, tmp_path):
+    """.fa.gz is read through zlib like the reference does; a truncated gzip stream or a corrupt .mmi header gives no index"""
+    import gzip
+    import mappy_rs
+    fa = open(os.path.join(golden_dir, "test.fa"), "rb").read()
+    gz = tmp_path / "test.fa.gz"
+    with gzip.open(gz, "wb") as fh:
+        fh.write(fa)
+    al = mappy_rs.Aligner(str(gz))
+    ref = mappy_rs.Aligner(os.path.join(golden_dir, "test.fa"))
+    assert al.n_seq == 4 and al.seq_names == ref.seq_names and al.seq("Bacillus_subtilis") == BACILLUS
+    nm, nd = C.c_int64(), C.c_int64()
+    ffi.lib().mm355_index_stat(al._idx, C.byref(nm), C.byref(nd), None, None)
+    assert (nm.value, nd.value) == (280, 280)
+    bad = tmp_path / "trunc.fa.gz"
+    bad.write_bytes(gz.read_bytes()[:len(gz.read_bytes()) // 2])
+    with pytest.raises(RuntimeError, match="Did not create or open an index"):
+        mappy_rs.Aligner(str(bad))
+    mmi = bytearray(open(os.path.join(golden_dir, "test.mmi"), "rb").read())
+    for off, val in ((12, 40), (8, 0), (4, 0), (8, 200)):      # b = 40, k = 0, w = 0, k = 200
+        c = bytearray(mmi); c[off:off + 4] = int(val).to_bytes(4, "little")
+        f = tmp_path / ("bad%d_%d.mmi" % (off, val)); f.write_bytes(bytes(c))
+        with pytest.raises(RuntimeError, match="Did not create or open an index"):
+            mappy_rs.Aligner(str(f))
+
+
+def test_no_seq_index_has_no_sequence(ffi, golden_dir, tmp_path):
+    """minimap2 --idx-no-seq (MM_I_NO_SEQ): `seq()` reports nothing (lib.rs:710-714); mapping is refused on the GPU (test_gpu_map)"""
+    import mappy_rs
+    mmi = bytearray(open(os.path.join(golden_dir, "test.mmi"), "rb").read())
+    flag = int.from_bytes(mmi[20:24], "little")
+    assert flag == 0
+    mmi[20:24] = (flag | 2).to_bytes(4, "little")
+    n_S = (4 * 400 + 7) // 8 * 4
+    f = tmp_path / "noseq.mmi"; f.write_bytes(bytes(mmi[:-n_S]))
+    al = mappy_rs.Aligner(str(f))
+    assert al.n_seq == 4 and al.seq("Bacillus_subtilis") is None
 
 
 def _all_minimizers(al, seqs):
