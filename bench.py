@@ -298,8 +298,12 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(n_thr)
 
-    def step(resident):
-        res = [r for part in pool.map(lambda ti: [step_one(si, resident) for si in range(ti, n_str, n_thr)], range(n_thr)) for r in part]
+    def run_steps(resident, steps):
+        """`steps` passes over the batch: every host thread maps its own sub-batches `steps` times, one after the other, without waiting
+        for the other threads between passes (the passes of different threads overlap; the barriers bracket the whole region, not a pass)"""
+        def thread(ti):
+            return [step_one(si, resident) for _ in range(steps) for si in range(ti, n_str, n_thr)]
+        res = [r for part in pool.map(thread, range(n_thr)) for r in part]
         agg_st = {}
         for _a, _h, st in res:
             for k, _t in _ffi.Stats._fields_:
@@ -320,21 +324,15 @@ def main():
 
     def timed(resident, steps):
         barrier()
-        agg = {}
         t0 = time.perf_counter()
-        aligned_tot = 0
-        for _ in range(steps):
-            aligned, n_hits, st = step(resident)
-            aligned_tot += aligned
-            for k, _t in _ffi.Stats._fields_:
-                agg[k] = agg.get(k, 0) + st[k]
+        aligned_tot, n_hits, agg = run_steps(resident, steps)
         barrier()
         dt = time.perf_counter() - t0
         dt, aligned_all, bases_all = aggregate(dist, dt, aligned_tot, n_bases * steps)
         return dt, aligned_all, bases_all, agg
 
-    for _ in range(args.warmup):
-        step(False)
+    if args.warmup:
+        run_steps(False, args.warmup)
     K = args.steps
     dt, aligned_all, bases_all, agg = timed(False, K)           # `value`: H2D + map + D2H
     if args.no_resident:
@@ -353,11 +351,13 @@ def main():
         expand_bytes = 8 * n_am + 16 * n_a
         n_ldp = max(1.0, agg["n_launch_dp"] / K)          # extension launch groups per step (one per sub-batch and round)
         # the extension kernel that takes the most time, timed alone with HIP events on its own stream (group = 2 * size class + exact)
+        # (the long-target classes -- 4096 / 12288 positions of LDS state, HBM state, approx and exact -- are ONE launch, timed as group 8)
         gnames = ["k_ksw_reg<%d, %s>" % (np_, ex) for np_ in (1, 2, 4, 8) for ex in ("false", "true")] + \
-                 ["k_ksw_extd2<512> (lds 4096, %s)" % m for m in ("approx", "exact")] + ["k_ksw_extd2<512> (lds 12288, %s)" % m for m in ("approx", "exact")] + \
-                 ["k_ksw_extd2<512> (hbm state, %s)" % m for m in ("approx", "exact")] + ["-", "-"]
+                 ["k_ksw_extd2<512> (every target > 1024)"] + ["-"] * 7
+        cells_g = np.array(agg["dp_cells_group"], dtype=np.float64); cells_g[8] = cells_g[8:14].sum(); cells_g[9:14] = 0
+        nl_g = np.array(agg["n_launch_group"], dtype=np.float64); nl_g[8] = nl_g[8:14].max(); nl_g[9:14] = 0
         gi = int(np.argmax(agg["ms_dp_group"]))
-        g_ms, g_cells, g_nl = agg["ms_dp_group"][gi] / K, agg["dp_cells_group"][gi] / K, max(1.0, agg["n_launch_group"][gi] / K)
+        g_ms, g_cells, g_nl = agg["ms_dp_group"][gi] / K, cells_g[gi] / K, max(1.0, nl_g[gi] / K)
         n_lfront = float(n_str)                            # one launch of every front kernel per sub-batch
         cand = {   # name: (algorithmic bytes per step, summed kernel ms per step, launches per step, formula)
             gnames[gi]: (g_cells, g_ms, g_nl, "1 B/cell direction matrix written to HBM, %.4g cells per launch (HIP events on the kernel's own stream)" % (g_cells / g_nl)),
@@ -390,7 +390,8 @@ def main():
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
             "resident_mbases_per_s": None if dt_res is None else round(aligned_res / dt_res / 1e6, 3),
             "roofline": roof[dom], "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
-            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(14) if agg["n_launch_group"][i] > 0},
+            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(9) if nl_g[i] > 0},
+            "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(9) if nl_g[i] > 0},
             "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
                                       n_dp_jobs=int(agg["n_dp_jobs"] / K)),
         }

@@ -28,6 +28,7 @@ struct DevBatch {            // one batch of reads resident in HBM
 	const int64_t *roff;       // byte offset of read r in seq; also its slot offset in mz/seed arrays
 	const int32_t *rlen;
 	const int32_t *order;      // reads sorted by length (desc) for the lane-per-read kernels
+	unsigned long long *prof;  // MM355_KPROF=1: [0..31] summed / [32..63] maximal shader cycles per kernel phase (diagnostics), else null
 };
 
 struct DevSeeds {

@@ -68,7 +68,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
                                                     const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, int32_t *offbase,
                                                     uint32_t *cigbase, uint64_t *stbase, int32_t *Hbase, mm355_dpres_t *res,
-                                                    int lds_cap, unsigned long long *cells_ctr, uint32_t *dense, unsigned long long *dense_ctr)
+                                                    int lds_cap, unsigned long long *cells_ctr, uint32_t *dense, unsigned long long *dense_ctr, int cls_base)
 {
 	extern __shared__ uint64_t lds[];
 	// [lds_cap] state words, then [lds_cap] int32 H
@@ -305,7 +305,9 @@ __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jo
 		o.n_cigar = i0;            // start cell, replaced by the CIGAR length / offset in k_ksw_backtrack
 		o.cigar_off = j0;
 		res[jid] = o;
-		if (cells) atomicAdd(cells_ctr, cells);
+		// cells_ctr: one counter per launch group, or (cls_base >= 0: the merged launch of every long-target class) the base of the
+		// per-group counters, indexed by the job's own size class
+		if (cells) atomicAdd(cls_base >= 0? cells_ctr + 2 * (cls_base + (T > 4096) + (T > 12288)) + (approx_max? 0 : 1) : cells_ctr, cells);
 	}
 }
 
@@ -481,13 +483,15 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		grp_off[DP_N_GROUP] = acc;
 		size_t cur[DP_N_GROUP];
 		for (int g = 0; g < DP_N_GROUP; ++g) cur[g] = grp_off[g];
-		for (size_t i = 0; i < n; ++i) h_ids[cur[grp[i]]++] = (int32_t)i;
 		uint32_t a2 = 0;
 		for (int k = 0; k <= LB; ++k) { uint32_t t = lcnt[k]; lcnt[k] = a2; a2 += t; }
 		for (size_t i = 0; i < n; ++i) {
 			int lb = (jobs[i].qlen + jobs[i].tlen) >> 3; if (lb < 0) lb = 0; if (lb >= LB) lb = LB - 1;
 			h_ord[lcnt[LB - 1 - lb]++] = (int32_t)i;
 		}
+		// launch lists in the same order (most anti-diagonals first): a wave is one alignment, so the longest sweeps of a class start at
+		// t = 0 and the short ones fill in behind them instead of the launch ending on a late-started long one
+		for (size_t k = 0; k < n; ++k) { const int32_t i = h_ord[k]; h_ids[cur[grp[i]]++] = i; }
 	}
 	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64) ||
 	    c->dp_work.ensure((off_tot + 16) * 4 + (2 * n + 32) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_dense.ensure((cig_tot + 16) * 4) ||
@@ -530,33 +534,53 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
 		// groups share a few streams (launch order = big problems first): 0 the wide approx classes (targets <= 256), 1 every exact
 		// class <= 1024, 2 approx 512/1024, 3.. the eight-wave kernels (few long alignments each: they overlap one another).  MM355_DP_STREAMS=0: one stream per group.
-		static const bool few_streams = [] { const char *e = getenv("MM355_DP_STREAMS"); return !(e && atoi(e) == 0); }();
-		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
-			if (n_grp[g] == 0) continue;
-			const DpClass &k = classes[g >> 1];
-			const int sidx = !few_streams? g : (g >= 8? 3 + (g - 8) : (g & 1)? 1 : g >= 4? 2 : 0);   // the eight-wave classes are latency chains: one stream each
-			hipStream_t gst;
-			// MM355_DP_GLOBAL_STREAMS=1: the extension streams are shared by all contexts of the device (only the context that holds the turn
-			// uses them), which keeps the number of streams competing for hardware queues small
-			static const bool global_st = [] { const char *e = getenv("MM355_DP_GLOBAL_STREAMS"); return e && atoi(e) != 0; }();
-			static hipStream_t g_st[16][16] = {};
-			static std::mutex g_st_mu;
-			hipStream_t *slot = global_st? &g_st[c->dev & 15][sidx] : &c->dp_st[sidx];
-			if (*slot == 0) {
-				std::lock_guard<std::mutex> lk(g_st_mu);
-				if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
-			}
+		// Streams (created back to back at context creation, so they sit on different hardware queues): 0 approx targets <= 256 (the wide
+		// grids), 1 every exact register class, 2 approx 1024, 3 approx 512, 4 the eight-wave kernel.  The long-target classes (4096 /
+		// 12288 LDS state, HBM state; approx and exact) are ONE launch: a few dozen latency-bound alignments that must not queue behind
+		// one another, nor in front of the register classes on a shared hardware queue (they are not part of the turn).
+		static const bool legacy_groups = [] { const char *e = getenv("MM355_DP_SPLIT_LONG"); return e && atoi(e) != 0; }();
+		const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();
+		mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
+		auto group_stream = [&](int sidx, hipStream_t *out) -> int {
+			hipStream_t *slot = &c->dp_st[sidx];
+			if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
+			*out = *slot;
+			return 0;
+		};
+		auto group_begin = [&](int g, hipStream_t gst) -> int {
 			if (c->dp_ev[g] == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming));
-			gst = *slot;
 			HIPCHK(hipStreamWaitEvent(gst, c->dp_up_ev, 0));
 			if (c->dp_ev0[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev0[g]));
 			if (c->dp_ev1[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev1[g]));
 			HIPCHK(hipEventRecord(c->dp_ev0[g], gst));
+			return 0;
+		};
+		auto group_end = [&](int g, hipStream_t gst, bool in_turn) -> int {
+			HIPCHK(hipEventRecord(c->dp_ev1[g], gst));
+			HIPCHK(hipEventRecord(c->dp_ev[g], gst));
+			if (in_turn) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the eight-wave kernels are joined after the turn (below)
+			return 0;
+		};
+		const size_t n_long = grp_off[DP_N_GROUP] - grp_off[8];
+		if (!legacy && !legacy_groups && n_long > 0) {   // every long-target class in one launch (its list is contiguous: groups 8..13)
+			hipStream_t gst; int rc2;
+			if ((rc2 = group_stream(4, &gst))) return rc2;
+			if ((rc2 = group_begin(8, gst))) return rc2;
+			hipLaunchKernelGGL(k_ksw_extd2<512>, dim3((unsigned)n_long), dim3(512), (size_t)12288 * 12, gst, dc, dj, d_ids + grp_off[8], (int)n_long, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+			                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, 12288, d_gcells, c->dp_dense.as<uint32_t>(), d_dense, 4);
+			if ((rc2 = group_end(8, gst, false))) return rc2;
+		}
+		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
+			if (n_grp[g] == 0) continue;
+			const DpClass &k = classes[g >> 1];
+			if (k.kind == 2 && !legacy && !legacy_groups) continue;   // launched above
+			const int sidx = k.kind != 0? 4 + (g - 8) : (g & 1)? 1 : g >= 6? 2 : g >= 4? 3 : 0;
+			hipStream_t gst; int rc2;
+			if ((rc2 = group_stream(sidx, &gst))) return rc2;
+			if ((rc2 = group_begin(g, gst))) return rc2;
 			unsigned long long *gc = d_gcells + g;
 			const unsigned nj = (unsigned)n_grp[g];
 			const int32_t *gid = d_ids + grp_off[g];
-			const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();
-			mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
 			if (k.kind == 0) {
 				const bool ex = g & 1;
 				if (k.np == 1) launch_reg<1>(ex, nj, gst, dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
@@ -565,20 +589,22 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 				else launch_reg<8>(ex, nj, gst, dc, dj, gid, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, gc);
 			} else if (k.kind == 1)
 				hipLaunchKernelGGL(k_ksw_extd2<64>, dim3(nj), dim3(64), (size_t)k.cap * 12, gst, dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
-				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense);
+				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense, -1);
 			else
 				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3(nj), dim3(512), (size_t)k.cap * 12, gst, dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
-				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense);
-			HIPCHK(hipEventRecord(c->dp_ev1[g], gst));
-			HIPCHK(hipEventRecord(c->dp_ev[g], gst));
-			if (k.kind == 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the eight-wave kernels are joined after the turn (below)
+				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense, -1);
+			if ((rc2 = group_end(g, gst, k.kind == 0))) return rc2;
 		}
 		// the turn ends when the extension kernels are done: the backtrack below is a latency-bound pointer walk and, like the result
 		// copies, overlaps the next context's round
 		// (only the wide register-kernel grids count: the few long alignments of the eight-wave classes are latency chains that
 		// leave the GPU almost empty; they keep running while the next context's round starts)
 		if (take_turns) { const double tl1 = mm355_now_ms(); HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); const double tl2 = mm355_now_ms(); mm355_trace_add(c, "dpk", t_turn0, tl2); mm355_trace_add(c, "dpk_launch", t_turn0, tl1); }
-		for (int g = 0; g < DP_N_GROUP; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
+		for (int g = 0; g < DP_N_GROUP; ++g) if (n_grp[g] && classes[g >> 1].kind != 0 && c->dp_ev[g]) {
+			if (!legacy && !legacy_groups && g != 8 && classes[g >> 1].kind == 2) continue;       // merged into the launch recorded under group 8
+			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
+		}
+		if (!legacy && !legacy_groups && n_long > 0 && n_grp[8] == 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[8], 0));
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
@@ -596,10 +622,12 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	HIPCHK(mm355_wait_stream(c->st));
 	{
 		int64_t tot = 0;
+		const bool merged_long = !legacy && getenv("MM355_DP_SPLIT_LONG") == 0;
 		for (int g = 0; g < DP_N_GROUP; ++g) {
-			if (n_grp[g] == 0) continue;
+			const bool timed_here = merged_long && g >= 8? (g == 8 && grp_off[DP_N_GROUP] > grp_off[8]) : n_grp[g] != 0;   // the merged long-target launch is timed as group 8
 			float ms = 0.f;
-			if (hipEventElapsedTime(&ms, c->dp_ev0[g], c->dp_ev1[g]) == hipSuccess) c->stats.ms_dp_group[g] += ms;
+			if (timed_here && hipEventElapsedTime(&ms, c->dp_ev0[g], c->dp_ev1[g]) == hipSuccess) c->stats.ms_dp_group[g] += ms;
+			if (n_grp[g] == 0) continue;
 			c->stats.dp_cells_group[g] += (int64_t)ctr[2 + g]; ++c->stats.n_launch_group[g];
 			tot += (int64_t)ctr[2 + g];
 		}
@@ -625,7 +653,7 @@ int mm355_run_read_codes(mm355_ctx *c)
 {
 	if (c->hb.n_reads == 0) return 0;
 	if (c->rq.ensure((size_t)c->hb.n_bytes * 2 + 64)) return MM355_ENOMEM;
-	DevBatch b; b.n_reads = (int32_t)c->hb.n_reads; b.seq = c->seq.as<uint8_t>(); b.roff = c->roff.as<int64_t>(); b.rlen = c->rlen.as<int32_t>(); b.order = c->order.as<int32_t>();
+	DevBatch b; b.n_reads = (int32_t)c->hb.n_reads; b.seq = c->seq.as<uint8_t>(); b.roff = c->roff.as<int64_t>(); b.rlen = c->rlen.as<int32_t>(); b.order = c->order.as<int32_t>(); b.prof = 0;
 	hipLaunchKernelGGL(k_read_codes, dim3((unsigned)c->hb.n_reads), dim3(256), 0, c->st, b, c->rq.as<uint8_t>());
 	HIPCHK(hipGetLastError());
 	return 0;

@@ -37,6 +37,9 @@
 // kernels whose waves are serial dependence chains (one read or one chain segment per wave): raise their issue priority inside the
 // SIMD so that they are not starved by the wide, throughput-bound extension grids of other contexts sharing the CU
 #define MM355_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(3)
+// MM355_KPROF diagnostics: shader cycles of a kernel phase, summed over reads and the maximum over reads (lane 0 of a wave)
+#define KPROF_BEGIN(bt) unsigned long long *kp_ = (bt).prof; unsigned long long kp_t_ = kp_? (unsigned long long)clock64() : 0
+#define KPROF(i) do { if (kp_ && (threadIdx.x & 63) == 0) { const unsigned long long t_ = (unsigned long long)clock64(); atomicAdd(&kp_[i], t_ - kp_t_); atomicMax(&kp_[32 + (i)], t_ - kp_t_); kp_t_ = t_; } } while (0)
 __global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
 {
 	MM355_LATENCY_KERNEL();
@@ -277,6 +280,66 @@ __device__ void wave_radix_sort(T *a, uint32_t n, Key key, SortLds *L, T *stage,
 	wave_rs_core<true>(a, n, 56, key, L, stage, stage_cap, ws);
 }
 
+// Cross-lane scans and reductions by DPP register moves (row_shr / row_bcast): ~12 VALU operations, no LDS crossbar round trips
+// (a __shfl is a ds_bpermute, >100 cycles each -- seven of them were the longest part of a chaining step)
+#define DPP_I32(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (rmask), 0xf, false)
+__device__ inline int32_t wave_incl_scan_max(int32_t x)   // inclusive prefix max over lanes 0..lane
+{
+	int32_t y;
+	y = DPP_I32(INT32_MIN, x, 0x111, 0xf); x = x > y? x : y;   // row_shr:1
+	y = DPP_I32(INT32_MIN, x, 0x112, 0xf); x = x > y? x : y;   // row_shr:2
+	y = DPP_I32(INT32_MIN, x, 0x114, 0xf); x = x > y? x : y;   // row_shr:4
+	y = DPP_I32(INT32_MIN, x, 0x118, 0xf); x = x > y? x : y;   // row_shr:8
+	y = DPP_I32(INT32_MIN, x, 0x142, 0xa); x = x > y? x : y;   // row_bcast:15 into rows 1 and 3
+	y = DPP_I32(INT32_MIN, x, 0x143, 0xc); x = x > y? x : y;   // row_bcast:31 into rows 2 and 3
+	return x;
+}
+__device__ inline int32_t wave_incl_scan_add(int32_t x)   // inclusive prefix sum over lanes 0..lane
+{
+	x += DPP_I32(0, x, 0x111, 0xf); x += DPP_I32(0, x, 0x112, 0xf); x += DPP_I32(0, x, 0x114, 0xf); x += DPP_I32(0, x, 0x118, 0xf);
+	x += DPP_I32(0, x, 0x142, 0xa); x += DPP_I32(0, x, 0x143, 0xc);
+	return x;
+}
+__device__ inline int32_t wave_incl_scan_min(int32_t x)   // inclusive prefix minimum over lanes 0..lane
+{
+	int32_t y;
+	y = DPP_I32(INT32_MAX, x, 0x111, 0xf); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x112, 0xf); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x114, 0xf); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x118, 0xf); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x142, 0xa); x = x < y? x : y;
+	y = DPP_I32(INT32_MAX, x, 0x143, 0xc); x = x < y? x : y;
+	return x;
+}
+__device__ inline int32_t wave_excl_prefix_max(int32_t v, int lane)   // exclusive prefix max over lanes, INT32_MIN identity
+{
+	(void)lane;
+	const int32_t x = wave_incl_scan_max(v);
+	return DPP_I32(INT32_MIN, x, 0x138, 0xf);   // wave_shr:1, lane 0 keeps the identity
+}
+__device__ inline int32_t wave_reduce_max(int32_t v) { return __builtin_amdgcn_readlane(wave_incl_scan_max(v), 63); }
+__device__ inline long long wave_reduce_max64(long long v)   // maximum of a 64-bit key over the wave (uniform result)
+{
+	const int ctrl[6] = { 0x111, 0x112, 0x114, 0x118, 0x142, 0x143 }, rm[6] = { 0xf, 0xf, 0xf, 0xf, 0xa, 0xc };
+#pragma unroll
+	for (int k = 0; k < 6; ++k) {
+		int lo = (int)(uint32_t)v, hi = (int)(v >> 32), ylo, yhi;
+		switch (k) {   // the builtin wants immediate control words
+		case 0: ylo = DPP_I32(0, lo, 0x111, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x111, 0xf); break;
+		case 1: ylo = DPP_I32(0, lo, 0x112, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x112, 0xf); break;
+		case 2: ylo = DPP_I32(0, lo, 0x114, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x114, 0xf); break;
+		case 3: ylo = DPP_I32(0, lo, 0x118, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x118, 0xf); break;
+		case 4: ylo = DPP_I32(0, lo, 0x142, 0xa); yhi = DPP_I32(INT32_MIN, hi, 0x142, 0xa); break;
+		default: ylo = DPP_I32(0, lo, 0x143, 0xc); yhi = DPP_I32(INT32_MIN, hi, 0x143, 0xc); break;
+		}
+		(void)ctrl; (void)rm;
+		const long long y = (long long)(((unsigned long long)(uint32_t)yhi << 32) | (uint32_t)ylo);
+		v = v > y? v : y;
+	}
+	const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), rhi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), 63);
+	return (long long)(((unsigned long long)rhi << 32) | rlo);
+}
+
 struct key_hi32 { __host__ __device__ uint64_t operator()(const uint64_t &v) const { return v >> 32; } };
 
 // ------------------------------------------------------------------ a2: mm_seed_mz_flt
@@ -337,36 +400,59 @@ __global__ __launch_bounds__(WAVE) void k_mzflt(DevParams pr, DevBatch bt, DevSe
 
 // ------------------------------------------------------------------ a3: seed lookup (the HBM-gather kernel)
 // Algorithmic bytes per minimizer: 16 (minimizer read) + 16 (one slot, when present).
+// A probe is ONE line fetch: the eight lanes of a group load the eight 16-B slots of the minimizer's 128-B line with one
+// global_load_dwordx4 each -- a single coalesced 128-B request per minimizer -- and a ballot finds the matching slot.  Occupied slots
+// form a prefix of a line (the builders fill the first empty slot and never delete), so: a match anywhere in the line = hit, else an
+// empty slot = absent, else (line full, ~1 line in 12 at load 0.55) the next line.  A wave keeps LK_UNROLL x 8 independent line fetches
+// in flight per iteration; nothing in the loop depends on an earlier fetch.
+#define LK_UNROLL 4
 __global__ __launch_bounds__(256) void k_seed_lookup(DevIndex ix, DevBatch bt, DevSeeds sd)
 {
 	const int r = blockIdx.x;
 	const int n = sd.n_mz[r];
 	const int64_t off = bt.roff[r];
 	const mm128 *mz = sd.mz + off;
+	const int grp = threadIdx.x >> 3, sl = threadIdx.x & 7;          // 32 groups of 8 lanes per block; lane sl owns slot sl of the line
+	const int gsh = (threadIdx.x & 63) & ~7;                          // bit position of this group's 8 lanes in a wave ballot
 	unsigned int hits = 0;
-	for (int j = threadIdx.x; j < n; j += 256) {
-		const uint64_t minier = mz[j].x >> 8;
-		uint64_t line = mm_table_hash(minier) & ix.line_mask;
-		uint32_t cnt = 0; uint64_t val = 0;
-		for (;;) {
-			const mm355_slot *ln = ix.slots + line * MM355_SLOTS_PER_LINE;
-			bool done = false;
-#pragma unroll 1
-			for (int q = 0; q < MM355_SLOTS_PER_LINE; ++q) {
-				const uint4 raw = *(const uint4*)(ln + q);   // one 16-B slot
-				const uint64_t key = (uint64_t)raw.y << 32 | raw.x, v = (uint64_t)raw.w << 32 | raw.z;
-				if (key == UINT64_MAX) { done = true; break; }
-				if ((key >> 1) == minier) {
-					if (key & 1) cnt = 1, val = v;
-					else cnt = (uint32_t)v, val = v >> 32;
-					done = true; break;
-				}
-			}
-			if (done) break;
-			line = (line + 1) & ix.line_mask;
+	for (int j0 = 0; j0 < n; j0 += 32 * LK_UNROLL) {
+		uint64_t minier[LK_UNROLL], line[LK_UNROLL]; uint4 raw[LK_UNROLL]; bool live[LK_UNROLL];
+#pragma unroll
+		for (int u = 0; u < LK_UNROLL; ++u) {
+			const int j = j0 + u * 32 + grp;
+			live[u] = j < n;
+			minier[u] = live[u]? mz[j].x >> 8 : 0;
+			line[u] = mm_table_hash(minier[u]) & ix.line_mask;
 		}
-		sd.sn[off + j] = cnt; sd.sv[off + j] = val;
-		hits += cnt > 0;
+#pragma unroll
+		for (int u = 0; u < LK_UNROLL; ++u)                           // LK_UNROLL line fetches issued back to back
+			raw[u] = live[u]? *(const uint4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl) : make_uint4(~0u, ~0u, 0, 0);
+#pragma unroll
+		for (int u = 0; u < LK_UNROLL; ++u) {
+			const int j = j0 + u * 32 + grp;
+			for (;;) {                                                 // uniform per group; groups of a wave only diverge on a full line
+				const uint64_t key = (uint64_t)raw[u].y << 32 | raw[u].x, v = (uint64_t)raw[u].w << 32 | raw[u].z;
+				const bool match = live[u] && (key >> 1) == minier[u] && key != UINT64_MAX;
+				const bool empty = key == UINT64_MAX;
+				const unsigned int mm = (unsigned int)(__ballot(match) >> gsh) & 0xffu, em = (unsigned int)(__ballot(empty) >> gsh) & 0xffu;
+				if (mm) {
+					if (match) {
+						uint32_t cnt; uint64_t val;
+						if (key & 1) cnt = 1, val = v;
+						else cnt = (uint32_t)v, val = v >> 32;
+						sd.sn[off + j] = cnt; sd.sv[off + j] = val;
+						++hits;
+					}
+					break;
+				}
+				if (em || !live[u]) {
+					if (live[u] && sl == 0) { sd.sn[off + j] = 0; sd.sv[off + j] = 0; }
+					break;
+				}
+				line[u] = (line[u] + 1) & ix.line_mask;                // full line without the key: probe the next one
+				raw[u] = *(const uint4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl);
+			}
+		}
 	}
 	for (int o = 32; o > 0; o >>= 1) hits += __shfl_down(hits, o);
 	if ((threadIdx.x & 63) == 0 && hits) atomicAdd(&sd.counters[0], (unsigned long long)hits);
@@ -391,142 +477,231 @@ __device__ __forceinline__ uint32_t mm355_keep_strand(int64_t flag, bool forward
 	return forward? !(flag & MMF_REV_ONLY) : !(flag & MMF_FOR_ONLY);
 }
 
+// One wave per read; nothing is done lane by lane except the heap of U:seed.c::mm_seed_select on streaks that are LONGER than the
+// number of high-occurrence seeds they may keep (rare):
+//   1. hit list, order preserving, as dense per-hit arrays (occurrence count, query word, index of the minimizer) + a bit mask of the
+//      high-occurrence hits (c > mid_occ) in LDS, one 64-bit word per tile of 64 hits;
+//   2. mm_seed_select walks the STREAKS of high-occurrence hits (maximal runs of set bits, found with scalar bit scans on the LDS mask):
+//      a streak that may keep nothing is filtered, one that may keep all of its hits is kept, by all lanes; only a streak longer than
+//      its quota runs the reference's max-heap selection (lane 0, the streak's dense counts);
+//   3. mm_collect_matches' tail as wave scans over tiles of 64 hits: kept list (ballot compaction), anchor offsets (prefix sum of the
+//      occurrence counts), mini_pos, and rep_len as "every filtered seed that starts a new covered run adds prev_end - start" with the
+//      last end added once (the union length of the filtered seeds' query intervals, accumulated exactly like the sequential loop).
+// The dense arrays alias the outputs (soff <- counts, mini_pos <- query words, hl <- minimizer index): a tile is read completely before
+// its (never more numerous) kept entries are written at or below its own range.
+#define SEL_MASK_TILES 1024          // tiles of 64 hits whose mask is kept in LDS (reads up to ~0.6 Mb); later tiles are recomputed on the fly
 __global__ __launch_bounds__(WAVE) void k_seed_select(DevIndex ix, DevParams pr, DevBatch bt, DevSeeds sd)
 {
 	MM355_LATENCY_KERNEL();
 	__shared__ uint64_t heap[128];
+	__shared__ unsigned long long hmask[SEL_MASK_TILES];
 	const int r = blockIdx.x, lane = threadIdx.x;
 	const int n = sd.n_mz[r], qlen = bt.rlen[r];
 	const int64_t off = bt.roff[r];
 	const mm128 *mz = sd.mz + off;
 	const uint32_t *sn = sd.sn + off;
-	uint8_t *sflt = sd.sflt + off;
-	int32_t *hl = sd.hl + off;
-	uint32_t *soff = sd.soff + off;
-	uint64_t *mini_pos = sd.mini_pos + off;
+	uint8_t *hflt = sd.sflt + off;                 // per HIT ordinal: 1 = filtered
+	int32_t *hl = sd.hl + off;                     // per hit ordinal: index of the minimizer; rewritten as the kept list
+	uint32_t *hc = sd.soff + off;                  // per hit ordinal: occurrence count; rewritten as the anchor offsets of the kept seeds
+	uint64_t *hy = sd.mini_pos + off;              // per hit ordinal: q_span << 32 | (q_pos << 1 | strand); rewritten as mini_pos
 	const int max_occ = pr.mid_occ;
 	int n_m0 = 0, n_high = 0;
-	for (int base = 0; base < n; base += WAVE) {   // hit list, order preserving
-		int j = base + lane;
-		uint32_t c = j < n? sn[j] : 0;
-		bool hit = c > 0;
-		unsigned long long mask = __ballot(hit);
-		if (hit) hl[n_m0 + __popcll(mask & LANE_LT_MASK(lane))] = j;
-		if (j < n) sflt[j] = 0;
+	KPROF_BEGIN(bt);
+	for (int base = 0; base < n; base += WAVE) {   // 1. hit list, order preserving
+		const int j = base + lane;
+		const uint32_t c = j < n? sn[j] : 0;
+		const bool hit = c > 0;
+		const unsigned long long mask = __ballot(hit);
+		if (hit) {
+			const int e = n_m0 + __popcll(mask & LANE_LT_MASK(lane));
+			const mm128 m = mz[j];
+			hl[e] = j; hc[e] = c; hy[e] = (m.x & 0xff) << 32 | (uint32_t)m.y; hflt[e] = 0;
+		}
 		n_m0 += __popcll(mask);
-		n_high += __popcll(__ballot(hit && c > (uint32_t)max_occ));
 	}
 	__syncthreads();
-	if (lane != 0) return;
-	if (pr.occ_dist > 0 && pr.max_max_occ > max_occ) {   // mm_seed_select
+	const int n_tiles = (n_m0 + WAVE - 1) / WAVE;
+	for (int t = 0; t < n_tiles; ++t) {            // high-occurrence mask (dense order)
+		const int i = t * WAVE + lane;
+		const bool high = i < n_m0 && hc[i] > (uint32_t)max_occ;
+		const unsigned long long m = __ballot(high);
+		if (lane == 0 && t < SEL_MASK_TILES) hmask[t] = m;
+		n_high += __popcll(m);
+	}
+	__syncthreads();
+	KPROF(4);
+	if (pr.occ_dist > 0 && pr.max_max_occ > max_occ) {   // 2. mm_seed_select
 		if (n_m0 >= 2 && n_high > 0) {
 			const int dist = pr.occ_dist;
-			for (int i = 0, last0 = -1; i <= n_m0; ++i) {
-				if (i == n_m0 || sn[hl[i]] <= (uint32_t)max_occ) {
-					if (i - last0 > 1) {
-						int32_t ps = last0 < 0? 0 : (int32_t)((uint32_t)mz[hl[last0]].y >> 1);
-						int32_t pe = i == n_m0? qlen : (int32_t)((uint32_t)mz[hl[i]].y >> 1);
-						int32_t j, k, st = last0 + 1, en = i;
-						int32_t max_high_occ = (int32_t)((double)(pe - ps) / dist + .499);
-						if (max_high_occ > 0) {
-							if (max_high_occ > 128) max_high_occ = 128;
-							for (j = st, k = 0; j < en && k < max_high_occ; ++j, ++k)
-								heap[k] = (uint64_t)sn[hl[j]] << 32 | (uint32_t)j;
-							for (uint32_t h = ((uint32_t)k >> 1) - 1; h != (uint32_t)-1; --h) heapdown_u64(h, (uint32_t)k, heap);
-							for (; j < en; ++j) {
-								if ((int32_t)sn[hl[j]] < (int32_t)(heap[0] >> 32)) {
-									heap[0] = (uint64_t)sn[hl[j]] << 32 | (uint32_t)j;
-									heapdown_u64(0, (uint32_t)k, heap);
-								}
+			int pos = 0;                           // scan position (hit ordinal), wave-uniform
+			auto tile_mask = [&](int t) -> unsigned long long {   // wave-uniform calls only
+				if (t < SEL_MASK_TILES) return hmask[t];
+				const int i = t * WAVE + lane;
+				return __ballot(i < n_m0 && hc[i] > (uint32_t)max_occ);
+			};
+			while (pos < n_m0) {
+				// next streak [st, en): first set bit at or after pos, then the first clear bit after it
+				int t = pos >> 6;
+				unsigned long long w = tile_mask(t) & (~0ULL << (pos & 63));
+				while (w == 0 && ++t < n_tiles) w = tile_mask(t);
+				if (w == 0) break;
+				const int st = t * 64 + __builtin_ctzll(w);
+				unsigned long long z = ~tile_mask(t) & (~0ULL << (st & 63));
+				while (z == 0 && ++t < n_tiles) z = ~tile_mask(t);
+				int en = z? t * 64 + __builtin_ctzll(z) : n_m0;
+				if (en > n_m0) en = n_m0;
+				pos = en;
+				const int32_t ps = st == 0? 0 : (int32_t)((uint32_t)hy[st - 1] >> 1);
+				const int32_t pe = en == n_m0? qlen : (int32_t)((uint32_t)hy[en] >> 1);
+				int32_t max_high_occ = (int32_t)((double)(pe - ps) / dist + .499);
+				const int L = en - st;
+				if (max_high_occ > 128) max_high_occ = 128;
+				if (max_high_occ <= 0) {              // nothing may stay: flt = 0 ^ 1
+					for (int i = st + lane; i < en; i += WAVE) hflt[i] = 1;
+				} else if (L <= max_high_occ) {        // the heap would hold the whole streak: flt = 1 ^ 1, then the max_max_occ cut
+					for (int i = st + lane; i < en; i += WAVE) hflt[i] = hc[i] > (uint32_t)pr.max_max_occ? 1 : 0;
+				} else {                               // the reference's selection, literally (max-heap of the max_high_occ smallest)
+					if (lane == 0) {
+						int j, k;
+						for (j = st, k = 0; j < en && k < max_high_occ; ++j, ++k) heap[k] = (uint64_t)hc[j] << 32 | (uint32_t)j;
+						for (uint32_t h = ((uint32_t)k >> 1) - 1; h != (uint32_t)-1; --h) heapdown_u64(h, (uint32_t)k, heap);
+						for (; j < en; ++j) {
+							if ((int32_t)hc[j] < (int32_t)(heap[0] >> 32)) {
+								heap[0] = (uint64_t)hc[j] << 32 | (uint32_t)j;
+								heapdown_u64(0, (uint32_t)k, heap);
 							}
-							for (j = 0; j < k; ++j) sflt[hl[(uint32_t)heap[j]]] = 1;
 						}
-						for (j = st; j < en; ++j) sflt[hl[j]] ^= 1;
-						for (j = st; j < en; ++j)
-							if (sn[hl[j]] > (uint32_t)pr.max_max_occ) sflt[hl[j]] = 1;
+						for (j = st; j < en; ++j) hflt[j] = 1;
+						for (j = 0; j < k; ++j) hflt[(uint32_t)heap[j]] = 0;
+						for (j = st; j < en; ++j) if (hc[j] > (uint32_t)pr.max_max_occ) hflt[j] = 1;
 					}
-					last0 = i;
 				}
+				__syncthreads();
 			}
 		}
 	} else {
-		for (int i = 0; i < n_m0; ++i)
-			if (sn[hl[i]] > (uint32_t)max_occ) sflt[hl[i]] = 1;
+		for (int i = lane; i < n_m0; i += WAVE) if (hc[i] > (uint32_t)max_occ) hflt[i] = 1;
 	}
-	// mm_collect_matches tail: rep_len, n_a, mini_pos, kept list (hl/soff are rewritten in place, kept ordinal <= i)
-	int rep_st = 0, rep_en = 0, rep_len = 0, n_kept = 0;
-	uint32_t n_a = 0; unsigned long long multi = 0;
-	for (int i = 0; i < n_m0; ++i) {
-		const int j = hl[i];
-		const mm128 m = mz[j];
-		const uint32_t q_pos = (uint32_t)m.y, q_span = (uint32_t)(m.x & 0xff);
-		if (sflt[j]) {
-			int en = (int)(q_pos >> 1) + 1, st = en - (int)q_span;
-			if (st > rep_en) {
-				rep_len += rep_en - rep_st;
-				rep_st = st, rep_en = en;
-			} else rep_en = en;
-		} else {
-			const uint32_t c = sn[j];
-			uint32_t c_eff = c;
-			if (pr.flag & (MMF_FOR_ONLY | MMF_REV_ONLY)) {   // U:map.c::skip_seed: hits of the excluded strand produce no anchor
-				const uint64_t v = sd.sv[off + j];
-				c_eff = 0;
-				for (uint32_t kq = 0; kq < c; ++kq) {
-					const uint64_t rk = c == 1? v : ix.pos[v + kq];
-					c_eff += mm355_keep_strand(pr.flag, (rk & 1) == (q_pos & 1));
-				}
-			}
-			hl[n_kept] = j; soff[n_kept] = n_a;
-			mini_pos[n_kept] = (uint64_t)q_span << 32 | q_pos >> 1;
-			n_a += c_eff; ++n_kept;
-			if (c > 1) multi += c;
+	__syncthreads();
+	KPROF(5);
+	// 3. mm_collect_matches tail
+	const bool strand_flt = (pr.flag & (MMF_FOR_ONLY | MMF_REV_ONLY)) != 0;
+	int n_kept = 0;
+	uint32_t n_a = 0;
+	unsigned long long multi = 0;
+	long long rep_acc = 0;                         // sum over run starts of (previous end - start)
+	int32_t last_en = 0; bool any_flt = false;     // end of the last filtered seed so far
+	for (int t = 0; t < n_tiles; ++t) {
+		const int i = t * WAVE + lane;
+		const bool in = i < n_m0;
+		uint32_t c = 0; uint64_t yw = 0; int j = 0; bool flt = false;
+		if (in) { c = hc[i]; yw = hy[i]; j = hl[i]; flt = hflt[i] != 0; }
+		const uint32_t q_pos = (uint32_t)yw, q_span = (uint32_t)(yw >> 32) & 0xff;
+		const int32_t en_i = (int32_t)(q_pos >> 1) + 1, st_i = en_i - (int32_t)q_span;
+		// rep_len: previous filtered seed's end (inside the tile: the nearest lower filtered lane; else the carry)
+		const unsigned long long fm = __ballot(in && flt);
+		if (fm) {
+			const unsigned long long lower = fm & LANE_LT_MASK(lane);
+			const int src = lower? 63 - __builtin_clzll(lower) : lane;
+			int32_t prev_en = __shfl(en_i, src);
+			if (!lower) prev_en = any_flt? last_en : 0;
+			long long contrib = 0;
+			if (in && flt && st_i > prev_en) contrib = (long long)prev_en - st_i;
+			for (int o2 = 32; o2 > 0; o2 >>= 1) contrib += __shfl_xor(contrib, o2);
+			rep_acc += contrib;
+			last_en = __shfl(en_i, 63 - __builtin_clzll(fm)); any_flt = true;
 		}
+		// kept seeds
+		const bool keep = in && !flt;
+		uint32_t c_eff = keep? c : 0;
+		if (keep && strand_flt) {                  // U:map.c::skip_seed: hits of the excluded strand produce no anchor
+			const uint64_t v = sd.sv[off + j];
+			c_eff = 0;
+			for (uint32_t kq = 0; kq < c; ++kq) {
+				const uint64_t rk = c == 1? v : ix.pos[v + kq];
+				c_eff += mm355_keep_strand(pr.flag, (rk & 1) == (q_pos & 1));
+			}
+		}
+		const unsigned long long km = __ballot(keep);
+		const uint32_t incl = (uint32_t)wave_incl_scan_add((int32_t)c_eff);
+		const uint32_t tile_sum = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		unsigned long long mc = keep && c > 1? (unsigned long long)c : 0ULL;
+		for (int o2 = 32; o2 > 0; o2 >>= 1) mc += __shfl_xor(mc, o2);
+		multi += mc;
+		__syncthreads();                           // the whole tile has been read: its kept entries may now overwrite it
+		if (keep) {
+			const int e = n_kept + __popcll(km & LANE_LT_MASK(lane));
+			hl[e] = j; hc[e] = n_a + incl - c_eff; hy[e] = (uint64_t)q_span << 32 | q_pos >> 1;
+		}
+		n_kept += __popcll(km); n_a += tile_sum;
+		__syncthreads();
 	}
-	rep_len += rep_en - rep_st;
-	sd.n_a[r] = (int32_t)n_a; sd.rep_len[r] = rep_len; sd.n_mini[r] = n_kept;
-	if (multi) atomicAdd(&sd.counters[1], multi);
+	if (lane == 0) {
+		sd.n_a[r] = (int32_t)n_a; sd.rep_len[r] = (int32_t)(rep_acc + (any_flt? last_en : 0)); sd.n_mini[r] = n_kept;
+		if (multi) atomicAdd(&sd.counters[1], multi);
+	}
+	KPROF(6);
 }
 
 // ------------------------------------------------------------------ a5: collect_seed_hits (anchor expansion)
+// One lane per anchor, 256-thread block per read.  The kept seeds of the read are staged through LDS in tiles of EX_TILE (prefix of
+// their hit counts, occurrence count, pos[] offset / singleton word, query word, tandem flag), so that finding the seed of anchor t
+// (binary search over the prefix) and reading its record never leave the CU; HBM sees the pos[] gather (8 B per multi-occurrence
+// anchor, consecutive lanes read consecutive entries of a run) and the coalesced 16-B anchor stores.
+#define EX_TILE 1024
 __global__ __launch_bounds__(256) void k_seed_expand(DevIndex ix, DevParams pr, DevBatch bt, DevSeeds sd, DevAnchors an)
 {
+	__shared__ uint32_t s_off[EX_TILE + 1], s_c[EX_TILE];
+	__shared__ uint64_t s_v[EX_TILE], s_y[EX_TILE];      // s_y: q_span << 32 | q_pos word (strand in bit 0) | tandem flag in bit 63
 	const int r = blockIdx.x;
 	const int na = sd.n_a[r], nk = sd.n_mini[r], nmz = sd.n_mz[r], qlen = bt.rlen[r];
+	if (na == 0) return;
 	const int64_t off = bt.roff[r];
 	const mm128 *mz = sd.mz + off;
 	const int32_t *hl = sd.hl + off;
 	const uint32_t *soff = sd.soff + off;
 	mm128 *a = an.a + an.aoff[r];
-	for (int t = threadIdx.x; t < na; t += 256) {
-		int lo = 0, hi = nk;
-		while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (soff[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
-		const int j = hl[lo];
-		const uint32_t kq = (uint32_t)t - soff[lo];
-		const mm128 m = mz[j];
-		const uint32_t c = sd.sn[off + j];
-		const uint64_t v = sd.sv[off + j];
-		const uint32_t q_pos = (uint32_t)m.y, q_span = (uint32_t)(m.x & 0xff);
-		uint64_t rk = c == 1? v : ix.pos[v + kq];
-		if ((pr.flag & (MMF_FOR_ONLY | MMF_REV_ONLY)) && c > 1) {   // kq counts the hits of the admitted strand only (k_seed_select)
-			uint32_t seen = 0;
-			for (uint32_t kk = 0; kk < c; ++kk) {
-				rk = ix.pos[v + kk];
-				if (mm355_keep_strand(pr.flag, (rk & 1) == (q_pos & 1)) && seen++ == kq) break;
+	const bool strand_flt = (pr.flag & (MMF_FOR_ONLY | MMF_REV_ONLY)) != 0;
+	for (int k0 = 0; k0 < nk; k0 += EX_TILE) {
+		const int kn = nk - k0 < EX_TILE? nk - k0 : EX_TILE;
+		__syncthreads();
+		for (int i = threadIdx.x; i < kn; i += 256) {
+			const int j = hl[k0 + i];
+			const mm128 m = mz[j];
+			const bool tandem = (j > 0 && (mz[j-1].x >> 8) == (m.x >> 8)) || (j < nmz - 1 && (mz[j+1].x >> 8) == (m.x >> 8));
+			s_off[i] = soff[k0 + i]; s_c[i] = sd.sn[off + j]; s_v[i] = sd.sv[off + j];
+			s_y[i] = (m.x & 0xff) << 32 | (uint32_t)m.y | (tandem? 1ULL << 63 : 0);
+		}
+		if (threadIdx.x == 0) s_off[kn] = k0 + kn < nk? soff[k0 + kn] : (uint32_t)na;
+		__syncthreads();
+		const int t0 = (int)s_off[0], t1 = (int)s_off[kn];
+		for (int t = t0 + (int)threadIdx.x; t < t1; t += 256) {
+			int lo = 0, hi = kn;
+			while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= (uint32_t)t) lo = mid; else hi = mid; }
+			const uint32_t kq = (uint32_t)t - s_off[lo];
+			const uint32_t c = s_c[lo];
+			const uint64_t v = s_v[lo], yw = s_y[lo];
+			const uint32_t q_pos = (uint32_t)yw, q_span = (uint32_t)(yw >> 32) & 0xff;
+			uint64_t rk = c == 1? v : ix.pos[v + kq];
+			if (strand_flt && c > 1) {   // kq counts the hits of the admitted strand only (k_seed_select)
+				uint32_t seen = 0;
+				for (uint32_t kk = 0; kk < c; ++kk) {
+					rk = ix.pos[v + kk];
+					if (mm355_keep_strand(pr.flag, (rk & 1) == (q_pos & 1)) && seen++ == kq) break;
+				}
 			}
+			const uint32_t rpos = (uint32_t)rk >> 1;
+			mm128 o;
+			if ((rk & 1) == (q_pos & 1)) {   // forward strand
+				o.x = (rk & 0xffffffff00000000ULL) | rpos;
+				o.y = (uint64_t)q_span << 32 | q_pos >> 1;
+			} else {                          // reverse strand
+				o.x = 1ULL << 63 | (rk & 0xffffffff00000000ULL) | rpos;
+				o.y = (uint64_t)q_span << 32 | (uint32_t)(qlen - (int)((q_pos >> 1) + 1 - q_span) - 1);
+			}
+			if (yw >> 63) o.y |= MM355_SEED_TANDEM;
+			a[t] = o;
 		}
-		const uint32_t rpos = (uint32_t)rk >> 1;
-		bool tandem = (j > 0 && (mz[j-1].x >> 8) == (m.x >> 8)) || (j < nmz - 1 && (mz[j+1].x >> 8) == (m.x >> 8));
-		mm128 o;
-		if ((rk & 1) == (q_pos & 1)) {   // forward strand
-			o.x = (rk & 0xffffffff00000000ULL) | rpos;
-			o.y = (uint64_t)q_span << 32 | q_pos >> 1;
-		} else {                          // reverse strand
-			o.x = 1ULL << 63 | (rk & 0xffffffff00000000ULL) | rpos;
-			o.y = (uint64_t)q_span << 32 | (uint32_t)(qlen - (int)((q_pos >> 1) + 1 - q_span) - 1);
-		}
-		if (tandem) o.y |= MM355_SEED_TANDEM;
-		a[t] = o;
 	}
 }
 
@@ -540,10 +715,12 @@ __global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors a
 	const int r = heavy_first[blockIdx.x];
 	const int64_t o = an.aoff[r];
 	const uint32_t n = (uint32_t)(an.aoff[r+1] - o);
+	KPROF_BEGIN(bt);
 	WalkScratch ws; ws.out = an.b + o; ws.fpos = (uint32_t*)an.f + o; ws.rank = (uint32_t*)an.p + o; ws.flab = an.t8 + o;   // all free before chaining
 	ws.tcnt = an.tcnt? an.tcnt + o : 0;
 	wave_radix_sort(an.a + o, n, mm_key_x(), &L, stage, (uint32_t)A_STAGE, &ws);
 	if (threadIdx.x == 0 && n > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
+	KPROF(8);
 }
 
 // ---- heavy reads: the top radix levels of an array with tens/hundreds of thousands of elements are done by a whole
@@ -745,66 +922,6 @@ __global__ void k_make_heavy_tasks(DevAnchors an, const int32_t *heavy_first, in
 #define TW_SIZE 8192
 #define TW_MASK (TW_SIZE - 1)
 
-// Cross-lane scans and reductions by DPP register moves (row_shr / row_bcast): ~12 VALU operations, no LDS crossbar round trips
-// (a __shfl is a ds_bpermute, >100 cycles each -- seven of them were the longest part of a chaining step)
-#define DPP_I32(old, src, ctrl, rmask) __builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), (rmask), 0xf, false)
-__device__ inline int32_t wave_incl_scan_max(int32_t x)   // inclusive prefix max over lanes 0..lane
-{
-	int32_t y;
-	y = DPP_I32(INT32_MIN, x, 0x111, 0xf); x = x > y? x : y;   // row_shr:1
-	y = DPP_I32(INT32_MIN, x, 0x112, 0xf); x = x > y? x : y;   // row_shr:2
-	y = DPP_I32(INT32_MIN, x, 0x114, 0xf); x = x > y? x : y;   // row_shr:4
-	y = DPP_I32(INT32_MIN, x, 0x118, 0xf); x = x > y? x : y;   // row_shr:8
-	y = DPP_I32(INT32_MIN, x, 0x142, 0xa); x = x > y? x : y;   // row_bcast:15 into rows 1 and 3
-	y = DPP_I32(INT32_MIN, x, 0x143, 0xc); x = x > y? x : y;   // row_bcast:31 into rows 2 and 3
-	return x;
-}
-__device__ inline int32_t wave_incl_scan_add(int32_t x)   // inclusive prefix sum over lanes 0..lane
-{
-	x += DPP_I32(0, x, 0x111, 0xf); x += DPP_I32(0, x, 0x112, 0xf); x += DPP_I32(0, x, 0x114, 0xf); x += DPP_I32(0, x, 0x118, 0xf);
-	x += DPP_I32(0, x, 0x142, 0xa); x += DPP_I32(0, x, 0x143, 0xc);
-	return x;
-}
-__device__ inline int32_t wave_incl_scan_min(int32_t x)   // inclusive prefix minimum over lanes 0..lane
-{
-	int32_t y;
-	y = DPP_I32(INT32_MAX, x, 0x111, 0xf); x = x < y? x : y;
-	y = DPP_I32(INT32_MAX, x, 0x112, 0xf); x = x < y? x : y;
-	y = DPP_I32(INT32_MAX, x, 0x114, 0xf); x = x < y? x : y;
-	y = DPP_I32(INT32_MAX, x, 0x118, 0xf); x = x < y? x : y;
-	y = DPP_I32(INT32_MAX, x, 0x142, 0xa); x = x < y? x : y;
-	y = DPP_I32(INT32_MAX, x, 0x143, 0xc); x = x < y? x : y;
-	return x;
-}
-__device__ inline int32_t wave_excl_prefix_max(int32_t v, int lane)   // exclusive prefix max over lanes, INT32_MIN identity
-{
-	(void)lane;
-	const int32_t x = wave_incl_scan_max(v);
-	return DPP_I32(INT32_MIN, x, 0x138, 0xf);   // wave_shr:1, lane 0 keeps the identity
-}
-__device__ inline int32_t wave_reduce_max(int32_t v) { return __builtin_amdgcn_readlane(wave_incl_scan_max(v), 63); }
-__device__ inline long long wave_reduce_max64(long long v)   // maximum of a 64-bit key over the wave (uniform result)
-{
-	const int ctrl[6] = { 0x111, 0x112, 0x114, 0x118, 0x142, 0x143 }, rm[6] = { 0xf, 0xf, 0xf, 0xf, 0xa, 0xc };
-#pragma unroll
-	for (int k = 0; k < 6; ++k) {
-		int lo = (int)(uint32_t)v, hi = (int)(v >> 32), ylo, yhi;
-		switch (k) {   // the builtin wants immediate control words
-		case 0: ylo = DPP_I32(0, lo, 0x111, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x111, 0xf); break;
-		case 1: ylo = DPP_I32(0, lo, 0x112, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x112, 0xf); break;
-		case 2: ylo = DPP_I32(0, lo, 0x114, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x114, 0xf); break;
-		case 3: ylo = DPP_I32(0, lo, 0x118, 0xf); yhi = DPP_I32(INT32_MIN, hi, 0x118, 0xf); break;
-		case 4: ylo = DPP_I32(0, lo, 0x142, 0xa); yhi = DPP_I32(INT32_MIN, hi, 0x142, 0xa); break;
-		default: ylo = DPP_I32(0, lo, 0x143, 0xc); yhi = DPP_I32(INT32_MIN, hi, 0x143, 0xc); break;
-		}
-		(void)ctrl; (void)rm;
-		const long long y = (long long)(((unsigned long long)(uint32_t)yhi << 32) | (uint32_t)ylo);
-		v = v > y? v : y;
-	}
-	const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), rhi = (uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), 63);
-	return (long long)(((unsigned long long)rhi << 32) | rlo);
-}
-
 // Chaining is independent between "segments": maximal runs of the sorted anchor array with the same strand|rid whose
 // consecutive x differ by at most max_dist_x.  For the first anchor of a segment the window start `st` reaches the anchor
 // itself (every earlier anchor is on another strand/rid or farther than max_dist_x), so no score, no t[] mark and no
@@ -822,8 +939,25 @@ __device__ inline void chain_dist(const DevParams &pr, int qlen, int32_t &max_di
 	if (max_dist_y < pr.bw) max_dist_y = pr.bw;
 }
 
+// One 256-thread block per read sweeps the anchors in tiles of 256: a lane flags "segment start" for its anchor (O(1): only the left
+// neighbour is looked at), the block's four ballots form the tile's start mask, and every start finds the next start with bit scans on
+// that mask -- no lane ever walks a segment.  A segment that is still open at the end of a tile is carried to the next tile as a
+// block-uniform (open_i0) and closed by the first start found there (or by the end of the read).
+__device__ __forceinline__ void chain_seg_emit(DevAnchors &an, const mm128 *a, int64_t o, int r, int i0, int len, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
+{
+	if (len == 1) {
+		const int32_t sp = (int32_t)(a[i0].y >> 32 & 0xff);
+		an.f[o + i0] = sp; an.p[o + i0] = -1; an.v[o + i0] = sp;
+	} else {
+		ChainSeg sg; sg.read = r; sg.i0 = i0; sg.len = len; sg.pad = 0;
+		if (len <= small_max) small[atomicAdd(&ctr[0], 1u)] = sg;
+		else big[atomicAdd(&ctr[1], 1u)] = sg;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch bt, DevAnchors an, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
 {
+	__shared__ unsigned long long s_mask[4];
 	const int r = blockIdx.x;
 	const int64_t o = an.aoff[r];
 	const int n = (int)(an.aoff[r+1] - o);
@@ -831,24 +965,38 @@ __global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch b
 	const mm128 *a = an.a + o;
 	int32_t mdx, mdy;
 	chain_dist(pr, bt.rlen[r], mdx, mdy);
-	for (int i = threadIdx.x; i < n; i += 256) {
-		const uint64_t xi = a[i].x;
-		bool start = i == 0;
-		if (!start) { const uint64_t xp = a[i-1].x; start = (xi >> 32 != xp >> 32) || xi > xp + (uint64_t)(int64_t)mdx; }
-		if (!start) continue;
-		int e = i + 1;
-		uint64_t xp = xi;
-		while (e < n) { const uint64_t xe = a[e].x; if ((xe >> 32 != xp >> 32) || xe > xp + (uint64_t)(int64_t)mdx) break; xp = xe; ++e; }
-		const int len = e - i;
-		if (len == 1) {
-			const int32_t sp = (int32_t)(a[i].y >> 32 & 0xff);
-			an.f[o + i] = sp; an.p[o + i] = -1; an.v[o + i] = sp;
-		} else {
-			ChainSeg sg; sg.read = r; sg.i0 = i; sg.len = len; sg.pad = 0;
-			if (len <= small_max) small[atomicAdd(&ctr[0], 1u)] = sg;
-			else big[atomicAdd(&ctr[1], 1u)] = sg;
+	const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+	int open_i0 = -1;                                   // start of the segment that is still open (block-uniform)
+	for (int base = 0; base < n; base += 256) {
+		const int i = base + tid;
+		bool start = false;
+		if (i < n) {
+			start = i == 0;
+			if (!start) { const uint64_t xi = a[i].x, xp = a[i-1].x; start = (xi >> 32 != xp >> 32) || xi > xp + (uint64_t)(int64_t)mdx; }
 		}
+		const unsigned long long m = __ballot(start);
+		if (lane == 0) s_mask[wv] = m;
+		__syncthreads();
+		const unsigned long long m0 = s_mask[0], m1 = s_mask[1], m2 = s_mask[2], m3 = s_mask[3];
+		// first start of the tile closes the open segment (thread 0 does it)
+		int first = -1;
+		if (m0) first = __builtin_ctzll(m0); else if (m1) first = 64 + __builtin_ctzll(m1); else if (m2) first = 128 + __builtin_ctzll(m2); else if (m3) first = 192 + __builtin_ctzll(m3);
+		if (tid == 0 && open_i0 >= 0 && first >= 0) chain_seg_emit(an, a, o, r, open_i0, base + first - open_i0, small, big, ctr, small_max);
+		if (start) {                                      // the next start after this lane inside the tile, if any
+			int nxt = -1;
+			const unsigned long long mk[4] = { m0, m1, m2, m3 };
+			unsigned long long rest = lane == 63? 0ULL : (mk[wv] >> (lane + 1)) << (lane + 1);
+			if (rest) nxt = wv * 64 + __builtin_ctzll(rest);
+			else for (int w2 = wv + 1; w2 < 4; ++w2) if (mk[w2]) { nxt = w2 * 64 + __builtin_ctzll(mk[w2]); break; }
+			if (nxt >= 0) chain_seg_emit(an, a, o, r, i, base + nxt - i, small, big, ctr, small_max);
+		}
+		// the last start of the tile stays open
+		int last = -1;
+		if (m3) last = 192 + 63 - __builtin_clzll(m3); else if (m2) last = 128 + 63 - __builtin_clzll(m2); else if (m1) last = 64 + 63 - __builtin_clzll(m1); else if (m0) last = 63 - __builtin_clzll(m0);
+		if (last >= 0) open_i0 = base + last;
+		__syncthreads();
 	}
+	if (tid == 0 && open_i0 >= 0) chain_seg_emit(an, a, o, r, open_i0, n - open_i0, small, big, ctr, small_max);
 }
 
 #define CHAIN_SMALL 32
@@ -929,6 +1077,7 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 #define CH_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 	const int lane = threadIdx.x;
 	if (blockIdx.x >= n_segs) return;
+	KPROF_BEGIN(bt);
 	const ChainSeg sg = segs[blockIdx.x];
 	const int r = sg.read;
 	const int64_t o = an.aoff[r];
@@ -1061,6 +1210,7 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 		CH_SYNC();
 	}
 #undef CH_SYNC
+	KPROF(12);
 	if (lane == 0 && pairs) atomicAdd(pairs_ctr, pairs);
 }
 
@@ -1085,6 +1235,7 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 	uint64_t *u = an.u + o, *u2 = an.u2 + o;
 	mm128 *wk = an.wk + o;
 	const int min_sc = pr.min_chain_score, min_cnt = pr.min_cnt, max_drop = pr.bw;
+	KPROF_BEGIN(bt);
 	// z[] = (f, i) for f >= min_sc, in anchor order
 	int n_z = 0;
 	for (int base = 0; base < n; base += WAVE) {
@@ -1096,6 +1247,7 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 		n_z += __popcll(mask);
 	}
 	__syncthreads();
+	KPROF(0);
 	if (n_z == 0) return;
 	WalkScratch ws; ws.out = u2; ws.fpos = (uint32_t*)vi; ws.rank = (uint32_t*)(an.v + o); ws.flab = t8; ws.tcnt = 0;   // v[] is dead after the DP fill
 	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws);
@@ -1103,6 +1255,7 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 	__syncthreads();
 	for (int i = lane; i < n; i += WAVE) t8[i] = 0;
 	__syncthreads();
+	KPROF(1);
 	__shared__ int s_nu, s_nv;
 	if (lane == 0) {
 		int n_v = 0, n_u = 0;
@@ -1135,6 +1288,7 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 	}
 	__syncthreads();
 	const int n_u = s_nu, n_v = s_nv;
+	KPROF(2);
 	if (n_u == 0) return;
 	// compact_a: chains written forward; then chains re-ordered by the x of their first anchor
 	// (1) per-chain start offsets into wk[].y (k<<32|i), b[] filled in forward order
@@ -1171,6 +1325,7 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 	__syncthreads();
 	for (int c = lane; c < n_u; c += WAVE) u[c] = u2[c];
 	if (lane == 0) { an.n_u[r] = n_u; an.n_v[r] = n_v; }
+	KPROF(3);
 }
 
 // ------------------------------------------------------------------ launchers

@@ -409,6 +409,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	c->stats.ms_host = ms_host; c->stats.n_ext_rounds = n_rounds;
 	c->stats.ms_total = now_ms() - t_start;
 	if (verbose) mm355_prof_dump(n_reads);
+	if (verbose) mm355_kprof_dump(c);
 	*out = H;
 	return 0;
 }

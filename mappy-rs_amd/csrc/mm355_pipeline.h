@@ -62,6 +62,7 @@ struct mm355_ctx {
 	HBuf h_jobs, h_gather, h_ids;          // pinned staging of the extension round (descriptors, launch orders)
 	HBuf h_arena[8]; int n_arena = 0;
 	hipEvent_t dp_up_ev = 0;      // dense CIGAR arenas of the launches of the current batch (results point into them)
+	DBuf kprof;    // MM355_KPROF phase counters (64 x u64)
 	DBuf rq;       // per-read query codes fwd|rev
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
@@ -95,6 +96,7 @@ struct EvTimer2 {
 	~EvTimer2() { float ms = 0; (void)hipEventRecord(c->ev1, c->st); (void)mm355_wait_stream(c->st); (void)hipEventElapsedTime(&ms, c->ev0, c->ev1); *acc += ms; }
 };
 void mm355_timers_resolve(mm355_ctx *c);
+void mm355_kprof_dump(mm355_ctx *c);
 struct EvTimer {
 	mm355_ctx *c; int slot;
 	EvTimer(mm355_ctx *c_, double *a) : c(c_)

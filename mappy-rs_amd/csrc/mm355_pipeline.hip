@@ -89,10 +89,13 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		// other: +6 ms on a 16 ms round when contexts created their streams concurrently on first use).
 		static std::mutex mk;
 		std::lock_guard<std::mutex> lk(mk);
-		for (int i = 0; i < 4; ++i) {
+		for (int i = 0; i < 5; ++i) {   // 0..3 the register classes, 4 the eight-wave kernel (mm355_dp_run)
 			if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, c->prio_low));
 			else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[i], hipStreamNonBlocking));
 		}
+		// the stream of the block-level sort of anchor-rich reads: same consideration (7 streams per context, 8 hardware queues)
+		if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->aux_st, hipStreamNonBlocking, c->prio_high)); else HIPCHK(hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev2, hipEventDisableTiming));
 	}
 	HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
 	// the index replica of this device (shared by all its contexts; created on first use: H2D from the host image or a peer copy)
@@ -103,9 +106,24 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	c->dix.seq_off = (const uint64_t*)rp.seq_off; c->dix.seq_len = (const uint32_t*)rp.seq_len;
 	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
 	if (c->counters.ensure(256) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
+	if (getenv("MM355_KPROF")) { if (c->kprof.ensure(512)) { delete c; return MM355_ENOMEM; } HIPCHK(hipMemset(c->kprof.p, 0, 512)); }
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	*out = c;
 	return 0;
+}
+
+// MM355_KPROF=1: per-phase shader-cycle counters of the per-read latency kernels (sum over reads / slowest read), printed and reset
+void mm355_kprof_dump(mm355_ctx *c)
+{
+	if (c->kprof.p == 0) return;
+	unsigned long long h[64];
+	if (hipMemcpy(h, c->kprof.p, 512, hipMemcpyDeviceToHost) != hipSuccess) return;
+	(void)hipMemset(c->kprof.p, 0, 512);
+	static const char *nm[32] = { "bt:zlist", "bt:zsort", "bt:walk", "bt:compact", "sel:hits", "sel:streaks", "sel:tail", "-",
+	                              "srt:total", "-", "-", "-", "chb:total", "chs:total", "-", "-", "mzf:total", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-", "-" };
+	fprintf(stderr, "[mm355] kprof (Mcycles: sum over reads / slowest read):");
+	for (int i = 0; i < 32; ++i) if (h[i]) fprintf(stderr, " %s %.1f/%.2f", nm[i], h[i] / 1e6, h[32 + i] / 1e6);
+	fprintf(stderr, "\n");
 }
 
 // ------------------------------------------------------------------ index replicas (one per device)
@@ -181,7 +199,7 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 	DBuf *bufs[] = { &c->sort_tasks, &c->sort_tmp, &c->sort_flag, &c->tie_list, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
-		&c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
+		&c->kprof, &c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
 	for (DBuf *b : bufs) b->release();
 	for (ResidentBatch &r : c->slots) { r.seq.release(); r.roff.release(); r.rlen.release(); r.order.release(); r.ck_read.release(); r.ck_start.release(); r.ck_r0.release(); }
 	c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
@@ -204,6 +222,7 @@ static DevBatch dev_batch(mm355_ctx *c)
 	DevBatch b;
 	b.n_reads = (int32_t)c->hb.n_reads; b.seq = c->seq.as<uint8_t>(); b.roff = c->roff.as<int64_t>();
 	b.rlen = c->rlen.as<int32_t>(); b.order = c->order.as<int32_t>();
+	b.prof = c->kprof.as<unsigned long long>();
 	return b;
 }
 static DevSeeds dev_seeds(mm355_ctx *c)
