@@ -130,7 +130,7 @@ def pmc_traffic(workload, reads_per_sub, kernel):
 WORKLOADS = {
     # name: (genome, preset, read-set seed, read model, default reads/step/GPU, streams, depth, BASELINE config text)
     "human": dict(genome="human", preset="map-ont", seed=4, reads=dict(n50=10000, sigma=0.75, lo=500, hi=100000),
-                  n_reads=49152, streams=6, depth=4, cfg="configs[2]", what="synthetic ONT reads N50~10kb 6% error (read set seed 4)"),
+                  n_reads=49152, streams=6, depth=2, cfg="configs[2]", what="synthetic ONT reads N50~10kb 6% error (read set seed 4)"),
     "human-hifi": dict(genome="human", preset="map-hifi", seed=6, reads=dict(n50=18000, sigma=0.14, lo=5000, hi=60000, sub=0.0005, ins=0.00075, dele=0.00075),
                        n_reads=24576, streams=6, depth=2, cfg="configs[4]", what="synthetic HiFi reads ~N(18kb, 2.5kb) 0.2% error (read set seed 6)"),
     "ecoli": dict(genome="ecoli", preset="map-ont", seed=2, reads=dict(n50=8000, sigma=0.75, lo=500, hi=100000),
@@ -351,11 +351,11 @@ def main():
         expand_bytes = 8 * n_am + 16 * n_a
         n_ldp = max(1.0, agg["n_launch_dp"] / K)          # extension launch groups per step (one per sub-batch and round)
         # the extension kernel that takes the most time, timed alone with HIP events on its own stream (group = 2 * size class + exact)
-        # (the long-target classes -- 4096 / 12288 positions of LDS state, HBM state, approx and exact -- are ONE launch, timed as group 8)
+        # (the long-target classes are two launches, approx and exact alignments together: targets <= 4096 timed as group 8, longer ones as 10)
         gnames = ["k_ksw_reg<%d, %s>" % (np_, ex) for np_ in (1, 2, 4, 8) for ex in ("false", "true")] + \
-                 ["k_ksw_extd2<512> (every target > 1024)"] + ["-"] * 7
-        cells_g = np.array(agg["dp_cells_group"], dtype=np.float64); cells_g[8] = cells_g[8:14].sum(); cells_g[9:14] = 0
-        nl_g = np.array(agg["n_launch_group"], dtype=np.float64); nl_g[8] = nl_g[8:14].max(); nl_g[9:14] = 0
+                 ["k_ksw_extd2<512> (targets 1025..4096)", "-", "k_ksw_extd2<512> (targets > 4096)"] + ["-"] * 5
+        cells_g = np.array(agg["dp_cells_group"], dtype=np.float64); cells_g[8] = cells_g[8:10].sum(); cells_g[10] = cells_g[10:14].sum(); cells_g[9] = 0; cells_g[11:14] = 0
+        nl_g = np.array(agg["n_launch_group"], dtype=np.float64); nl_g[8] = nl_g[8:10].max(); nl_g[10] = nl_g[10:14].max(); nl_g[9] = 0; nl_g[11:14] = 0
         gi = int(np.argmax(agg["ms_dp_group"]))
         g_ms, g_cells, g_nl = agg["ms_dp_group"][gi] / K, cells_g[gi] / K, max(1.0, nl_g[gi] / K)
         n_lfront = float(n_str)                            # one launch of every front kernel per sub-batch
@@ -390,8 +390,8 @@ def main():
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
             "resident_mbases_per_s": None if dt_res is None else round(aligned_res / dt_res / 1e6, 3),
             "roofline": roof[dom], "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
-            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(9) if nl_g[i] > 0},
-            "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(9) if nl_g[i] > 0},
+            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(11) if nl_g[i] > 0},
+            "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(11) if nl_g[i] > 0},
             "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
                                       n_dp_jobs=int(agg["n_dp_jobs"] / K)),
         }

@@ -561,14 +561,31 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			if (in_turn) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the eight-wave kernels are joined after the turn (below)
 			return 0;
 		};
-		const size_t n_long = grp_off[DP_N_GROUP] - grp_off[8];
-		if (!legacy && !legacy_groups && n_long > 0) {   // every long-target class in one launch (its list is contiguous: groups 8..13)
+		// The long-target classes are two launches: targets <= 4096 (49 KB of LDS state: three alignments per CU) on stream 4, and longer ones
+		// (147 KB: one per CU; state in HBM beyond 12288 positions) on stream 5; approx and exact alignments share a launch.
+		// (MM355_DP_LONG_NT=1024: sixteen waves per alignment -- measured slower, 1019 vs 880 ms/step: the wider barrier costs more than
+		// the saved chunk rounds.)
+		static const bool nt512 = [] { const char *e = getenv("MM355_DP_LONG_NT"); return !(e && atoi(e) == 1024); }();
+		struct LongLaunch { int g0, g1, cap, sidx; };
+		static const LongLaunch long_launch[2] = { { 10, 14, 12288, 5 }, { 8, 10, 4096, 4 } };   // the longest sweeps first
+		bool long_used[2] = { false, false };
+		if (!legacy && !legacy_groups) for (int li = 0; li < 2; ++li) {
+			const LongLaunch &ll = long_launch[li];
+			const size_t nl = grp_off[ll.g1] - grp_off[ll.g0];
+			if (nl == 0) continue;
+			long_used[li] = true;
 			hipStream_t gst; int rc2;
-			if ((rc2 = group_stream(4, &gst))) return rc2;
-			if ((rc2 = group_begin(8, gst))) return rc2;
-			hipLaunchKernelGGL(k_ksw_extd2<512>, dim3((unsigned)n_long), dim3(512), (size_t)12288 * 12, gst, dc, dj, d_ids + grp_off[8], (int)n_long, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
-			                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, 12288, d_gcells, c->dp_dense.as<uint32_t>(), d_dense, 4);
-			if ((rc2 = group_end(8, gst, false))) return rc2;
+			if ((rc2 = group_stream(ll.sidx, &gst))) return rc2;
+			if ((rc2 = group_begin(ll.g0, gst))) return rc2;
+			if (nt512)
+				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3((unsigned)nl), dim3(512), (size_t)ll.cap * 12, gst, dc, dj, d_ids + grp_off[ll.g0], (int)nl, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, ll.cap, d_gcells, c->dp_dense.as<uint32_t>(), d_dense, 4);
+			else {
+				(void)hipFuncSetAttribute((const void*)k_ksw_extd2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
+				hipLaunchKernelGGL(k_ksw_extd2<1024>, dim3((unsigned)nl), dim3(1024), (size_t)ll.cap * 12, gst, dc, dj, d_ids + grp_off[ll.g0], (int)nl, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, ll.cap, d_gcells, c->dp_dense.as<uint32_t>(), d_dense, 4);
+			}
+			if ((rc2 = group_end(ll.g0, gst, false))) return rc2;
 		}
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
 			if (n_grp[g] == 0) continue;
@@ -600,11 +617,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// (only the wide register-kernel grids count: the few long alignments of the eight-wave classes are latency chains that
 		// leave the GPU almost empty; they keep running while the next context's round starts)
 		if (take_turns) { const double tl1 = mm355_now_ms(); HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); const double tl2 = mm355_now_ms(); mm355_trace_add(c, "dpk", t_turn0, tl2); mm355_trace_add(c, "dpk_launch", t_turn0, tl1); }
-		for (int g = 0; g < DP_N_GROUP; ++g) if (n_grp[g] && classes[g >> 1].kind != 0 && c->dp_ev[g]) {
-			if (!legacy && !legacy_groups && g != 8 && classes[g >> 1].kind == 2) continue;       // merged into the launch recorded under group 8
-			HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
-		}
-		if (!legacy && !legacy_groups && n_long > 0 && n_grp[8] == 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[8], 0));
+		if (!legacy && !legacy_groups) { for (int li = 0; li < 2; ++li) if (long_used[li]) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[long_launch[li].g0], 0)); }
+		else for (int g = 0; g < DP_N_GROUP; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
@@ -624,7 +638,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		int64_t tot = 0;
 		const bool merged_long = !legacy && getenv("MM355_DP_SPLIT_LONG") == 0;
 		for (int g = 0; g < DP_N_GROUP; ++g) {
-			const bool timed_here = merged_long && g >= 8? (g == 8 && grp_off[DP_N_GROUP] > grp_off[8]) : n_grp[g] != 0;   // the merged long-target launch is timed as group 8
+			// the merged long-target launches are timed as groups 8 (targets <= 4096) and 10 (longer)
+			const bool timed_here = merged_long && g >= 8? ((g == 8 && grp_off[10] > grp_off[8]) || (g == 10 && grp_off[DP_N_GROUP] > grp_off[10])) : n_grp[g] != 0;
 			float ms = 0.f;
 			if (timed_here && hipEventElapsedTime(&ms, c->dp_ev0[g], c->dp_ev1[g]) == hipSuccess) c->stats.ms_dp_group[g] += ms;
 			if (n_grp[g] == 0) continue;

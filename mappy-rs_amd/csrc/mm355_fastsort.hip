@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void k_fs_ties(const int64_t *aoff, const uint
 	bool tie = false;
 	for (int64_t i = b + threadIdx.x; i < e; i += 256) { const bool t = i > b && kx[i] == kx[i - 1]; tf[i] = t? 1 : 0; tie |= t; }
 	const int any = __syncthreads_or(tie);
-	if (threadIdx.x == 0) flag[r] = any? 1 : 0;
+	// (an array of up to 64 elements is insertion-sorted by the reference: stable, i.e. what the plain sort already produced)
+	if (threadIdx.x == 0) flag[r] = any && e - b > 64? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_fs_merge(const int64_t *aoff, const uint64_t *kx, const uint64_t *ky, mm128 *a, const uint8_t *flag, int n_reads, FsKey fk)

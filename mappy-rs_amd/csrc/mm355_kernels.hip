@@ -111,6 +111,33 @@ struct SortLds {
 struct WalkScratch { void *out; uint32_t *fpos; uint32_t *rank; uint8_t *flab; const int32_t *tcnt; };
 __device__ inline bool ws_has_tie(const int32_t *tc, uint32_t b, uint32_t e) { return tc == 0 || tc[e - 1] - tc[b] > 0; }
 
+// The sequential part of a level (see wave_rs_level_walk): one thread follows the cycles over the 1-byte label queues.  The state of a
+// bucket is ONE LDS word cn[c] = cursor << 8 | label of the element at the cursor, so a step of the chase is a single dependent LDS read
+// (cn of the bucket the popped element goes to); the refill of cn (label of the next element), the arrival counter and the rank store are
+// issued beside it.  A foreign element never carries the label of its own region, so cn[g2] may be read before cn[g] is written back.
+// lab[] must be readable one entry past the last foreign element.
+__device__ inline void rs_walk_packed(uint32_t *cn, const uint32_t *fend, uint32_t *arr, uint32_t *abef, const uint8_t *lab, uint32_t *rank)
+{
+	for (uint32_t k = 0; k < 256; ++k) {
+		abef[k] = arr[k];
+		uint32_t ck = cn[k] >> 8;
+		const uint32_t fk = fend[k];
+		while (ck < fk) {
+			uint32_t e = ck++, g = lab[e];
+			uint32_t w = cn[g], r = arr[g];
+			while (g != k) {
+				const uint32_t e2 = w >> 8, g2 = w & 255u;
+				const uint32_t nl = lab[e2 + 1];
+				const uint32_t w2 = cn[g2], r2 = arr[g2];      // g2 != g
+				arr[g] = r + 1; rank[e] = r;
+				cn[g] = (e2 + 1) << 8 | nl;
+				e = e2; g = g2; w = w2; r = r2;
+			}
+			arr[k] = r + 1; rank[e] = r;
+		}
+	}
+}
+
 // One level of the in-place cycle-leader permutation of rs_sort, reproduced WITHOUT moving elements one by one.
 // The permutation only depends on the byte labels: inside the region R_k of bucket k an element is "home" (label k) or
 // "foreign".  Foreign elements leave their region in position order; an element arriving at bucket l before l's own
@@ -153,8 +180,12 @@ __device__ void wave_rs_level_walk(T *a, uint32_t beg, uint32_t end, int s, Key 
 		const uint32_t m = nfor >> 1;
 		for (uint32_t e = lane; e < nfor; e += WAVE) rank[e] = e < m? e : e - m;
 		for (uint32_t k = lane; k < 256; k += WAVE) L->abef[k] = (L->cnt[k] != 0 && L->bb[k] != 0)? m : 0;
-	} else if (lane == 0) {   // the only sequential part: one step per foreign element, on 1-byte labels
-		const bool in_lds = nfor <= lds_cap;
+	} else if (nfor < lds_cap) {   // the only sequential part: one step per foreign element, on 1-byte labels
+		for (uint32_t k = lane; k < 256; k += WAVE) { const uint32_t f0 = L->fst[k]; L->cur[k] = f0 << 8 | lds_lab[f0]; }
+		__syncthreads();
+		if (lane == 0) rs_walk_packed(L->cur, L->fend, L->arr, L->abef, lds_lab, rank);
+	} else if (lane == 0) {
+		const bool in_lds = false;
 		for (uint32_t k = 0; k < 256; ++k) {
 			L->abef[k] = L->arr[k];
 			while (L->cur[k] < L->fend[k]) {
@@ -728,12 +759,13 @@ __global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors a
 // emits the resulting buckets as independent tasks; tasks that are still large go through another block level, the rest
 // is finished by one wave each (k_sort_tasks).  The latency of the slowest read drops from O(n) wave-serial steps per
 // level to O(n/1024) + the 1-byte label walk.
-struct SortTask { int32_t read; uint32_t beg, end; int32_t s; };
 #define MW_NT 1024
 #define MW_LAB_CAP 122880   // 120 KB of labels in LDS
-#define MW_BIG 16384        // buckets larger than this take another block-level pass
+#define MW_BIG 16384        // buckets larger than this take a 1024-thread level
+#define MW_MED 2048         // ... larger than this a 256-thread level; smaller ones are finished by one wave in LDS
 
 int mm355_sort_heavy_threshold(void);
+int mm355_sort_medium_threshold(void);
 template <typename T> struct SortArr;   // per-read base pointers of the array being sorted and of its scratch
 template <> struct SortArr<mm128> {
 	__device__ static mm128 *arr(const DevAnchors &an, int64_t o) { return an.a + o; }
@@ -744,32 +776,37 @@ template <> struct SortArr<uint64_t> {   // z[] of the backtrack: v[] and vi[] a
 	__device__ static WalkScratch ws(const DevAnchors &an, int64_t o) { WalkScratch w; w.out = an.u2 + o; w.fpos = (uint32_t*)an.vi + o; w.rank = (uint32_t*)an.v + o; w.flab = an.t8 + o; w.tcnt = 0; return w; }
 };
 
-struct MwLds {
+template <int NT> struct MwLds {
 	uint32_t cnt[256], bb[256], be[256], cur[256], fend[256], arr[256], abef[256], fst[256];
-	uint32_t wtot[MW_NT / WAVE];
+	uint32_t wtot[NT / WAVE];
 	uint32_t nfor, single;
 };
 
 // block-wide exclusive count of `flag` over the threads of this iteration, in thread order; returns the offset and adds the total to *base
-__device__ inline uint32_t block_ordered_prefix(bool flag, uint32_t &base, MwLds *L)
+template <int NT>
+__device__ inline uint32_t block_ordered_prefix(bool flag, uint32_t &base, MwLds<NT> *L)
 {
 	const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 	const unsigned long long mask = __ballot(flag);
 	if (lane == 0) L->wtot[wv] = (uint32_t)__popcll(mask);
 	__syncthreads();
 	uint32_t before = 0, tot = 0;
-	for (uint32_t w2 = 0; w2 < MW_NT / WAVE; ++w2) { const uint32_t c = L->wtot[w2]; if (w2 < wv) before += c; tot += c; }
+	for (uint32_t w2 = 0; w2 < NT / WAVE; ++w2) { const uint32_t c = L->wtot[w2]; if (w2 < wv) before += c; tot += c; }
 	const uint32_t off = base + before + (uint32_t)__popcll(mask & LANE_LT_MASK(lane));
 	base += tot;
 	__syncthreads();
 	return off;
 }
 
-template <typename T, typename Key>
-__global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const SortTask *tasks, int n_tasks, SortTask *out_big, SortTask *out_small, unsigned int *ctr, uint32_t big_min, int *err)
+// One block per task (a bucket of one read at byte shift s).  NT threads, LABCAP label bytes in LDS: <1024, 120 KB> for buckets of more
+// than MW_BIG elements, <256, MW_BIG + 64 B> for the medium ones (six blocks per CU instead of one).  Children go to the list of their
+// own size class; ctr = { next-level big, next-level medium, wave tasks (running total) }.
+template <typename T, typename Key, int NT, int LABCAP>
+__global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortTask *tasks, int n_tasks, SortTask *out_big, SortTask *out_med, SortTask *out_small,
+                                                      unsigned int *ctr, uint32_t big_min, uint32_t med_min, int *err)
 {
-	__shared__ MwLds L;
-	extern __shared__ uint8_t lds_lab[];   // MW_LAB_CAP labels
+	__shared__ MwLds<NT> L;
+	extern __shared__ uint8_t lds_lab[];   // LABCAP labels
 	if ((int)blockIdx.x >= n_tasks) return;
 	const SortTask tk = tasks[blockIdx.x];
 	const int64_t o = an.aoff[tk.read];
@@ -780,10 +817,10 @@ __global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const So
 	int s = tk.s;
 	// skip the levels where every key has the same byte (identity permutation)
 	for (;;) {
-		for (uint32_t i = tid; i < 256; i += MW_NT) L.cnt[i] = 0;
+		for (uint32_t i = tid; i < 256; i += NT) L.cnt[i] = 0;
 		if (tid == 0) L.single = 0;
 		__syncthreads();
-		for (uint32_t i = beg + tid; i < end; i += MW_NT) atomicAdd(&L.cnt[(uint32_t)(key(a[i]) >> s) & 255u], 1u);
+		for (uint32_t i = beg + tid; i < end; i += NT) atomicAdd(&L.cnt[(uint32_t)(key(a[i]) >> s) & 255u], 1u);
 		__syncthreads();
 		if (tid < 256 && L.cnt[tid] == tot) L.single = 1;
 		__syncthreads();
@@ -798,12 +835,12 @@ __global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const So
 	uint32_t *fpos = ws.fpos + beg, *rank = ws.rank + beg;
 	uint8_t *flab = ws.flab + beg;
 	uint32_t nfor = 0;
-	for (uint32_t base = 0; base < tot; base += MW_NT) {
+	for (uint32_t base = 0; base < tot; base += NT) {
 		const uint32_t rel = base + tid;
 		uint32_t g = 0; bool foreign = false;
 		if (rel < tot) { g = (uint32_t)(key(a[beg + rel]) >> s) & 255u; foreign = !(rel >= L.bb[g] && rel < L.be[g]); }
-		const uint32_t e = block_ordered_prefix(foreign, nfor, &L);
-		if (foreign) { fpos[e] = rel; flab[e] = (uint8_t)g; if (e < MW_LAB_CAP) lds_lab[e] = (uint8_t)g; }
+		const uint32_t e = block_ordered_prefix<NT>(foreign, nfor, &L);
+		if (foreign) { fpos[e] = rel; flab[e] = (uint8_t)g; if (e < (uint32_t)LABCAP) lds_lab[e] = (uint8_t)g; }
 	}
 	__syncthreads();
 	if (tid < 256) {
@@ -823,17 +860,20 @@ __global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const So
 	__syncthreads();
 	if (two) {
 		const uint32_t m = nfor >> 1;   // foreign elements per region
-		for (uint32_t e = tid; e < nfor; e += MW_NT) rank[e] = e < m? e : e - m;
+		for (uint32_t e = tid; e < nfor; e += NT) rank[e] = e < m? e : e - m;
 		if (tid < 256) L.abef[tid] = (L.cnt[tid] != 0 && L.bb[tid] != 0)? m : 0;   // bb != 0: the second of the two regions
-	} else if (tid == 0) {
-		const bool in_lds = nfor <= MW_LAB_CAP;
+	} else if (nfor < (uint32_t)LABCAP) {
+		if (tid < 256) { const uint32_t f0 = L.fst[tid]; L.cur[tid] = f0 << 8 | lds_lab[f0]; }
+		__syncthreads();
+		if (tid == 0) rs_walk_packed(L.cur, L.fend, L.arr, L.abef, lds_lab, rank);
+	} else if (tid == 0) {           // labels do not fit the LDS: walk them in HBM
 		for (uint32_t k = 0; k < 256; ++k) {
 			L.abef[k] = L.arr[k];
 			while (L.cur[k] < L.fend[k]) {
 				uint32_t c = k;
 				do {
 					const uint32_t e = L.cur[c]++;
-					const uint32_t g = in_lds? lds_lab[e] : flab[e];
+					const uint32_t g = flab[e];
 					rank[e] = L.arr[g]++;
 					c = g;
 				} while (c != k);
@@ -842,11 +882,11 @@ __global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const So
 	}
 	__syncthreads();
 	uint32_t nfb = 0;
-	for (uint32_t base = 0; base < tot; base += MW_NT) {
+	for (uint32_t base = 0; base < tot; base += NT) {
 		const uint32_t rel = base + tid;
 		uint32_t g = 0; bool foreign = false; T el;
 		if (rel < tot) { el = a[beg + rel]; g = (uint32_t)(key(el) >> s) & 255u; foreign = !(rel >= L.bb[g] && rel < L.be[g]); }
-		const uint32_t pre = block_ordered_prefix(foreign, nfb, &L);
+		const uint32_t pre = block_ordered_prefix<NT>(foreign, nfb, &L);
 		if (rel < tot) {
 			uint32_t dest;
 			const uint32_t al = L.abef[g], f0 = L.fst[g];
@@ -856,15 +896,16 @@ __global__ __launch_bounds__(MW_NT) void k_sort_level_mw(DevAnchors an, const So
 		}
 	}
 	__syncthreads();
-	for (uint32_t i = tid; i < tot; i += MW_NT) a[beg + i] = out[i];
+	for (uint32_t i = tid; i < tot; i += NT) a[beg + i] = out[i];
 	__syncthreads();
-	if (s > 0 && tid < 256) {   // children: big -> another block level, medium -> one wave each, <= 64 -> insertion sort right here
+	if (s > 0 && tid < 256) {   // children: big / medium -> another block level, small -> one wave each, <= 64 -> insertion sort right here
 		const uint32_t b0 = L.bb[tid], sz = L.cnt[tid];
 		if (sz > 1 && !ws_has_tie(ws.tcnt, beg + b0, beg + b0 + sz)) { /* unique content, restored by the caller */ }
 		else if (sz > MM355_RS_MIN_SIZE) {
 			SortTask c; c.read = tk.read; c.beg = beg + b0; c.end = beg + b0 + sz; c.s = s - 8;
 			if (sz > big_min) out_big[atomicAdd(&ctr[0], 1u)] = c;
-			else out_small[atomicAdd(&ctr[1], 1u)] = c;
+			else if (sz > med_min) out_med[atomicAdd(&ctr[1], 1u)] = c;
+			else out_small[atomicAdd(&ctr[2], 1u)] = c;
 		} else if (sz > 1) mm_rs_insertsort(a + beg + b0, a + beg + b0 + sz, key);
 	}
 	(void)err;
@@ -879,6 +920,10 @@ __global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTa
 	if ((int)blockIdx.x >= n_tasks) return;
 	const SortTask tk = tasks[blockIdx.x];
 	const int64_t o = an.aoff[tk.read];
+	if (tk.end - tk.beg <= MM355_RS_MIN_SIZE) {   // only a whole array can be this short (children are larger): radix_sort = insertion sort
+		wave_rank_sort_small(SortArr<T>::arr(an, o) + tk.beg, tk.end - tk.beg, Key());
+		return;
+	}
 	WalkScratch ws = SortArr<T>::ws(an, o);
 	ws.out = (T*)ws.out + tk.beg; ws.fpos += tk.beg; ws.rank += tk.beg; ws.flab += tk.beg; if (ws.tcnt) ws.tcnt += tk.beg;
 	if (threadIdx.x == 0) { L.stk_n = 0; L.overflow = 0; }
@@ -887,35 +932,29 @@ __global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTa
 	if (threadIdx.x == 0 && L.overflow) *err = 1;
 }
 
-// host side of the heavy path: tasks0 (n0 entries, on the device) = whole arrays of the heavy reads at level 56
+// host side: the initial tasks (whole arrays of the reads to sort, at byte 56) are already in the three size-class lists on the device;
+// a level = one launch per non-empty block-level class, then the counters come back and the lists swap.  ctr = { big, medium, small }.
+#define MW_MED_LAB (MW_BIG + 64)
 template <typename T, typename Key>
-static int sort_heavy_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_small, unsigned int *d_ctr, int n0, int *err, hipStream_t st)
+static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, int *err, hipStream_t st)
 {
-	(void)hipFuncSetAttribute((const void*)k_sort_level_mw<T, Key>, hipFuncAttributeMaxDynamicSharedMemorySize, MW_LAB_CAP);
-	int n_big = n0, cur = 0;
-	unsigned int h[2] = {0, 0};
-	if (hipMemsetAsync(d_ctr, 0, 8, st) != hipSuccess) return -1;
-	for (int level = 0; level < 9 && n_big > 0; ++level) {
-		hipLaunchKernelGGL((k_sort_level_mw<T, Key>), dim3(n_big), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], n_big, d_big[cur ^ 1], d_small + h[1], d_ctr, (uint32_t)mm355_sort_heavy_threshold(), err);
-		// counters: ctr[0] = children for the next block level (restarted per level), ctr[1] = running total of wave tasks
-		unsigned int hh[2];
-		if (hipMemcpyAsync(hh, d_ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+	(void)hipFuncSetAttribute((const void*)k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, MW_LAB_CAP);
+	const uint32_t big_min = (uint32_t)mm355_sort_heavy_threshold(), med_min = (uint32_t)mm355_sort_medium_threshold();
+	int cur = 0;
+	unsigned int h[3] = { 0, 0, (unsigned int)n_small };
+	if (hipMemcpyAsync(d_ctr, h, 12, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+	for (int level = 0; level < 9 && n_big + n_med > 0; ++level) {
+		if (n_big) hipLaunchKernelGGL((k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>), dim3(n_big), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], n_big, d_big[cur ^ 1], d_med[cur ^ 1], d_small, d_ctr, big_min, med_min, err);
+		if (n_med) hipLaunchKernelGGL((k_sort_level_mw<T, Key, 256, MW_MED_LAB>), dim3(n_med), dim3(256), MW_MED_LAB, st, an, d_med[cur], n_med, d_big[cur ^ 1], d_med[cur ^ 1], d_small, d_ctr, big_min, med_min, err);
+		unsigned int hh[3];
+		if (hipMemcpyAsync(hh, d_ctr, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
 		if (mm355_wait_stream(st) != hipSuccess) return -1;
-		n_big = (int)hh[0]; h[1] += hh[1];
-		if (hipMemsetAsync(d_ctr, 0, 8, st) != hipSuccess) return -1;
+		n_big = (int)hh[0]; n_med = (int)hh[1]; h[2] = hh[2];
+		if (hipMemsetAsync(d_ctr, 0, 8, st) != hipSuccess) return -1;   // the small-task total keeps running
 		cur ^= 1;
 	}
-	if (h[1]) hipLaunchKernelGGL((k_sort_tasks<T, Key>), dim3(h[1]), dim3(WAVE), 0, st, an, d_small, (int)h[1], err);
+	if (h[2]) hipLaunchKernelGGL((k_sort_tasks<T, Key>), dim3(h[2]), dim3(WAVE), 0, st, an, d_small, (int)h[2], err);
 	return 0;
-}
-
-__global__ void k_make_heavy_tasks(DevAnchors an, const int32_t *heavy_first, int n_heavy, SortTask *tasks)
-{
-	int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i >= n_heavy) return;
-	const int r = heavy_first[i];
-	SortTask t; t.read = r; t.beg = 0; t.end = (uint32_t)(an.aoff[r + 1] - an.aoff[r]); t.s = 56;
-	tasks[i] = t;
 }
 
 // ------------------------------------------------------------------ a7: mg_lchain_dp (fill)
@@ -1367,26 +1406,35 @@ void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const Dev
 	if (bt.n_reads == 0) return;
 	hipLaunchKernelGGL(k_seed_expand, dim3(bt.n_reads), dim3(256), 0, st, ix, pr, bt, sd, an);
 }
-// heavy_first[0..n_heavy) = reads with more than MW_BIG anchors (block-level path, on st_heavy); the others take one wave each.
-// task_buf: device scratch for 3 task lists of `task_cap` entries each + 2 counters
-// list[0..n_list): the reads to sort, most anchors first; the first n_heavy of them take the block-level path
-int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, int n_heavy, int n_list, void *task_buf, size_t task_cap, hipStream_t st, hipStream_t st_heavy)
+// Literal radix_sort_128x of the listed reads.  h_tasks: the initial whole-read tasks (byte 56) grouped by size class -- n_big entries
+// (> MW_BIG anchors: 1024-thread levels), then n_med (> MW_MED: 256-thread levels), then n_small (one wave each) -- in pinned or otherwise
+// stable host memory until the stream has consumed it.  task_buf: device scratch for 5 task lists of `task_cap` entries + counters.
+int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, void *task_buf, size_t task_cap, hipStream_t st)
 {
-	if (n_list == 0) return 0;
-	if (n_list > n_heavy) hipLaunchKernelGGL(k_sort_anchors, dim3(n_list - n_heavy), dim3(WAVE), 0, st, bt, an, err, heavy_first + n_heavy);
-	if (n_heavy > 0) {
-		SortTask *big[2] = { (SortTask*)task_buf, (SortTask*)task_buf + task_cap };
-		SortTask *small = (SortTask*)task_buf + 2 * task_cap;
-		unsigned int *ctr = (unsigned int*)((SortTask*)task_buf + 3 * task_cap);
-		hipLaunchKernelGGL(k_make_heavy_tasks, dim3((n_heavy + 255) / 256), dim3(256), 0, st_heavy, an, heavy_first, n_heavy, big[0]);
-		if (sort_heavy_run<mm128, mm_key_x>(an, big, small, ctr, n_heavy, err, st_heavy)) return -1;
-	}
-	return 0;
+	(void)bt;
+	const int n = n_big + n_med + n_small;
+	if (n == 0) return 0;
+	SortTask *base = (SortTask*)task_buf;
+	SortTask *big[2] = { base, base + task_cap }, *med[2] = { base + 2 * task_cap, base + 3 * task_cap };
+	SortTask *small = base + 4 * task_cap;
+	unsigned int *ctr = (unsigned int*)(base + 5 * task_cap);
+	const SortTask *ht = (const SortTask*)h_tasks;
+	if (n_big && hipMemcpyAsync(big[0], ht, (size_t)n_big * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+	if (n_med && hipMemcpyAsync(med[0], ht + n_big, (size_t)n_med * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+	if (n_small && hipMemcpyAsync(small, ht + n_big + n_med, (size_t)n_small * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, err, st);
 }
-int mm355_sort_heavy_threshold(void)   // MM355_SORT_HEAVY_MIN: test hook that pushes ordinary reads through the block-level path
+int mm355_sort_task_bytes(void) { return (int)sizeof(SortTask); }
+int mm355_sort_heavy_threshold(void)   // MM355_SORT_HEAVY_MIN: test hook that pushes ordinary reads through the 1024-thread path
 {
 	static int thr = [] { const char *e = getenv("MM355_SORT_HEAVY_MIN"); int v = e? atoi(e) : MW_BIG; return v < 65? 65 : v; }();
 	return thr;
+}
+int mm355_sort_medium_threshold(void)   // buckets above this (and up to the heavy threshold) take a 256-thread level; MM355_SORT_MEDIUM_MIN: test hook
+{
+	static int thr = [] { const char *e = getenv("MM355_SORT_MEDIUM_MIN"); int v = e? atoi(e) : MW_MED; return v < 65? 65 : v; }();
+	const int hv = mm355_sort_heavy_threshold();
+	return thr < hv? thr : hv;
 }
 // seg_small / seg_big: scratch lists of at least tot_a/2 + 1 entries each; ctr: 2 zeroed u32 on the device
 int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr, hipStream_t st)

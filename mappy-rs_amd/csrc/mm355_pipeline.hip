@@ -89,7 +89,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		// other: +6 ms on a 16 ms round when contexts created their streams concurrently on first use).
 		static std::mutex mk;
 		std::lock_guard<std::mutex> lk(mk);
-		for (int i = 0; i < 5; ++i) {   // 0..3 the register classes, 4 the eight-wave kernel (mm355_dp_run)
+		for (int i = 0; i < 6; ++i) {   // 0..3 the register classes, 4 and 5 the eight-wave kernel (mm355_dp_run): with the main and the sort stream, 8 per context
 			if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, c->prio_low));
 			else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[i], hipStreamNonBlocking));
 		}
@@ -202,7 +202,7 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 		&c->kprof, &c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
 	for (DBuf *b : bufs) b->release();
 	for (ResidentBatch &r : c->slots) { r.seq.release(); r.roff.release(); r.rlen.release(); r.order.release(); r.ck_read.release(); r.ck_start.release(); r.ck_r0.release(); }
-	c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
+	c->h_tasks.release(); c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
 	for (int i = 0; i < 16; ++i) { if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]); if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); if (c->dp_ev0[i]) (void)hipEventDestroy(c->dp_ev0[i]); if (c->dp_ev1[i]) (void)hipEventDestroy(c->dp_ev1[i]); }
 	if (c->dp_up_ev) (void)hipEventDestroy(c->dp_up_ev);
 	if (c->aux_st) (void)hipStreamDestroy(c->aux_st);
@@ -361,41 +361,47 @@ static int check_err(mm355_ctx *c)
 int mm355_run_sort(mm355_ctx *c)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
-	if (c->aux_st == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->aux_st, hipStreamNonBlocking, c->prio_high)); else HIPCHK(hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev2, hipEventDisableTiming)); }
 	{
-		// every emitted task covers > 64 elements, so tot_a / 64 bounds each list
-		const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->n_heavy + 1024;
-		if (c->sort_tasks.ensure(task_cap * 3 * 16 + 64)) return MM355_ENOMEM;
+		// every emitted task covers > 64 elements, so tot_a / 64 (+ one whole-array task per read) bounds each list
+		const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->hb.n_reads + 1024;
+		if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 64)) return MM355_ENOMEM;
 		EvTimer t(c, &c->stats.ms_sort);
 		const int n_reads = (int)c->hb.n_reads;
-		const int32_t *list = c->heavy.as<int32_t>();
-		int n_list = n_reads, n_heavy = c->n_heavy;
 		// anchor-rich batches (GRCh38-scale): one segmented radix sort for all reads; only the reads with equal keys -- where the tie
 		// order of the reference's unstable sort is observable -- go through the literal emulation (MM355_FAST_SORT=0/1 forces the choice)
 		static const int force = [] { const char *e = getenv("MM355_FAST_SORT"); return e? atoi(e) : -1; }();
 		const bool fast = force >= 0? force != 0 : (n_reads > 0 && c->hb.tot_a / n_reads >= 2048);
+		std::vector<uint8_t> flag;
 		if (fast) {
-			std::vector<uint8_t> flag;
 			int rc = mm355_fast_sort(c, c->hb.tot_a, n_reads, flag);
 			if (rc) return rc;
-			std::vector<int32_t> tl;
-			for (int i = 0; i < n_reads; ++i) if (flag[i]) tl.push_back(i);
-			std::stable_sort(tl.begin(), tl.end(), [&](int32_t x, int32_t y) { return c->hb.n_a[x] > c->hb.n_a[y]; });
-			n_list = (int)tl.size(); n_heavy = 0;
-			c->stats.n_sort_fast_reads += n_reads; c->stats.n_sort_tie_reads += n_list;
-			for (int i = 0; i < n_list && c->hb.n_a[tl[i]] > mm355_sort_heavy_threshold(); ++i) ++n_heavy;
-			if (n_list) {
-				if (c->tie_list.ensure((size_t)n_list * 4 + 64)) return MM355_ENOMEM;
-				HIPCHK(hipMemcpyAsync(c->tie_list.p, tl.data(), (size_t)n_list * 4, hipMemcpyHostToDevice, c->st));
-				HIPCHK(mm355_wait_stream(c->st));   // tl is pageable
-			}
-			list = c->tie_list.as<int32_t>();
 			a.tcnt = c->v.as<int32_t>();   // the literal recursion skips buckets without equal keys (restored by mm355_fast_sort_fix)
 		}
-		HIPCHK(hipEventRecord(c->aux_ev, c->st)); HIPCHK(hipStreamWaitEvent(c->aux_st, c->aux_ev, 0));   // anchors are complete
-		if (mm355_launch_sort(b, a, c->err.as<int>(), list, n_heavy, n_list, c->sort_tasks.p, task_cap, c->st, c->aux_st)) return MM355_EHIP;
-		HIPCHK(hipEventRecord(c->aux_ev2, c->aux_st)); HIPCHK(hipStreamWaitEvent(c->st, c->aux_ev2, 0));
-		if (fast && n_list > 0) { int rc = mm355_fast_sort_fix(c, n_reads); if (rc) return rc; }
+		// whole-array tasks of the reads that are sorted literally, by size class: 1024-thread levels, 256-thread levels, one wave
+		const int big_min = mm355_sort_heavy_threshold(), med_min = mm355_sort_medium_threshold();
+		int nb = 0, nm = 0, ns = 0;
+		for (int i = 0; i < n_reads; ++i) {
+			const int na = c->hb.n_a[i];
+			if (na < 2 || (fast && !flag[i])) continue;
+			if (na > big_min) ++nb; else if (na > med_min) ++nm; else ++ns;
+		}
+		const int n_list = nb + nm + ns;
+		if (fast) { c->stats.n_sort_fast_reads += n_reads; c->stats.n_sort_tie_reads += n_list; }
+		if (n_list) {
+			if (c->h_tasks.ensure((size_t)n_list * sizeof(SortTask))) return MM355_ENOMEM;   // pinned: consumed by asynchronous copies
+			SortTask *ht = (SortTask*)c->h_tasks.p;
+			int ib = 0, im = nb, is = nb + nm;
+			for (int i = 0; i < n_reads; ++i) {
+				const int na = c->hb.n_a[i];
+				if (na < 2 || (fast && !flag[i])) continue;
+				SortTask tk; tk.read = i; tk.beg = 0; tk.end = (uint32_t)na; tk.s = 56;
+				if (na > big_min) ht[ib++] = tk; else if (na > med_min) ht[im++] = tk; else ht[is++] = tk;
+			}
+			// big tasks first in their list: the longest level walks start at t = 0
+			std::stable_sort(ht, ht + nb, [](const SortTask &x, const SortTask &y) { return x.end > y.end; });
+			if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
+			if (fast) { int rc = mm355_fast_sort_fix(c, n_reads); if (rc) return rc; }
+		}
 	}
 	HIPCHK(hipGetLastError());
 	return check_err(c);
