@@ -74,7 +74,9 @@ struct SortTask { int32_t read; uint32_t beg, end; int32_t s; };   // a bucket [
 int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, void *task_buf, size_t task_cap, hipStream_t st);
 int mm355_sort_heavy_threshold(void);
 int mm355_sort_medium_threshold(void);
-int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr, hipStream_t st);
+int mm355_chain_chunk(void);
+int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr,
+                       const void *chunks, int n_chunks, hipStream_t st);
 void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st);
 #endif
 hipError_t mm355_wait_stream(hipStream_t st);   // like hipStreamSynchronize, but the calling thread sleeps

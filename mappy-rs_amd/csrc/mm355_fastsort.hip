@@ -8,19 +8,26 @@
 #include <cstdio>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include "mm355_pipeline.h"
 
 // The sort key is the anchor's x = strand << 63 | rid << 32 | rpos with its zero bits squeezed out (strand | rid in rb bits | rpos in pb
 // bits: 34 bits for GRCh38 instead of 64), an order-preserving bijection: the radix sort then runs half the digit passes.
-struct FsKey { int pb, rb; };
+// With the index of the read on top of that (read << kb | key: 46 bits for 4096 reads) ONE device-wide radix sort orders every read's
+// anchors at once and leaves the reads where they were: the library's global onesweep sort moves the data in far fewer, fully
+// coalesced passes than a segmented sort that handles each read in its own block.
+struct FsKey { int pb, rb, kb; };
 __device__ __forceinline__ uint64_t fs_pack(uint64_t x, FsKey k) { return (x >> 63) << (k.rb + k.pb) | ((x >> 32) & 0x7fffffffULL) << k.pb | (x & 0xffffffffULL); }
-__device__ __forceinline__ uint64_t fs_unpack(uint64_t p, FsKey k) { return (p >> (k.rb + k.pb)) << 63 | ((p >> k.pb) & ((1ULL << k.rb) - 1)) << 32 | (p & ((1ULL << k.pb) - 1)); }
+__device__ __forceinline__ uint64_t fs_unpack(uint64_t p, FsKey k) { return ((p >> (k.rb + k.pb)) & 1ULL) << 63 | ((p >> k.pb) & ((1ULL << k.rb) - 1)) << 32 | (p & ((1ULL << k.pb) - 1)); }
 
-__global__ __launch_bounds__(256) void k_fs_split(const mm128 *a, uint64_t *kx, uint64_t *ky, int64_t n, FsKey fk)
+__global__ __launch_bounds__(256) void k_fs_split(const int64_t *aoff, const mm128 *a, uint64_t *kx, uint64_t *ky, int n_reads, FsKey fk)
 {
-	const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-	if (i < n) { const mm128 e = a[i]; kx[i] = fs_pack(e.x, fk); ky[i] = e.y; }
+	const int r = blockIdx.x;
+	if (r >= n_reads) return;
+	const int64_t b = aoff[r], e = aoff[r + 1];
+	const uint64_t top = (uint64_t)r << fk.kb;
+	for (int64_t i = b + threadIdx.x; i < e; i += 256) { const mm128 v = a[i]; kx[i] = top | fs_pack(v.x, fk); ky[i] = v.y; }
 }
 
 // one block per read: does the sorted key array of the read contain two equal neighbours?
@@ -67,6 +74,7 @@ static FsKey fs_key(const mm355_ctx *c)   // bit widths of rpos (longest contig)
 	FsKey k; k.pb = 1; k.rb = 1;
 	while (k.pb < 32 && (1ULL << k.pb) < (uint64_t)max_len + 1) ++k.pb;
 	while (k.rb < 31 && (1ULL << k.rb) < (uint64_t)c->mi->n_seq) ++k.rb;
+	k.kb = 1 + k.rb + k.pb;
 	return k;
 }
 
@@ -88,12 +96,22 @@ int mm355_fast_sort(mm355_ctx *c, int64_t tot, int n_reads, std::vector<uint8_t>
 	uint64_t *kx_in = c->b.as<uint64_t>(), *ky_in = kx_in + tot, *kx_out = c->wk.as<uint64_t>(), *ky_out = kx_out + tot;
 	const int64_t *aoff = c->aoff.as<int64_t>();
 	const FsKey fk = fs_key(c);
-	const unsigned int end_bit = (unsigned int)(1 + fk.rb + fk.pb);
-	hipLaunchKernelGGL(k_fs_split, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->st, c->a.as<mm128>(), kx_in, ky_in, tot, fk);
+	int read_bits = 1;
+	while ((1LL << read_bits) < (long long)n_reads) ++read_bits;
+	hipLaunchKernelGGL(k_fs_split, dim3((unsigned)n_reads), dim3(256), 0, c->st, aoff, c->a.as<mm128>(), kx_in, ky_in, n_reads, fk);
 	size_t tb = 0;
-	if (rocprim::segmented_radix_sort_pairs(nullptr, tb, kx_in, kx_out, ky_in, ky_out, (unsigned int)tot, (unsigned int)n_reads, aoff, aoff + 1, 0u, end_bit, c->st) != hipSuccess) return MM355_EHIP;
-	if (c->sort_tmp.ensure(tb + 256) || c->sort_flag.ensure((size_t)n_reads + 64)) return MM355_ENOMEM;
-	if (rocprim::segmented_radix_sort_pairs(c->sort_tmp.p, tb, kx_in, kx_out, ky_in, ky_out, (unsigned int)tot, (unsigned int)n_reads, aoff, aoff + 1, 0u, end_bit, c->st) != hipSuccess) return MM355_EHIP;
+	if (c->sort_flag.ensure((size_t)n_reads + 64)) return MM355_ENOMEM;
+	if (fk.kb + read_bits <= 64) {   // one device-wide sort, the read index is the top of the key
+		const unsigned int end_bit = (unsigned int)(fk.kb + read_bits);
+		if (rocprim::radix_sort_pairs(nullptr, tb, kx_in, kx_out, ky_in, ky_out, (size_t)tot, 0u, end_bit, c->st) != hipSuccess) return MM355_EHIP;
+		if (c->sort_tmp.ensure(tb + 256)) return MM355_ENOMEM;
+		if (rocprim::radix_sort_pairs(c->sort_tmp.p, tb, kx_in, kx_out, ky_in, ky_out, (size_t)tot, 0u, end_bit, c->st) != hipSuccess) return MM355_EHIP;
+	} else {                         // (more than 2^(64 - kb) reads in a batch: per-read segments)
+		const unsigned int end_bit = (unsigned int)fk.kb;
+		if (rocprim::segmented_radix_sort_pairs(nullptr, tb, kx_in, kx_out, ky_in, ky_out, (unsigned int)tot, (unsigned int)n_reads, aoff, aoff + 1, 0u, end_bit, c->st) != hipSuccess) return MM355_EHIP;
+		if (c->sort_tmp.ensure(tb + 256)) return MM355_ENOMEM;
+		if (rocprim::segmented_radix_sort_pairs(c->sort_tmp.p, tb, kx_in, kx_out, ky_in, ky_out, (unsigned int)tot, (unsigned int)n_reads, aoff, aoff + 1, 0u, end_bit, c->st) != hipSuccess) return MM355_EHIP;
+	}
 	int32_t *tf = c->p.as<int32_t>(), *tcnt = c->v.as<int32_t>();   // p[] and v[] (4 B per anchor) are free until chaining; v[] = tcnt stays for the literal sort
 	hipLaunchKernelGGL(k_fs_ties, dim3((unsigned)n_reads), dim3(256), 0, c->st, aoff, kx_out, c->sort_flag.as<uint8_t>(), tf, n_reads);
 	{

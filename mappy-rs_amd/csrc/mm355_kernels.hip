@@ -966,7 +966,6 @@ static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2]
 // itself (every earlier anchor is on another strand/rid or farther than max_dist_x), so no score, no t[] mark and no
 // max_ii of an earlier segment can influence it.  k_chain_segments cuts the reads into segments; 1-anchor segments are
 // finished on the spot, short ones go to one lane each (k_chain_small), long ones to one wave each (k_chain_big).
-struct ChainSeg { int32_t read, i0, len, pad; };
 
 __device__ inline void chain_dist(const DevParams &pr, int qlen, int32_t &max_dist_x, int32_t &max_dist_y)
 {
@@ -982,60 +981,75 @@ __device__ inline void chain_dist(const DevParams &pr, int qlen, int32_t &max_di
 // neighbour is looked at), the block's four ballots form the tile's start mask, and every start finds the next start with bit scans on
 // that mask -- no lane ever walks a segment.  A segment that is still open at the end of a tile is carried to the next tile as a
 // block-uniform (open_i0) and closed by the first start found there (or by the end of the read).
-__device__ __forceinline__ void chain_seg_emit(DevAnchors &an, const mm128 *a, int64_t o, int r, int i0, int len, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
+// Segments are appended to the two lists with ONE atomic per wave and list (ballot + prefix inside the wave): millions of single-address
+// atomics would otherwise be the kernel (one word takes ~88 atomics per microsecond), and the lists stay in anchor order inside a
+// wave's batch, so neighbouring lanes of k_chain_small read neighbouring anchors.
+struct ChainSeg { int32_t read, i0, len, pad; };
+__device__ __forceinline__ void chain_seg_emit(bool have, DevAnchors &an, const mm128 *a, int64_t o, int r, int i0, int len, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
 {
-	if (len == 1) {
+	const int lane = threadIdx.x & 63;
+	if (have && len == 1) {
 		const int32_t sp = (int32_t)(a[i0].y >> 32 & 0xff);
 		an.f[o + i0] = sp; an.p[o + i0] = -1; an.v[o + i0] = sp;
-	} else {
+	}
+	const bool to_small = have && len > 1 && len <= small_max, to_big = have && len > small_max;
+	const unsigned long long ms = __ballot(to_small), mb = __ballot(to_big);
+	unsigned int base_s = 0, base_b = 0;
+	if (ms) { if (lane == (int)__builtin_ctzll(ms)) base_s = atomicAdd(&ctr[0], (unsigned int)__popcll(ms)); base_s = __shfl(base_s, (int)__builtin_ctzll(ms)); }
+	if (mb) { if (lane == (int)__builtin_ctzll(mb)) base_b = atomicAdd(&ctr[1], (unsigned int)__popcll(mb)); base_b = __shfl(base_b, (int)__builtin_ctzll(mb)); }
+	if (to_small || to_big) {
 		ChainSeg sg; sg.read = r; sg.i0 = i0; sg.len = len; sg.pad = 0;
-		if (len <= small_max) small[atomicAdd(&ctr[0], 1u)] = sg;
-		else big[atomicAdd(&ctr[1], 1u)] = sg;
+		if (to_small) small[base_s + __popcll(ms & LANE_LT_MASK(lane))] = sg;
+		else big[base_b + __popcll(mb & LANE_LT_MASK(lane))] = sg;
 	}
 }
 
-__global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch bt, DevAnchors an, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
+// One 256-thread block per CHUNK of SEG_CHUNK anchors of a read (chunk table from the host, which knows the anchor counts); a wave takes
+// the chunk's 64-anchor strips one after the other.  A lane flags "segment start" for its anchor (only the left neighbour is looked at);
+// a start's segment ends at the next start of the strip (bit scan on the ballot), and for the LAST start of a strip the wave looks ahead
+// 64 anchors at a time until it meets the next start -- no lane ever walks a segment, no strip waits for another one.
+#define SEG_CHUNK 4096
+__global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch bt, DevAnchors an, const int2 *chunks, int n_chunks, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
 {
-	__shared__ unsigned long long s_mask[4];
-	const int r = blockIdx.x;
+	if ((int)blockIdx.x >= n_chunks) return;
+	const int2 ck = chunks[blockIdx.x];
+	const int r = ck.x, c0 = ck.y;
 	const int64_t o = an.aoff[r];
 	const int n = (int)(an.aoff[r+1] - o);
-	if (n == 0) return;
 	const mm128 *a = an.a + o;
 	int32_t mdx, mdy;
 	chain_dist(pr, bt.rlen[r], mdx, mdy);
-	const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-	int open_i0 = -1;                                   // start of the segment that is still open (block-uniform)
-	for (int base = 0; base < n; base += 256) {
-		const int i = base + tid;
-		bool start = false;
-		if (i < n) {
-			start = i == 0;
-			if (!start) { const uint64_t xi = a[i].x, xp = a[i-1].x; start = (xi >> 32 != xp >> 32) || xi > xp + (uint64_t)(int64_t)mdx; }
-		}
+	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	const int c1 = c0 + SEG_CHUNK < n? c0 + SEG_CHUNK : n;
+	for (int base = c0 + wv * 64; base < c1; base += 256) {
+		const int i = base + lane;
+		uint64_t xi = 0;
+		if (i < n) xi = a[i].x;
+		uint64_t xp = __shfl_up(xi, 1);
+		if (lane == 0 && base > 0) xp = a[base - 1].x;
+		const bool start = i < n && (i == 0 || (xi >> 32 != xp >> 32) || xi > xp + (uint64_t)(int64_t)mdx);
 		const unsigned long long m = __ballot(start);
-		if (lane == 0) s_mask[wv] = m;
-		__syncthreads();
-		const unsigned long long m0 = s_mask[0], m1 = s_mask[1], m2 = s_mask[2], m3 = s_mask[3];
-		// first start of the tile closes the open segment (thread 0 does it)
-		int first = -1;
-		if (m0) first = __builtin_ctzll(m0); else if (m1) first = 64 + __builtin_ctzll(m1); else if (m2) first = 128 + __builtin_ctzll(m2); else if (m3) first = 192 + __builtin_ctzll(m3);
-		if (tid == 0 && open_i0 >= 0 && first >= 0) chain_seg_emit(an, a, o, r, open_i0, base + first - open_i0, small, big, ctr, small_max);
-		if (start) {                                      // the next start after this lane inside the tile, if any
-			int nxt = -1;
-			const unsigned long long mk[4] = { m0, m1, m2, m3 };
-			unsigned long long rest = lane == 63? 0ULL : (mk[wv] >> (lane + 1)) << (lane + 1);
-			if (rest) nxt = wv * 64 + __builtin_ctzll(rest);
-			else for (int w2 = wv + 1; w2 < 4; ++w2) if (mk[w2]) { nxt = w2 * 64 + __builtin_ctzll(mk[w2]); break; }
-			if (nxt >= 0) chain_seg_emit(an, a, o, r, i, base + nxt - i, small, big, ctr, small_max);
+		if (m == 0) continue;                                  // (wave-uniform)
+		int end = -1;
+		if (start) { const unsigned long long rest = lane == 63? 0ULL : (m >> (lane + 1)) << (lane + 1); if (rest) end = base + __builtin_ctzll(rest); }
+		// the last start of the strip: look ahead for the next start
+		const int last = 63 - __builtin_clzll(m);
+		int fend = n;
+		uint64_t xl = __shfl(xi, 63);                          // x of the anchor just before the look-ahead position
+		for (int pos = base + 64; pos < n; pos += 64) {
+			const int j = pos + lane;
+			uint64_t xj = 0;
+			if (j < n) xj = a[j].x;
+			uint64_t xq = __shfl_up(xj, 1);
+			if (lane == 0) xq = xl;
+			const bool st2 = j < n && ((xj >> 32 != xq >> 32) || xj > xq + (uint64_t)(int64_t)mdx);
+			const unsigned long long m2 = __ballot(st2);
+			if (m2) { fend = pos + __builtin_ctzll(m2); break; }
+			xl = __shfl(xj, 63);
 		}
-		// the last start of the tile stays open
-		int last = -1;
-		if (m3) last = 192 + 63 - __builtin_clzll(m3); else if (m2) last = 128 + 63 - __builtin_clzll(m2); else if (m1) last = 64 + 63 - __builtin_clzll(m1); else if (m0) last = 63 - __builtin_clzll(m0);
-		if (last >= 0) open_i0 = base + last;
-		__syncthreads();
+		if (lane == last) end = fend;
+		chain_seg_emit(start, an, a, o, r, i, end - i, small, big, ctr, small_max);
 	}
-	if (tid == 0 && open_i0 >= 0) chain_seg_emit(an, a, o, r, open_i0, n - open_i0, small, big, ctr, small_max);
 }
 
 #define CHAIN_SMALL 32
@@ -1254,7 +1268,7 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 }
 
 // ------------------------------------------------------------------ a8: mg_chain_backtrack + compact_a
-#define Z_STAGE 4096
+#define Z_STAGE 2048      // 16 KB: with SortLds five blocks per CU (4096 entries: three)
 __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, DevAnchors an, int *err, const int32_t *heavy_first)
 {
 	MM355_LATENCY_KERNEL();
@@ -1292,41 +1306,77 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws);
 	if (lane == 0 && n_z > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
 	__syncthreads();
-	for (int i = lane; i < n; i += WAVE) t8[i] = 0;
+	// The walk below is a pointer chase (one lane): every step used to be two dependent HBM/L2 round trips (p[i], then f and the mark of
+	// the node it points to).  All three now sit in ONE 8-byte word per anchor -- pf[i] = { (p + 1) | mark << 30, f } in the u2[] region,
+	// free between the two sorts -- so a step is one load; the nodes a probe visits are remembered in LDS (the sort stage, idle here), so
+	// the reset and collect passes of U:lchain.c::mg_chain_bk_end / mg_chain_backtrack store without chasing again; and the "already used"
+	// test of the n_z candidates is prefetched 64 at a time by the whole wave (a mark is final once it is 1, only zeros are re-read).
+	int2 *pf = (int2*)u2;
+	for (int i = lane; i < n; i += WAVE) pf[i] = make_int2(p[i] + 1, f[i]);
 	__syncthreads();
 	KPROF(1);
 	__shared__ int s_nu, s_nv;
-	if (lane == 0) {
-		int n_v = 0, n_u = 0;
-		for (int k = n_z - 1; k >= 0; --k) {
-			const int zi = (int)(uint32_t)z[k];
-			const int32_t zx = (int32_t)(z[k] >> 32);
-			if (t8[zi] != 0) continue;
-			// mg_chain_bk_end
-			int i = zi, end_i = -1, max_i = i;
-			int32_t max_s = 0;
-			do {
-				int32_t s;
-				t8[i] = 2;
-				end_i = i = p[i];
-				s = i < 0? zx : zx - f[i];
-				if (s > max_s) max_s = s, max_i = i;
-				else if (max_s - s > max_drop) break;
-			} while (i >= 0 && t8[i] == 0);
-			for (i = zi; i >= 0 && i != end_i; i = p[i]) t8[i] = 0;
-			end_i = max_i;
-			// collect
-			const int n_v0 = n_v;
-			for (i = zi; i != end_i; i = p[i]) vi[n_v++] = i, t8[i] = 1;
-			const int32_t sc = i < 0? zx : zx - f[i];
-			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt)
-				u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)(n_v - n_v0);
-			else n_v = n_v0;
+	uint32_t *visited = (uint32_t*)zstage;                    // 2 * Z_STAGE entries
+	const int VCAP = 2 * Z_STAGE;
+	int n_v = 0, n_u = 0;
+#define PF_P(w) ((int)((uint32_t)(w).x & 0x3fffffffu) - 1)
+#define PF_MARK(w) ((uint32_t)(w).x >> 30)
+	for (int kb = n_z - 1; kb >= 0; kb -= WAVE) {
+		const int kk = kb - lane;
+		uint64_t zk = 0; bool cand = false;
+		if (kk >= 0) { zk = z[kk]; cand = PF_MARK(pf[(uint32_t)zk]) == 0; }
+		unsigned long long todo = __ballot(cand);
+		if (todo == 0) continue;                                  // wave-uniform
+		const uint32_t zlo = (uint32_t)zk, zhi = (uint32_t)(zk >> 32);
+		if (lane == 0) {
+			while (todo) {
+				const int l = __builtin_ctzll(todo); todo &= todo - 1;
+				const int zi = (int)(uint32_t)__builtin_amdgcn_readlane((int)zlo, l);
+				const int32_t zx = (int32_t)__builtin_amdgcn_readlane((int)zhi, l);
+				int2 w = pf[zi];
+				if (PF_MARK(w) != 0) continue;
+				// mg_chain_bk_end
+				int i = zi, end_i, max_i = zi, nvis = 0, q = 0;
+				int32_t max_s = 0;
+				bool over = false;
+				for (;;) {
+					pf[i].x = w.x | (int)(2u << 30);                      // t[i] = 2
+					if (nvis < VCAP) visited[nvis] = (uint32_t)i; else over = true;
+					++nvis;
+					end_i = i = PF_P(w);
+					int32_t sv = zx;
+					if (i >= 0) { w = pf[i]; sv = zx - w.y; }
+					if (sv > max_s) { max_s = sv; max_i = i; q = nvis; }
+					else if (max_s - sv > max_drop) break;
+					if (i < 0 || PF_MARK(w) != 0) break;
+				}
+				const int n_v0 = n_v;
+				if (!over) {   // marks: the first q visited nodes join the chain (1), the others are released (0)
+					for (int t = 0; t < nvis; ++t) {
+						const uint32_t vn = visited[t];
+						const uint32_t keep = t < q? 1u : 0u;
+						pf[vn].x = (int)(((uint32_t)pf[vn].x & 0x3fffffffu) | keep << 30);
+						if (keep) vi[n_v++] = (int)vn;
+					}
+				} else {       // a probe longer than the LDS list: the reference's two passes, chasing again
+					for (i = zi; i >= 0 && i != end_i; i = PF_P(pf[i])) pf[i].x = (int)((uint32_t)pf[i].x & 0x3fffffffu);
+					for (i = zi; i != max_i; i = PF_P(pf[i])) { vi[n_v++] = i; pf[i].x = (int)(((uint32_t)pf[i].x & 0x3fffffffu) | 1u << 30); }
+				}
+				const int32_t sc = q > 0? max_s : 0;
+				if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt)
+					u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)(n_v - n_v0);
+				else n_v = n_v0;
+			}
+			s_nu = n_u; s_nv = n_v;
 		}
-		s_nu = n_u; s_nv = n_v;
+		__syncthreads();
+		n_u = s_nu; n_v = s_nv;
 	}
+#undef PF_P
+#undef PF_MARK
+	if (lane == 0) { s_nu = n_u; s_nv = n_v; }
 	__syncthreads();
-	const int n_u = s_nu, n_v = s_nv;
+	n_u = s_nu; n_v = s_nv;
 	KPROF(2);
 	if (n_u == 0) return;
 	// compact_a: chains written forward; then chains re-ordered by the x of their first anchor
@@ -1436,12 +1486,15 @@ int mm355_sort_medium_threshold(void)   // buckets above this (and up to the hea
 	const int hv = mm355_sort_heavy_threshold();
 	return thr < hv? thr : hv;
 }
-// seg_small / seg_big: scratch lists of at least tot_a/2 + 1 entries each; ctr: 2 zeroed u32 on the device
-int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr, hipStream_t st)
+// seg_small / seg_big: scratch lists of at least tot_a/2 + 1 entries each; ctr: 2 zeroed u32 on the device; chunks: (read, first anchor)
+// of every mm355_chain_chunk()-anchor piece of every read
+int mm355_chain_chunk(void) { return SEG_CHUNK; }
+int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr,
+                       const void *chunks, int n_chunks, hipStream_t st)
 {
-	if (bt.n_reads == 0) return 0;
+	if (bt.n_reads == 0 || n_chunks == 0) return 0;
 	if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return -1;
-	hipLaunchKernelGGL(k_chain_segments, dim3(bt.n_reads), dim3(256), 0, st, pr, bt, an, (ChainSeg*)seg_small, (ChainSeg*)seg_big, ctr, CHAIN_SMALL);
+	hipLaunchKernelGGL(k_chain_segments, dim3(n_chunks), dim3(256), 0, st, pr, bt, an, (const int2*)chunks, n_chunks, (ChainSeg*)seg_small, (ChainSeg*)seg_big, ctr, CHAIN_SMALL);
 	unsigned int h[2] = {0, 0};
 	if (hipMemcpyAsync(h, ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
 	if (mm355_wait_stream(st) != hipSuccess) return -1;

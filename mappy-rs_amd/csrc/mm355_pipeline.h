@@ -60,6 +60,7 @@ struct mm355_ctx {
 	DBuf dp_jobs, dp_res, dp_q, dp_t, dp_bt, dp_cig, dp_work, dp_H, dp_dense, dp_gather, pack;
 	HBuf h_res, h_cig, h_pu, h_pa, h_pm, h_seq;
 	HBuf h_tasks;                          // whole-array tasks of the literal anchor sort (pinned)
+	HBuf h_chunks; DBuf d_chunks;          // chunk table of k_chain_segments
 	HBuf h_jobs, h_gather, h_ids;          // pinned staging of the extension round (descriptors, launch orders)
 	HBuf h_arena[8]; int n_arena = 0;
 	hipEvent_t dp_up_ev = 0;      // dense CIGAR arenas of the launches of the current batch (results point into them)

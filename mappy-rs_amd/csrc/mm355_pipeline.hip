@@ -199,10 +199,10 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 	DBuf *bufs[] = { &c->sort_tasks, &c->sort_tmp, &c->sort_flag, &c->tie_list, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
-		&c->kprof, &c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
+		&c->kprof, &c->d_chunks, &c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack };
 	for (DBuf *b : bufs) b->release();
 	for (ResidentBatch &r : c->slots) { r.seq.release(); r.roff.release(); r.rlen.release(); r.order.release(); r.ck_read.release(); r.ck_start.release(); r.ck_r0.release(); }
-	c->h_tasks.release(); c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
+	c->h_tasks.release(); c->h_chunks.release(); c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
 	for (int i = 0; i < 16; ++i) { if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]); if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); if (c->dp_ev0[i]) (void)hipEventDestroy(c->dp_ev0[i]); if (c->dp_ev1[i]) (void)hipEventDestroy(c->dp_ev1[i]); }
 	if (c->dp_up_ev) (void)hipEventDestroy(c->dp_up_ev);
 	if (c->aux_st) (void)hipStreamDestroy(c->aux_st);
@@ -410,8 +410,18 @@ int mm355_run_sort(mm355_ctx *c)
 int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
+	// chunk table of k_chain_segments: (read, first anchor) of every piece of mm355_chain_chunk() anchors
+	const int CH = mm355_chain_chunk();
+	size_t n_chunks = 0;
+	for (int64_t i = 0; i < c->hb.n_reads; ++i) n_chunks += ((size_t)c->hb.n_a[i] + CH - 1) / CH;
+	if (c->h_chunks.ensure(n_chunks * 8 + 8) || c->d_chunks.ensure(n_chunks * 8 + 8)) return MM355_ENOMEM;
+	{
+		int32_t *hc = (int32_t*)c->h_chunks.p; size_t k = 0;
+		for (int64_t i = 0; i < c->hb.n_reads; ++i) for (int32_t c0 = 0; c0 < c->hb.n_a[i]; c0 += CH) { hc[2 * k] = (int32_t)i; hc[2 * k + 1] = c0; ++k; }
+		if (n_chunks) HIPCHK(hipMemcpyAsync(c->d_chunks.p, hc, n_chunks * 8, hipMemcpyHostToDevice, c->st));
+	}
 	// segment lists live in scratch that is free at this point: z (8 B/anchor) and wk (16 B/anchor) hold >= tot_a/2 16-byte entries each
-	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + 3, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->st)) return MM355_EHIP; }
+	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + 3, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->d_chunks.p, (int)n_chunks, c->st)) return MM355_EHIP; }
 	HIPCHK(hipGetLastError());
 	unsigned long long pairs = 0;
 	HIPCHK(hipMemcpyAsync(&pairs, c->counters.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, c->st));
