@@ -312,6 +312,7 @@ __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jo
 }
 
 #include "mm355_dpreg.h"
+#include "mm355_dprow.h"
 
 // U:ksw2.h::ksw_backtrack (is_rot = 1).  The walk is a chain of dependent 1-byte loads (one per CIGAR column), i.e. pure
 // latency: with one lane per alignment a wave keeps 64 independent chains in flight instead of one.  off[]/off_end[] of
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 		n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
 		const int n_col = n_col_ * 16;
 		const uint8_t *p = pbase + jb.p_off;
+		const int row_stride = (tlen + 15) / 16 * 16 + 16;
 		int i = i0, j = j0, state = 0;
 		while (i >= 0 && j >= 0) {
 			int force_state = -1, rr = i + j;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 			uint32_t tmp;
 			if (i < st) force_state = 2;
 			if (i > en) force_state = 1;
-			tmp = force_state < 0? p[(size_t)rr * n_col + i - st] : 0;
+			tmp = force_state < 0? (jb.pad? p[(size_t)j * row_stride + i] : p[(size_t)rr * n_col + i - st]) : 0;   // pad = 1: k_ksw_row's row-major matrix
 			if (state == 0) state = tmp & 7;
 			else if (!(tmp >> (state + 2) & 1)) state = 0;
 			if (state == 0) state = tmp & 7;
@@ -423,7 +425,9 @@ struct DpClass { int cap, kind, np; };   // kind 0: k_ksw_reg, 1: k_ksw_extd2<64
 static const DpClass DP_CLASSES[] = { {128, 0, 1}, {256, 0, 2}, {512, 0, 4}, {1024, 0, 8}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 static const DpClass DP_CLASSES_LEGACY[] = { {256, 1, 0}, {512, 1, 0}, {1024, 1, 0}, {1024, 1, 0}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 #define DP_N_CLASS 7
-#define DP_N_GROUP (2 * DP_N_CLASS)      // group = class * 2 + exact
+#define DP_N_GROUP 16                    // group = class * 2 + exact for the seven classes; 14 / 15 = k_ksw_row<2> / <4> (full-band approximate fills)
+#define DP_G_ROW2 14
+#define DP_G_ROW4 15
 
 template <int NP>
 static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc, const DpJobDev *jobs, const int32_t *ids, const uint8_t *d_q, const uint8_t *d_t,
@@ -446,6 +450,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	if (n == 0) return 0;
 	DpConst dc = mm355_dp_const(mo);
 	static const bool legacy = [] { const char *e = getenv("MM355_DP_LEGACY"); return e && atoi(e) != 0; }();
+	static const bool use_row = [] { const char *e = getenv("MM355_DP_ROW"); return !legacy && !(e && atoi(e) == 0); }();   // MM355_DP_ROW=0: anti-diagonal kernels only
 	const DpClass *classes = legacy? DP_CLASSES_LEGACY : DP_CLASSES;
 	// lay out per-job work areas; group = size class * 2 + exact
 	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
@@ -462,17 +467,36 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		int T = (j.tlen + 15) / 16 * 16;
 		j.p_off = (int64_t)p_tot; j.off_off = (int64_t)off_tot; j.cig_off = (int64_t)cig_tot; j.st_off = 0;
 		int g = 0;
+		j.pad = 0;
 		if (j.qlen > 0 && j.tlen > 0 && !j.skip) {
-			p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
 			cig_tot += (size_t)j.qlen + j.tlen + 2;
-			int cls = 0;
-			while (cls < DP_N_CLASS - 1 && T > classes[cls].cap) ++cls;
-			if (cls == DP_N_CLASS - 1) { j.st_off = (int64_t)st_tot; st_tot += T; }
-			g = cls * 2 + ((j.flag & EZ_APPROX_MAX)? 0 : 1);
+			// gap fills whose band never binds, without z-drop on the approximate score: the row sweep (mm355_dprow.h)
+			// ... and only for a regular two-piece cost (after ksw2's ordering: e > e2, or two identical pieces).  Otherwise the boundary row and
+			// column of U:ksw2_extd2_sse.c follow the dearer piece (long_thres <= 1), H(t,q) - H(t-1,q-1) can exceed the match score next to
+			// them, the kernel's clamp `z = min(z, sc_mch)` becomes active and the result is no longer the plain recurrence the row sweep
+			// computes (found by the option fuzzer: scoring=(4,10,3,3,12,3)); those options keep the literal anti-diagonal kernels.
+			const bool regular = dc.e > dc.e2 || (dc.e == dc.e2 && dc.q == dc.q2);
+			const bool row = use_row && regular && (j.flag & EZ_APPROX_MAX) && !(j.flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= j.qlen + j.tlen &&
+			                 j.tlen <= ROW_MAX_T && j.qlen + j.tlen <= ROW_MAX_QT;
+			if (row) {
+				j.pad = 1;
+				p_tot += (size_t)j.qlen * ((size_t)T + 16) + 16;
+				g = j.tlen <= 256? DP_G_ROW2 : DP_G_ROW4;
+			} else {
+				p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
+				int cls = 0;
+				while (cls < DP_N_CLASS - 1 && T > classes[cls].cap) ++cls;
+				if (cls == DP_N_CLASS - 1) { j.st_off = (int64_t)st_tot; st_tot += T; }
+				g = cls * 2 + ((j.flag & EZ_APPROX_MAX)? 0 : 1);
+			}
 		}
 		grp[i] = (uint8_t)g; ++n_grp[g];
 		int lb = (j.qlen + j.tlen) >> 3; if (lb < 0) lb = 0; if (lb >= LB) lb = LB - 1;
 		++lcnt[LB - 1 - lb];
+	}
+	if (const char *dump = getenv("MM355_DP_DUMP")) {   // diagnostics: (qlen, tlen, w, flag) of every job of this launch group, appended
+		static std::mutex dm; std::lock_guard<std::mutex> lk(dm);
+		if (FILE *fp = fopen(dump, "ab")) { for (size_t i = 0; i < n; ++i) { int32_t v[4] = { jobs[i].qlen, jobs[i].tlen, jobs[i].w, jobs[i].flag }; fwrite(v, 4, 4, fp); } fclose(fp); }
 	}
 	if (c->h_ids.ensure((2 * n + 64) * 4)) return MM355_ENOMEM;
 	int32_t *h_ids = (int32_t*)c->h_ids.p, *h_ord = h_ids + n + 8;
@@ -567,7 +591,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// the saved chunk rounds.)
 		static const bool nt512 = [] { const char *e = getenv("MM355_DP_LONG_NT"); return !(e && atoi(e) == 1024); }();
 		struct LongLaunch { int g0, g1, cap, sidx; };
-		static const LongLaunch long_launch[2] = { { 10, 14, 12288, 5 }, { 8, 10, 4096, 4 } };   // the longest sweeps first
+		static const LongLaunch long_launch[2] = { { 10, 14, 12288, 5 }, { 8, 10, 4096, 4 } };   // (groups 14, 15 are the row kernels)   // the longest sweeps first
 		bool long_used[2] = { false, false };
 		if (!legacy && !legacy_groups) for (int li = 0; li < 2; ++li) {
 			const LongLaunch &ll = long_launch[li];
@@ -589,6 +613,15 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		}
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
 			if (n_grp[g] == 0) continue;
+			if (g >= DP_G_ROW2) {   // the row sweep of the full-band approximate fills: the wide throughput grids of a round
+				hipStream_t gst; int rc2;
+				if ((rc2 = group_stream(g == DP_G_ROW2? 0 : 3, &gst))) return rc2;
+				if ((rc2 = group_begin(g, gst))) return rc2;
+				if (g == DP_G_ROW2) hipLaunchKernelGGL(k_ksw_row<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
+				else hipLaunchKernelGGL(k_ksw_row<4>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
+				if ((rc2 = group_end(g, gst, true))) return rc2;
+				continue;
+			}
 			const DpClass &k = classes[g >> 1];
 			if (k.kind == 2 && !legacy && !legacy_groups) continue;   // launched above
 			const int sidx = k.kind != 0? 4 + (g - 8) : (g & 1)? 1 : g >= 6? 2 : g >= 4? 3 : 0;
@@ -618,7 +651,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// leave the GPU almost empty; they keep running while the next context's round starts)
 		if (take_turns) { const double tl1 = mm355_now_ms(); HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); const double tl2 = mm355_now_ms(); mm355_trace_add(c, "dpk", t_turn0, tl2); mm355_trace_add(c, "dpk_launch", t_turn0, tl1); }
 		if (!legacy && !legacy_groups) { for (int li = 0; li < 2; ++li) if (long_used[li]) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[long_launch[li].g0], 0)); }
-		else for (int g = 0; g < DP_N_GROUP; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
+		else for (int g = 0; g < 2 * DP_N_CLASS; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
@@ -630,6 +663,10 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, 128, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
+	if (const char *dump = getenv("MM355_DP_DUMP_BT")) {   // diagnostics: the direction matrices of this launch group, raw
+		std::vector<uint8_t> hb(p_tot + 64);
+		if (hipMemcpy(hb.data(), c->dp_bt.p, p_tot, hipMemcpyDeviceToHost) == hipSuccess) if (FILE *fp = fopen(dump, "wb")) { fwrite(hb.data(), 1, p_tot, fp); fclose(fp); }
+	}
 	const size_t n_dense = (size_t)ctr[1];
 	if (arena->ensure((n_dense + 16) * 4)) return MM355_ENOMEM;
 	if (n_dense) HIPCHK(hipMemcpyAsync(arena->p, c->dp_dense.p, n_dense * 4, hipMemcpyDeviceToHost, c->st));
@@ -639,7 +676,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		const bool merged_long = !legacy && getenv("MM355_DP_SPLIT_LONG") == 0;
 		for (int g = 0; g < DP_N_GROUP; ++g) {
 			// the merged long-target launches are timed as groups 8 (targets <= 4096) and 10 (longer)
-			const bool timed_here = merged_long && g >= 8? ((g == 8 && grp_off[10] > grp_off[8]) || (g == 10 && grp_off[DP_N_GROUP] > grp_off[10])) : n_grp[g] != 0;
+			const bool timed_here = merged_long && g >= 8 && g < 14? ((g == 8 && grp_off[10] > grp_off[8]) || (g == 10 && grp_off[14] > grp_off[10])) : n_grp[g] != 0;
 			float ms = 0.f;
 			if (timed_here && hipEventElapsedTime(&ms, c->dp_ev0[g], c->dp_ev1[g]) == hipSuccess) c->stats.ms_dp_group[g] += ms;
 			if (n_grp[g] == 0) continue;

@@ -1,0 +1,194 @@
+// mm355_dprow.h -- row-sweep form of the banded extension kernel for the problems that dominate a batch: gap fills
+// (KSW_EZ_APPROX_MAX without KSW_EZ_APPROX_DROP) whose band never binds (w >= qlen + tlen), targets up to 512 bases.
+// Included by mm355_dp.hip; same results, bit for bit, as k_ksw_reg / U:ksw2_extd2_sse.c::ksw_extd2_sse for these problems.
+//
+// Why another form.  The anti-diagonal sweep of k_ksw_reg pays one 128-cell block evaluation per anti-diagonal and block it touches,
+// whatever the number of cells of the matrix on it: on a 212 x 213 fill (the typical one) 55 % of the evaluated lanes are inside the
+// matrix, and every block needs its neighbours' boundary cells, the band masks and the systolic query.  With a band that never binds
+// none of the SSE kernel's order-dependent behaviour is left (no stale band-edge cells can feed a cell of the matrix, no z-drop on the
+// approximate score): every cell holds the true H / E / F / E2 / F2 of the two-piece affine recurrence, and the direction byte of a cell
+// is a function of those values alone --
+//     d & 7  = position of the first (KSW_EZ_RIGHT: last) maximum among (H(t-1,q-1) + s, E, F, E2, F2),
+//     0x08   = E  - H + q  > 0 (RIGHT: >= 0),   0x10 = F  - H + q  > 0,   0x20 = E2 - H + q2 > 0,   0x40 = F2 - H + q2 > 0
+// (the difference recurrences of the SSE kernel are these comparisons shifted by H(t-1,q-1); int8 never wraps on true cells).
+// So the matrix can be filled in any order.  Here: one wave per alignment, lane l of register set k owns target cells 128 k + 2 l, + 1
+// (two int16 halves per VGPR), and the sweep goes ROW by row of the query -- every lane of the target is useful on every step:
+//     F, F2 (gaps that consume query)  come from the row above in the same lane;
+//     M needs H of the row above one cell to the left: one DPP wave_shr + v_alignbit per set;
+//     E, E2 (gaps that consume target) run ALONG the row: E(t) = max_{k<t} (G(k) + k e) - q - e - (t - 1) e with G = max(M, F, F2)
+//     (opening a gap from an H that is itself an E never beats extending that E), i.e. an exclusive prefix maximum over the lanes:
+//     six v_max_i32 DPP steps per set and gap type, the carry between sets through one v_readlane.
+// About 80 VALU per 128 cells of a row, all of them cells of the matrix: ~0.7 VALU per cell against ~1.6 for the anti-diagonal form.
+// The direction bytes are written row-major (q * tstride + t; 2-byte stores per lane, 128 B per set and row, coalesced); the job
+// descriptor says so (DpJobDev::pad = 1) and k_ksw_backtrack reads them that way.  ez: only `score` is defined for these problems
+// (max = 0, max_t = max_q = -1, not z-dropped), as in the approximate full-band path of k_ksw_reg.
+#pragma once
+
+#define ROW_NEG (-16384)
+#define ROW_MAX_T 512               // four register sets
+#define ROW_MAX_QT 6000             // qlen + tlen: keeps every value inside int16
+
+__device__ __forceinline__ uint32_t pk8w(int v) { const uint32_t h = (uint32_t)(uint16_t)(int16_t)v; return h | h << 16; }   // plain int16 in both halves
+__device__ __forceinline__ uint32_t pk_sign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }   // 0xffff where the half is negative
+__device__ __forceinline__ int32_t wave_incl_scan_max32(int32_t x)   // inclusive prefix maximum over lanes 0..lane (DPP row shifts + row broadcasts)
+{
+	int32_t y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x111, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x112, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x114, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x118, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x142, 0xa, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x143, 0xc, 0xf, false); x = x > y? x : y;
+	return x;
+}
+
+struct RowK {                       // wave-uniform constants (SGPRs)
+	uint32_t qe1, e1, qe2, e2, q1, q2, mch, N, one, two, three, four, f8, f16, f32, f64;
+	int32_t q1i, q2i;
+};
+
+// boundary H(t, -1) = H(-1, t): the sum of the first t + 1 boundary differences of U:ksw2_extd2_sse.c (-q-e, then -e while the first
+// gap piece is the cheaper one, long_diff at the crossover, -e2 after it)
+__device__ __forceinline__ int row_hb(int t, const DpConst &dc)
+{
+	if (t < 0) return 0;
+	const int lt = dc.long_thres;
+	int n1 = lt - 1 < t? lt - 1 : t; if (n1 < 0) n1 = 0;
+	const int has = (lt >= 1 && lt <= t)? 1 : 0;
+	const int n2 = t - n1 - has;
+	return -(dc.q + dc.e) - n1 * dc.e + has * dc.long_diff - n2 * dc.e2;
+}
+
+__device__ __forceinline__ uint32_t pk2(int lo, int hi) { return (uint32_t)(uint16_t)(int16_t)lo | (uint32_t)(uint16_t)(int16_t)hi << 16; }
+__device__ __forceinline__ uint32_t pk_max_swap(uint32_t a) { uint32_t r; asm("v_pk_max_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }   // both halves = max(lo, hi)
+
+// exclusive prefix maximum of A over the cells of one set, with carry-in C (value for every cell, includes all earlier sets);
+// returns the packed prefix minus `sub` (a wave-uniform int), and the carry for the next set in C
+__device__ __forceinline__ uint32_t row_scan(const uint32_t A, int32_t &C, const int32_t sub)
+{
+	const int32_t lm = (int32_t)pk_max_swap(A) >> 16;                     // max(lo, hi) of the lane, sign-extended
+	const int32_t incl = wave_incl_scan_max32(lm);
+	int32_t ex = __builtin_amdgcn_update_dpp(C, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 <- carry
+	ex = ex > C? ex : C;
+	const int32_t lo32 = (int32_t)(A << 16) >> 16;
+	const int32_t hi = ex > lo32? ex : lo32;
+	const int32_t tot = __builtin_amdgcn_readlane(incl, 63);
+	C = C > tot? C : tot;
+	return (uint32_t)((ex - sub) & 0xffff) | (uint32_t)(hi - sub) << 16;
+}
+
+template <int NS, bool RIGHT>
+__device__ __forceinline__ void row_sweep(const DpConst &dc, const RowK &K, const DpJobDev &jb, const uint8_t *query, const uint8_t *target, uint8_t *p, const int tstride,
+                                          const bool any_n, const int lane, int32_t &score_out)
+{
+	const int qlen = jb.qlen, tlen = jb.tlen;
+	uint32_t Hp[NS], Fp[NS], F2p[NS], TQ[NS], KE1[NS], KE2[NS];
+#pragma unroll
+	for (int k = 0; k < NS; ++k) {
+		const int t0 = 128 * k + 2 * lane;
+		Hp[k] = pk2(row_hb(t0, dc), row_hb(t0 + 1, dc));
+		Fp[k] = F2p[k] = pk2(ROW_NEG, ROW_NEG);
+		TQ[k] = (t0 < tlen? (uint32_t)target[t0] : 0u) | (t0 + 1 < tlen? (uint32_t)target[t0 + 1] : 0u) << 16;
+		KE1[k] = pk2(t0 * dc.e, (t0 + 1) * dc.e);
+		KE2[k] = pk2(t0 * dc.e2, (t0 + 1) * dc.e2);
+	}
+	const uint32_t dmis = vreg_const(pk8w(dc.sc_mis - dc.sc_mch));
+	int32_t hl_prev = 0, hl = row_hb(0, dc);          // H(-1, q - 1), H(-1, q)
+	uint32_t qv = 0;
+	uint8_t *prow = p + 2 * lane;
+	for (int q = 0; q < qlen; ++q) {
+		if ((q & 63) == 0) qv = q + lane < qlen? query[q + lane] : 0;
+		const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
+		const uint32_t qc2 = qc | qc << 16;
+		int32_t C1 = hl - dc.e, C2 = hl - dc.e2;       // the k = -1 term of both prefix maxima: a gap opened at the left border
+		uint32_t carry_h = pk2(0, hl_prev);            // (hi half) H of the row above, one cell to the left of this set's first cell
+#pragma unroll
+		for (int k = 0; k < NS; ++k) {
+			if (128 * k >= tlen) break;                // (wave-uniform) sets beyond the target
+			// H(t-1, q-1): the row above, shifted one cell to the right
+			const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_h, (int)Hp[k], 0x138, 0xf, 0xf, false);
+			const uint32_t Hd = __builtin_amdgcn_alignbit(Hp[k], sh, 16);
+			carry_h = (uint32_t)__builtin_amdgcn_readlane((int)Hp[k], 63);
+			// substitution score
+			uint32_t s = pk_mad_vvs(pk_minu_s(TQ[k] ^ qc2, K.one), dmis, K.mch);
+			if (any_n) s = pk_mad(pk_shr2(TQ[k] | qc2), pk_rsub_s(K.N, s), s);   // either base ambiguous (code 4): sc_N
+			const uint32_t M = pk_add(Hd, s);
+			const uint32_t F = pk_max(pk_sub_s(Hp[k], K.qe1), pk_sub_s(Fp[k], K.e1));
+			const uint32_t F2 = pk_max(pk_sub_s(Hp[k], K.qe2), pk_sub_s(F2p[k], K.e2));
+			const uint32_t G = pk_max(pk_max(M, F), F2);
+			// E(t) = max_{k<t} (G(k) + k e) - (q + e) - (t - 1) e = [prefix - q] - t e
+			const uint32_t E = pk_sub(row_scan(pk_add(G, KE1[k]), C1, K.q1i), KE1[k]);
+			const uint32_t E2 = pk_sub(row_scan(pk_add(G, KE2[k]), C2, K.q2i), KE2[k]);
+			const uint32_t H = pk_max(pk_max(G, E), E2);
+			// direction byte
+			const uint32_t n1 = pk_minu_s(pk_sub(H, E), K.one), n2 = pk_minu_s(pk_sub(H, F), K.one), n3 = pk_minu_s(pk_sub(H, E2), K.one);
+			uint32_t d;
+			if (!RIGHT) {   // first maximum
+				const uint32_t n0 = pk_minu_s(pk_sub(H, M), K.one);
+				d = pk_mad_vss(n3, K.one);
+				d = pk_mad_vvs(n2, d, K.one);
+				d = pk_mad_vvs(n1, d, K.one);
+				d = pk_mul(n0, d);
+			} else {        // last maximum
+				const uint32_t n4 = pk_minu_s(pk_sub(H, F2), K.one);
+				d = pk_rsub_s(K.one, n1);
+				d = pk_mad_vvs(n2, pk_sub_s(d, K.two), K.two);
+				d = pk_mad_vvs(n3, pk_sub_s(d, K.three), K.three);
+				d = pk_mad_vvs(n4, pk_sub_s(d, K.four), K.four);
+			}
+			const uint32_t t1 = pk_sub_s(H, K.q1), t2 = pk_sub_s(H, K.q2);
+			uint32_t fa, fb, fa2, fb2;
+			if (!RIGHT) {   // > 0: the sign of the reversed difference (plain int16 halves: any positive value, not only multiples of 256)
+				fa = K.f8 & pk_sign16(pk_sub(t1, E)); fb = K.f16 & pk_sign16(pk_sub(t1, F));
+				fa2 = K.f32 & pk_sign16(pk_sub(t2, E2)); fb2 = K.f64 & pk_sign16(pk_sub(t2, F2));
+			} else {        // >= 0
+				fa = K.f8 & ~pk_sign16(pk_sub(E, t1)); fb = K.f16 & ~pk_sign16(pk_sub(F, t1));
+				fa2 = K.f32 & ~pk_sign16(pk_sub(E2, t2)); fb2 = K.f64 & ~pk_sign16(pk_sub(F2, t2));
+			}
+			d = d | fa | fb; d = d | fa2 | fb2;
+			if (128 * k + 2 * lane < tlen) *(uint16_t*)(prow + 128 * k) = (uint16_t)__builtin_amdgcn_perm(0, d, 0x0c0c0200);
+			Hp[k] = H; Fp[k] = F; F2p[k] = F2;
+		}
+		prow += tstride;
+		hl_prev = hl;
+		hl = row_hb(q + 1, dc);
+	}
+	// H(tlen - 1, qlen - 1)
+	const int tl = tlen - 1;
+	uint32_t hv = 0;
+#pragma unroll
+	for (int k = 0; k < NS; ++k) if ((tl >> 7) == k) hv = (uint32_t)__builtin_amdgcn_readlane((int)Hp[k], (tl >> 1) & 63);
+	// U:ksw2_extd2_sse.c anchors the absolute score with `H0 = v[0] - qe` where qe was taken BEFORE it ordered the two gap pieces: when
+	// it swaps them every absolute score carries the constant (q + e)_ordered - (q + e)_given
+	score_out = (int32_t)(int16_t)(tl & 1? hv >> 16 : hv & 0xffff) + (dc.q + dc.e) - dc.qe_preswap;
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void k_ksw_row(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+                                                 const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr)
+{
+	const int lane = threadIdx.x;
+	if ((int)blockIdx.x >= n_jobs) return;
+	const int jid = job_ids[blockIdx.x];
+	const DpJobDev jb = jobs[jid];
+	const uint8_t *target = tbase + jb.toff, *query = qbase + jb.qoff;
+	RowK K;
+	K.qe1 = pk8w(dc.q + dc.e); K.e1 = pk8w(dc.e); K.qe2 = pk8w(dc.q2 + dc.e2); K.e2 = pk8w(dc.e2); K.q1 = pk8w(dc.q); K.q2 = pk8w(dc.q2);
+	K.mch = pk8w(dc.sc_mch); K.N = pk8w(dc.sc_N); K.one = 0x00010001u; K.two = 0x00020002u; K.three = 0x00030003u; K.four = 0x00040004u;
+	K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u; K.q1i = dc.q; K.q2i = dc.q2;
+	bool n = false;
+	for (int i = lane; i < jb.tlen; i += 64) n |= target[i] > 3;
+	for (int i = lane; i < jb.qlen; i += 64) n |= query[i] > 3;
+	const bool any_n = __ballot(n) != 0;
+	const int tstride = (jb.tlen + 15) / 16 * 16 + 16;
+	int32_t score = KSW_NEG_INF;
+	if (jb.flag & EZ_RIGHT) row_sweep<NS, true>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, score);
+	else row_sweep<NS, false>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, score);
+	if (lane == 0) {
+		mm355_dpres_t o;
+		o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = KSW_NEG_INF; o.score = score; o.reach_end = 0;
+		o.n_cigar = jb.tlen - 1; o.cigar_off = jb.qlen - 1;   // start cell for k_ksw_backtrack (not z-dropped, not KSW_EZ_EXTZ_ONLY)
+		res[jid] = o;
+		atomicAdd(cells_ctr, (unsigned long long)jb.qlen * (unsigned long long)jb.tlen);
+	}
+}

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmm355.so")
+LIB_PATH = os.environ.get("MM355_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libmm355.so")   # (override: A/B runs of two builds)
 
 MM355_ENODEV, MM355_EINVAL, MM355_ENOMEM, MM355_EIO, MM355_ENOIDX, MM355_EEMPTY, MM355_EUNSUP, MM355_EHIP = \
     -1, -2, -3, -4, -5, -6, -7, -8

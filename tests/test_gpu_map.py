@@ -293,6 +293,27 @@ def test_dp_kernel_parity(ont):
         if w is None:
             w = int(rng.integers(5, 200))
         jobs.append((len(q), tl, w, zd, -1 if i % 5 else 10, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
+    # gap fills whose band never binds (KSW_EZ_APPROX_MAX, w >= qlen + tlen, targets <= 512): the row-sweep kernel k_ksw_row -- every
+    # register-set border (128 / 256 / 384 / 512), query much longer / shorter than the target, ambiguous bases, left- and right-aligned
+    # gaps, reversed CIGARs, long indels (the second gap piece), empty-ish problems
+    for i in range(420):
+        tl = int(rng.choice([1, 2, 3, 17, 127, 128, 129, 200, 255, 256, 257, 300, 383, 384, 385, 511, 512])) if i % 3 == 0 else int(rng.integers(1, 513))
+        t = S.random_codes(rng, tl)
+        q = S.mutate(t, rng, 0.06, 0.03, 0.03)
+        if i % 7 == 0 and len(q) > 40:
+            cut = int(rng.integers(5, len(q) - 30)); q = np.concatenate([q[:cut], q[cut + int(rng.integers(1, 30)):]])        # deletion
+        if i % 7 == 3:
+            cut = int(rng.integers(0, len(q) + 1)); q = np.concatenate([q[:cut], S.random_codes(rng, int(rng.integers(1, 120))), q[cut:]])   # insertion
+        if i % 10 == 0:
+            q = S.random_codes(rng, int(rng.integers(1, 900)))                 # unrelated query, any length ratio
+        if i % 11 == 0 and len(q) > 6:
+            q[len(q) // 2:len(q) // 2 + 3] = 4
+        if i % 13 == 0 and tl > 6:
+            t[tl // 3:tl // 3 + 2] = 4
+        if len(q) == 0:
+            q = S.random_codes(rng, 1)
+        flag = APPROX | (RIGHT if i % 2 else 0) | (REV if i % 4 == 1 else 0)
+        jobs.append((len(q), tl, len(q) + tl + int(rng.integers(0, 50)), 400, -1, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
     qcat = np.concatenate(qs); tcat = np.concatenate(ts)
     ja = (_ffi.DpJob * len(jobs))()
     qo = to = 0
@@ -320,7 +341,48 @@ def test_dp_kernel_parity(ont):
         n_zd += ezd
         if ez.n_cigar: OL.free(ez.cigar)
     assert n_zd > 0
+    groups = list(sr.stats().n_launch_group)
+    assert groups[14] > 0 and groups[15] > 0, groups      # k_ksw_row<2> and <4> ran
     sr.close()
+
+
+def test_dp_row_kernel_with_reordered_gap_costs(ont):
+    """k_ksw_row under options ksw2 re-orders (q + e > q2 + e2: the pieces are swapped, the absolute score keeps the given q + e) and under
+    a single-piece cost (q == q2, e == e2); an irregular cost (e == e2, q != q2) must stay on the literal kernels"""
+    from mappy_rs import _ffi
+    import copy
+    L = _ffi.lib(); OL = O.lib()
+    rng = np.random.default_rng(31)
+    al = ont["al"]
+    for (a, b, amb, q, e, q2, e2), expect_row in (((4, 6, 1, 10, 1, 3, 4), True), ((2, 5, 1, 5, 2, 5, 2), True), ((4, 10, 1, 3, 3, 12, 3), False)):
+        mo = copy.copy(al._mo)
+        mo.a, mo.b, mo.sc_ambi, mo.q, mo.e, mo.q2, mo.e2 = a, b, amb, q, e, q2, e2
+        qs, ts, jobs = [], [], []
+        for i in range(120):
+            tl = int(rng.integers(1, 513)); t = S.random_codes(rng, tl); x = S.mutate(t, rng, 0.06, 0.03, 0.03)
+            if i % 6 == 0 and len(x) > 40:
+                cut = int(rng.integers(5, len(x) - 30)); x = np.concatenate([x[:cut], x[cut + int(rng.integers(1, 40)):]])
+            if i % 9 == 0 and len(x) > 6: x[len(x) // 2:len(x) // 2 + 2] = 4
+            if len(x) == 0: x = S.random_codes(rng, 1)
+            qs.append(x.astype(np.uint8)); ts.append(t.astype(np.uint8)); jobs.append((len(x), tl, len(x) + tl + 1, 8 | (2 if i % 2 else 0)))
+        qcat = np.concatenate(qs); tcat = np.concatenate(ts)
+        ja = (_ffi.DpJob * len(jobs))()
+        qo = to = 0
+        for i, (ql, tl, w, fl) in enumerate(jobs):
+            ja[i].qlen, ja[i].tlen, ja[i].qoff, ja[i].toff, ja[i].w, ja[i].zdrop, ja[i].end_bonus, ja[i].flag = ql, tl, qo, to, w, 400, -1, fl
+            qo += ql; to += tl
+        res = (_ffi.DpRes * len(jobs))(); cap = int(qcat.size + tcat.size + 4 * len(jobs)); cig = np.zeros(cap, np.uint32)
+        sr = al._stage_runner()
+        _ffi.check(L.mm355_stage_dp(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, tcat.ctypes.data, tcat.size, res, cig.ctypes.data, cap))
+        groups = list(sr.stats().n_launch_group)
+        assert (groups[14] + groups[15] > 0) == expect_row, (groups, (q, e, q2, e2))
+        mat = np.zeros(25, np.int8); OL.mmo_ksw_gen_simple_mat(5, mat.ctypes.data, a, b, amb)
+        for i, (ql, tl, w, fl) in enumerate(jobs):
+            ez = O.Extz()
+            OL.mmo_ksw_extd2(ql, qs[i].ctypes.data, tl, ts[i].ctypes.data, 5, mat.ctypes.data, q, e, q2, e2, w, 400, -1, fl, C.byref(ez))
+            assert res[i].score == ez.score and list(cig[res[i].cigar_off:res[i].cigar_off + res[i].n_cigar]) == [ez.cigar[k] for k in range(ez.n_cigar)], (i, jobs[i], (q, e, q2, e2))
+            if ez.n_cigar: OL.free(ez.cigar)
+        sr.close()
 
 
 def test_stats_counters(ont):

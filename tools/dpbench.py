@@ -1,5 +1,5 @@
 """DP kernel micro-benchmark through mm355_stage_dp: n jobs of ~L x L (5 % divergence), approx or exact.
-usage: python tools/dpbench.py [L=210] [n=100000] [flag=8]"""
+usage: python tools/dpbench.py [L=210] [n=100000] [flag=8] [w=500]   (w=30001: the full band of a gap fill)"""
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "mappy-rs_amd"))
 import numpy as np
@@ -10,6 +10,7 @@ L = _ffi.lib()
 Lt = int(sys.argv[1]) if len(sys.argv) > 1 else 210
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 flag = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+band = int(sys.argv[4]) if len(sys.argv) > 4 else 500
 rng = np.random.default_rng(5)
 g = S.make_genome(1, [200000])
 S.write_fasta("/tmp/dpb.fa", g)
@@ -24,7 +25,7 @@ qo = np.concatenate([[0], np.cumsum([len(x) for x in qs])]); to = np.concatenate
 ja = (_ffi.DpJob * n)()
 for i in range(n):
     k = i % 64
-    ja[i].qlen, ja[i].tlen, ja[i].qoff, ja[i].toff, ja[i].w, ja[i].zdrop, ja[i].end_bonus, ja[i].flag = len(qs[k]), Lt, int(qo[k]), int(to[k]), 500, 400, -1, flag
+    ja[i].qlen, ja[i].tlen, ja[i].qoff, ja[i].toff, ja[i].w, ja[i].zdrop, ja[i].end_bonus, ja[i].flag = len(qs[k]), Lt, int(qo[k]), int(to[k]), band, 400, -1, flag
 res = (_ffi.DpRes * n)()
 cap = int(n * (2 * Lt + 40))
 cig = np.zeros(cap, np.uint32)
