@@ -149,9 +149,10 @@ typedef struct {
 	int64_t n_launch_seed;
 	int64_t n_launch_dp;                         /* extension launch groups (one per round and HBM-budget chunk) */
 	/* per extension kernel of a launch group, timed with HIP events on the stream it is launched on; group = 2 * size class + exact,
-	 * size classes: targets <= 128, 256, 512, 1024 (k_ksw_reg<1|2|4|8, exact>), <= 4096, <= 12288, larger (k_ksw_extd2<512>) */
-	double ms_dp_group[16];
-	int64_t dp_cells_group[16], n_launch_group[16];
+	 * size classes: targets <= 128, 256, 512, 1024 (k_ksw_reg<1|2|4|8, exact>), <= 4096, <= 12288, larger (k_ksw_extd2<512>; one launch
+	 * for groups 8-9, timed as 8, and one for 10-13, timed as 10); 14 / 15 / 16 = k_ksw_row<2|4|8> (full-band approximate gap fills) */
+	double ms_dp_group[24];
+	int64_t dp_cells_group[24], n_launch_group[24];
 	int64_t n_ext_rounds;                        /* extension rounds of the last call (the reference has no bound on them) */
 	int64_t n_sort_fast_reads, n_sort_tie_reads; /* anchor sort: reads sorted by the segmented radix sort / of those, reads with equal keys
 	                                                whose equal-key runs went through the literal radix_sort_128x emulation */

@@ -425,9 +425,10 @@ struct DpClass { int cap, kind, np; };   // kind 0: k_ksw_reg, 1: k_ksw_extd2<64
 static const DpClass DP_CLASSES[] = { {128, 0, 1}, {256, 0, 2}, {512, 0, 4}, {1024, 0, 8}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 static const DpClass DP_CLASSES_LEGACY[] = { {256, 1, 0}, {512, 1, 0}, {1024, 1, 0}, {1024, 1, 0}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 #define DP_N_CLASS 7
-#define DP_N_GROUP 16                    // group = class * 2 + exact for the seven classes; 14 / 15 = k_ksw_row<2> / <4> (full-band approximate fills)
+#define DP_N_GROUP 17                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills)
 #define DP_G_ROW2 14
 #define DP_G_ROW4 15
+#define DP_G_ROW8 16
 
 template <int NP>
 static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc, const DpJobDev *jobs, const int32_t *ids, const uint8_t *d_q, const uint8_t *d_t,
@@ -481,7 +482,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			if (row) {
 				j.pad = 1;
 				p_tot += (size_t)j.qlen * ((size_t)T + 16) + 16;
-				g = j.tlen <= 256? DP_G_ROW2 : DP_G_ROW4;
+				g = j.tlen <= 256? DP_G_ROW2 : j.tlen <= 512? DP_G_ROW4 : DP_G_ROW8;
 			} else {
 				p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
 				int cls = 0;
@@ -541,9 +542,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4, *d_dense = c->counters.as<unsigned long long>() + 5;
 	double t_turn0 = 0;
 	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
-	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + 8;   // cells per group [16]
+	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + 8;   // cells per group [24]
 	HIPCHK(hipMemsetAsync(d_cells, 0, 8, c->st));
-	HIPCHK(hipMemsetAsync(d_gcells, 0, 128, c->st));
+	HIPCHK(hipMemsetAsync(d_gcells, 0, 192, c->st));
 	// every group gets its own HIP stream: the few long alignments of the big classes run concurrently with the thousands of
 	// short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
 	HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
@@ -615,10 +616,11 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			if (n_grp[g] == 0) continue;
 			if (g >= DP_G_ROW2) {   // the row sweep of the full-band approximate fills: the wide throughput grids of a round
 				hipStream_t gst; int rc2;
-				if ((rc2 = group_stream(g == DP_G_ROW2? 0 : 3, &gst))) return rc2;
+				if ((rc2 = group_stream(g == DP_G_ROW2? 0 : g == DP_G_ROW4? 3 : 2, &gst))) return rc2;
 				if ((rc2 = group_begin(g, gst))) return rc2;
 				if (g == DP_G_ROW2) hipLaunchKernelGGL(k_ksw_row<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
-				else hipLaunchKernelGGL(k_ksw_row<4>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
+				else if (g == DP_G_ROW4) hipLaunchKernelGGL(k_ksw_row<4>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
+				else hipLaunchKernelGGL(k_ksw_row<8>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
 				if ((rc2 = group_end(g, gst, true))) return rc2;
 				continue;
 			}
@@ -643,7 +645,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			else
 				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3(nj), dim3(512), (size_t)k.cap * 12, gst, dc, dj, gid, (int)nj, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
 				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense, -1);
-			if ((rc2 = group_end(g, gst, k.kind == 0))) return rc2;
+			if ((rc2 = group_end(g, gst, k.kind == 0 && !(g & 1)))) return rc2;   // in the turn: the approximate register classes; the exact ones are small latency-bound grids
 		}
 		// the turn ends when the extension kernels are done: the backtrack below is a latency-bound pointer walk and, like the result
 		// copies, overlaps the next context's round
@@ -651,7 +653,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// leave the GPU almost empty; they keep running while the next context's round starts)
 		if (take_turns) { const double tl1 = mm355_now_ms(); HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); const double tl2 = mm355_now_ms(); mm355_trace_add(c, "dpk", t_turn0, tl2); mm355_trace_add(c, "dpk_launch", t_turn0, tl1); }
 		if (!legacy && !legacy_groups) { for (int li = 0; li < 2; ++li) if (long_used[li]) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[long_launch[li].g0], 0)); }
-		else for (int g = 0; g < 2 * DP_N_CLASS; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));
+		else { for (int g = 0; g < 2 * DP_N_CLASS; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0)); }
+		for (int g = 1; g < 8; g += 2) if (n_grp[g] && classes[g >> 1].kind == 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the exact register classes
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
@@ -660,7 +663,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 256)) return MM355_ENOMEM;
 	unsigned long long *ctr = (unsigned long long*)((char*)c->h_res.p + n * sizeof(mm355_dpres_t));   // pinned landing zone of the counters
 	HIPCHK(hipMemcpyAsync(ctr, d_cells, 16, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, 128, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, 192, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
 	if (const char *dump = getenv("MM355_DP_DUMP_BT")) {   // diagnostics: the direction matrices of this launch group, raw

@@ -1,5 +1,5 @@
 // mm355_dprow.h -- row-sweep form of the banded extension kernel for the problems that dominate a batch: gap fills
-// (KSW_EZ_APPROX_MAX without KSW_EZ_APPROX_DROP) whose band never binds (w >= qlen + tlen), targets up to 512 bases.
+// (KSW_EZ_APPROX_MAX without KSW_EZ_APPROX_DROP) whose band never binds (w >= qlen + tlen), targets up to 1024 bases.
 // Included by mm355_dp.hip; same results, bit for bit, as k_ksw_reg / U:ksw2_extd2_sse.c::ksw_extd2_sse for these problems.
 //
 // Why another form.  The anti-diagonal sweep of k_ksw_reg pays one 128-cell block evaluation per anti-diagonal and block it touches,
@@ -25,7 +25,7 @@
 #pragma once
 
 #define ROW_NEG (-16384)
-#define ROW_MAX_T 512               // four register sets
+#define ROW_MAX_T 1024              // eight register sets
 #define ROW_MAX_QT 6000             // qlen + tlen: keeps every value inside int16
 
 __device__ __forceinline__ uint32_t pk8w(int v) { const uint32_t h = (uint32_t)(uint16_t)(int16_t)v; return h | h << 16; }   // plain int16 in both halves

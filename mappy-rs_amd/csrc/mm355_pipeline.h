@@ -69,7 +69,7 @@ struct mm355_ctx {
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
 	std::vector<hipEvent_t> tev; std::vector<double*> tacc; int n_tpend = 0;   // lazy stage timers (EvTimer)
-	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[16] = {}, dp_ev0[16] = {}, dp_ev1[16] = {};
+	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[24] = {}, dp_ev0[24] = {}, dp_ev1[24] = {};
 	HostBatch hb;
 };
 

@@ -203,7 +203,8 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 	for (DBuf *b : bufs) b->release();
 	for (ResidentBatch &r : c->slots) { r.seq.release(); r.roff.release(); r.rlen.release(); r.order.release(); r.ck_read.release(); r.ck_start.release(); r.ck_r0.release(); }
 	c->h_tasks.release(); c->h_chunks.release(); c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
-	for (int i = 0; i < 16; ++i) { if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]); if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); if (c->dp_ev0[i]) (void)hipEventDestroy(c->dp_ev0[i]); if (c->dp_ev1[i]) (void)hipEventDestroy(c->dp_ev1[i]); }
+	for (int i = 0; i < 16; ++i) if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]);
+	for (int i = 0; i < 24; ++i) { if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); if (c->dp_ev0[i]) (void)hipEventDestroy(c->dp_ev0[i]); if (c->dp_ev1[i]) (void)hipEventDestroy(c->dp_ev1[i]); }
 	if (c->dp_up_ev) (void)hipEventDestroy(c->dp_up_ev);
 	if (c->aux_st) (void)hipStreamDestroy(c->aux_st);
 	if (c->aux_ev) (void)hipEventDestroy(c->aux_ev);

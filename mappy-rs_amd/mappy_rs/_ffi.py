@@ -64,7 +64,7 @@ class Stats(C.Structure):
                 ("ms_sketch", C.c_double), ("ms_seed", C.c_double), ("ms_sort", C.c_double), ("ms_chain", C.c_double),
                 ("ms_backtrack", C.c_double), ("ms_dp", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double),
                 ("ms_seed_lookup", C.c_double), ("ms_seed_expand", C.c_double), ("n_launch_seed", C.c_int64), ("n_launch_dp", C.c_int64),
-                ("ms_dp_group", C.c_double * 16), ("dp_cells_group", C.c_int64 * 16), ("n_launch_group", C.c_int64 * 16),
+                ("ms_dp_group", C.c_double * 24), ("dp_cells_group", C.c_int64 * 24), ("n_launch_group", C.c_int64 * 24),
                 ("n_ext_rounds", C.c_int64), ("n_sort_fast_reads", C.c_int64), ("n_sort_tie_reads", C.c_int64)]
 
 

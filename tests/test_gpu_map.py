@@ -293,11 +293,11 @@ def test_dp_kernel_parity(ont):
         if w is None:
             w = int(rng.integers(5, 200))
         jobs.append((len(q), tl, w, zd, -1 if i % 5 else 10, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
-    # gap fills whose band never binds (KSW_EZ_APPROX_MAX, w >= qlen + tlen, targets <= 512): the row-sweep kernel k_ksw_row -- every
-    # register-set border (128 / 256 / 384 / 512), query much longer / shorter than the target, ambiguous bases, left- and right-aligned
+    # gap fills whose band never binds (KSW_EZ_APPROX_MAX, w >= qlen + tlen, targets <= 1024): the row-sweep kernel k_ksw_row -- every
+    # register-set border (128 / 256 / ... / 1024), query much longer / shorter than the target, ambiguous bases, left- and right-aligned
     # gaps, reversed CIGARs, long indels (the second gap piece), empty-ish problems
     for i in range(420):
-        tl = int(rng.choice([1, 2, 3, 17, 127, 128, 129, 200, 255, 256, 257, 300, 383, 384, 385, 511, 512])) if i % 3 == 0 else int(rng.integers(1, 513))
+        tl = int(rng.choice([1, 2, 3, 17, 127, 128, 129, 200, 255, 256, 257, 300, 383, 384, 385, 511, 512, 513, 640, 767, 768, 769, 1023, 1024])) if i % 3 == 0 else int(rng.integers(1, 1025))
         t = S.random_codes(rng, tl)
         q = S.mutate(t, rng, 0.06, 0.03, 0.03)
         if i % 7 == 0 and len(q) > 40:
@@ -342,7 +342,7 @@ def test_dp_kernel_parity(ont):
         if ez.n_cigar: OL.free(ez.cigar)
     assert n_zd > 0
     groups = list(sr.stats().n_launch_group)
-    assert groups[14] > 0 and groups[15] > 0, groups      # k_ksw_row<2> and <4> ran
+    assert groups[14] > 0 and groups[15] > 0 and groups[16] > 0, groups      # k_ksw_row<2>, <4> and <8> ran
     sr.close()
 
 
@@ -375,7 +375,7 @@ def test_dp_row_kernel_with_reordered_gap_costs(ont):
         sr = al._stage_runner()
         _ffi.check(L.mm355_stage_dp(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, tcat.ctypes.data, tcat.size, res, cig.ctypes.data, cap))
         groups = list(sr.stats().n_launch_group)
-        assert (groups[14] + groups[15] > 0) == expect_row, (groups, (q, e, q2, e2))
+        assert (groups[14] + groups[15] + groups[16] > 0) == expect_row, (groups, (q, e, q2, e2))
         mat = np.zeros(25, np.int8); OL.mmo_ksw_gen_simple_mat(5, mat.ctypes.data, a, b, amb)
         for i, (ql, tl, w, fl) in enumerate(jobs):
             ez = O.Extz()
