@@ -550,68 +550,70 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
 	if (c->dp_up_ev == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_up_ev, hipEventDisableTiming));
 	HIPCHK(hipEventRecord(c->dp_up_ev, c->st));   // the group streams start after the uploads
+	(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
+	// groups share a few streams (launch order = big problems first): 0 the wide approx classes (targets <= 256), 1 every exact
+	// class <= 1024, 2 approx 512/1024, 3.. the eight-wave kernels (few long alignments each: they overlap one another).  MM355_DP_STREAMS=0: one stream per group.
+	// Streams (created back to back at context creation, so they sit on different hardware queues): 0 approx targets <= 256 (the wide
+	// grids), 1 every exact register class, 2 approx 1024, 3 approx 512, 4 the eight-wave kernel.  The long-target classes (4096 /
+	// 12288 LDS state, HBM state; approx and exact) are ONE launch: a few dozen latency-bound alignments that must not queue behind
+	// one another, nor in front of the register classes on a shared hardware queue (they are not part of the turn).
+	static const bool legacy_groups = [] { const char *e = getenv("MM355_DP_SPLIT_LONG"); return e && atoi(e) != 0; }();
+	const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();
+	mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
+	auto group_stream = [&](int sidx, hipStream_t *out) -> int {
+		hipStream_t *slot = &c->dp_st[sidx];
+		if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
+		*out = *slot;
+		return 0;
+	};
+	auto group_begin = [&](int g, hipStream_t gst) -> int {
+		if (c->dp_ev[g] == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming));
+		HIPCHK(hipStreamWaitEvent(gst, c->dp_up_ev, 0));
+		if (c->dp_ev0[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev0[g]));
+		if (c->dp_ev1[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev1[g]));
+		HIPCHK(hipEventRecord(c->dp_ev0[g], gst));
+		return 0;
+	};
+	auto group_end = [&](int g, hipStream_t gst, bool in_turn) -> int {
+		HIPCHK(hipEventRecord(c->dp_ev1[g], gst));
+		HIPCHK(hipEventRecord(c->dp_ev[g], gst));
+		if (in_turn) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the eight-wave kernels are joined after the turn (below)
+		return 0;
+	};
+	// The long-target classes are two launches: targets <= 4096 (49 KB of LDS state: three alignments per CU) on stream 4, and longer ones
+	// (147 KB: one per CU; state in HBM beyond 12288 positions) on stream 5; approx and exact alignments share a launch.
+	// (MM355_DP_LONG_NT=1024: sixteen waves per alignment -- measured slower, 1019 vs 880 ms/step: the wider barrier costs more than
+	// the saved chunk rounds.)
+	static const bool nt512 = [] { const char *e = getenv("MM355_DP_LONG_NT"); return !(e && atoi(e) == 1024); }();
+	struct LongLaunch { int g0, g1, cap, sidx; };
+	static const LongLaunch long_launch[2] = { { 10, 14, 12288, 5 }, { 8, 10, 4096, 4 } };   // (groups 14, 15 are the row kernels)   // the longest sweeps first
+	bool long_used[2] = { false, false };
+	if (!legacy && !legacy_groups) for (int li = 0; li < 2; ++li) {
+		const LongLaunch &ll = long_launch[li];
+		const size_t nl = grp_off[ll.g1] - grp_off[ll.g0];
+		if (nl == 0) continue;
+		long_used[li] = true;
+		hipStream_t gst; int rc2;
+		if ((rc2 = group_stream(ll.sidx, &gst))) return rc2;
+		if ((rc2 = group_begin(ll.g0, gst))) return rc2;
+		if (nt512)
+			hipLaunchKernelGGL(k_ksw_extd2<512>, dim3((unsigned)nl), dim3(512), (size_t)ll.cap * 12, gst, dc, dj, d_ids + grp_off[ll.g0], (int)nl, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+			                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, ll.cap, d_gcells, c->dp_dense.as<uint32_t>(), d_dense, 4);
+		else {
+			(void)hipFuncSetAttribute((const void*)k_ksw_extd2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
+			hipLaunchKernelGGL(k_ksw_extd2<1024>, dim3((unsigned)nl), dim3(1024), (size_t)ll.cap * 12, gst, dc, dj, d_ids + grp_off[ll.g0], (int)nl, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
+			                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, ll.cap, d_gcells, c->dp_dense.as<uint32_t>(), d_dense, 4);
+		}
+		if ((rc2 = group_end(ll.g0, gst, false))) return rc2;
+	}
+	// (the launches above -- the long-target kernels -- are not part of the turn: a few dozen latency-bound alignments that leave the GPU
+	// almost empty; started BEFORE the turn is taken they run while this context waits for it)
 	// everything this round depends on (code-string gather, descriptor uploads) is finished BEFORE the turn is taken: the turn then holds
 	// nothing but extension kernels
 	if (take_turns) { HIPCHK(mm355_wait_stream(c->st)); turn.lock(my_turn, turn_cap); }
 	t_turn0 = mm355_now_ms();
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
-		(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
-		// groups share a few streams (launch order = big problems first): 0 the wide approx classes (targets <= 256), 1 every exact
-		// class <= 1024, 2 approx 512/1024, 3.. the eight-wave kernels (few long alignments each: they overlap one another).  MM355_DP_STREAMS=0: one stream per group.
-		// Streams (created back to back at context creation, so they sit on different hardware queues): 0 approx targets <= 256 (the wide
-		// grids), 1 every exact register class, 2 approx 1024, 3 approx 512, 4 the eight-wave kernel.  The long-target classes (4096 /
-		// 12288 LDS state, HBM state; approx and exact) are ONE launch: a few dozen latency-bound alignments that must not queue behind
-		// one another, nor in front of the register classes on a shared hardware queue (they are not part of the turn).
-		static const bool legacy_groups = [] { const char *e = getenv("MM355_DP_SPLIT_LONG"); return e && atoi(e) != 0; }();
-		const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();
-		mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
-		auto group_stream = [&](int sidx, hipStream_t *out) -> int {
-			hipStream_t *slot = &c->dp_st[sidx];
-			if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
-			*out = *slot;
-			return 0;
-		};
-		auto group_begin = [&](int g, hipStream_t gst) -> int {
-			if (c->dp_ev[g] == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming));
-			HIPCHK(hipStreamWaitEvent(gst, c->dp_up_ev, 0));
-			if (c->dp_ev0[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev0[g]));
-			if (c->dp_ev1[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev1[g]));
-			HIPCHK(hipEventRecord(c->dp_ev0[g], gst));
-			return 0;
-		};
-		auto group_end = [&](int g, hipStream_t gst, bool in_turn) -> int {
-			HIPCHK(hipEventRecord(c->dp_ev1[g], gst));
-			HIPCHK(hipEventRecord(c->dp_ev[g], gst));
-			if (in_turn) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the eight-wave kernels are joined after the turn (below)
-			return 0;
-		};
-		// The long-target classes are two launches: targets <= 4096 (49 KB of LDS state: three alignments per CU) on stream 4, and longer ones
-		// (147 KB: one per CU; state in HBM beyond 12288 positions) on stream 5; approx and exact alignments share a launch.
-		// (MM355_DP_LONG_NT=1024: sixteen waves per alignment -- measured slower, 1019 vs 880 ms/step: the wider barrier costs more than
-		// the saved chunk rounds.)
-		static const bool nt512 = [] { const char *e = getenv("MM355_DP_LONG_NT"); return !(e && atoi(e) == 1024); }();
-		struct LongLaunch { int g0, g1, cap, sidx; };
-		static const LongLaunch long_launch[2] = { { 10, 14, 12288, 5 }, { 8, 10, 4096, 4 } };   // (groups 14, 15 are the row kernels)   // the longest sweeps first
-		bool long_used[2] = { false, false };
-		if (!legacy && !legacy_groups) for (int li = 0; li < 2; ++li) {
-			const LongLaunch &ll = long_launch[li];
-			const size_t nl = grp_off[ll.g1] - grp_off[ll.g0];
-			if (nl == 0) continue;
-			long_used[li] = true;
-			hipStream_t gst; int rc2;
-			if ((rc2 = group_stream(ll.sidx, &gst))) return rc2;
-			if ((rc2 = group_begin(ll.g0, gst))) return rc2;
-			if (nt512)
-				hipLaunchKernelGGL(k_ksw_extd2<512>, dim3((unsigned)nl), dim3(512), (size_t)ll.cap * 12, gst, dc, dj, d_ids + grp_off[ll.g0], (int)nl, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
-				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, ll.cap, d_gcells, c->dp_dense.as<uint32_t>(), d_dense, 4);
-			else {
-				(void)hipFuncSetAttribute((const void*)k_ksw_extd2<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
-				hipLaunchKernelGGL(k_ksw_extd2<1024>, dim3((unsigned)nl), dim3(1024), (size_t)ll.cap * 12, gst, dc, dj, d_ids + grp_off[ll.g0], (int)nl, d_q, d_t, c->dp_bt.as<uint8_t>(), d_off,
-				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, ll.cap, d_gcells, c->dp_dense.as<uint32_t>(), d_dense, 4);
-			}
-			if ((rc2 = group_end(ll.g0, gst, false))) return rc2;
-		}
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
 			if (n_grp[g] == 0) continue;
 			if (g >= DP_G_ROW2) {   // the row sweep of the full-band approximate fills: the wide throughput grids of a round
