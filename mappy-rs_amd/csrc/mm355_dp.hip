@@ -338,6 +338,10 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 		const uint8_t *p = pbase + jb.p_off;
 		const int row_stride = (tlen + 15) / 16 * 16 + 16;
 		int i = i0, j = j0, state = 0;
+		// the open CIGAR run lives in registers and is stored once, when the operation changes (it used to be a read-modify-write of the
+		// scratch entry on every column: one more memory round trip per step, and most of the kernel's write traffic)
+		uint32_t run_op = 0, run_len = 0;
+#define BT_PUSH(op, len) do { if (run_len && run_op == (uint32_t)(op)) run_len += (uint32_t)(len); else { if (run_len) cigar[n_cigar++] = run_len << 4 | run_op; run_op = (uint32_t)(op); run_len = (uint32_t)(len); } } while (0)
 		while (i >= 0 && j >= 0) {
 			int force_state = -1, rr = i + j;
 			int st = 0, en = tlen - 1;
@@ -354,12 +358,14 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 			else if (!(tmp >> (state + 2) & 1)) state = 0;
 			if (state == 0) state = tmp & 7;
 			if (force_state >= 0) state = force_state;
-			if (state == 0) push_cigar(cigar, n_cigar, 0, 1), --i, --j;
-			else if (state == 1 || state == 3) push_cigar(cigar, n_cigar, 2, 1), --i;
-			else push_cigar(cigar, n_cigar, 1, 1), --j;
+			if (state == 0) { BT_PUSH(0, 1); --i; --j; }
+			else if (state == 1 || state == 3) { BT_PUSH(2, 1); --i; }
+			else { BT_PUSH(1, 1); --j; }
 		}
-		if (i >= 0) push_cigar(cigar, n_cigar, 2, i + 1);
-		if (j >= 0) push_cigar(cigar, n_cigar, 1, j + 1);
+		if (i >= 0) BT_PUSH(2, i + 1);
+		if (j >= 0) BT_PUSH(1, j + 1);
+		if (run_len) cigar[n_cigar++] = run_len << 4 | run_op;
+#undef BT_PUSH
 	}
 	const long long dst = (long long)atomicAdd(dense_ctr, (unsigned long long)n_cigar);   // dense arena: only real ops travel to the host
 	if (jb.flag & EZ_REV_CIGAR) for (int k = 0; k < n_cigar; ++k) dense[dst + k] = cigar[k];

@@ -1032,20 +1032,25 @@ __global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch b
 		if (m == 0) continue;                                  // (wave-uniform)
 		int end = -1;
 		if (start) { const unsigned long long rest = lane == 63? 0ULL : (m >> (lane + 1)) << (lane + 1); if (rest) end = base + __builtin_ctzll(rest); }
-		// the last start of the strip: look ahead for the next start
+		// the last start of the strip: look ahead for the next start, 512 anchors per step (eight independent loads per lane in flight:
+		// a segment of 100 000 anchors is ~200 steps, not 1600)
 		const int last = 63 - __builtin_clzll(m);
 		int fend = n;
 		uint64_t xl = __shfl(xi, 63);                          // x of the anchor just before the look-ahead position
-		for (int pos = base + 64; pos < n; pos += 64) {
-			const int j = pos + lane;
-			uint64_t xj = 0;
-			if (j < n) xj = a[j].x;
-			uint64_t xq = __shfl_up(xj, 1);
-			if (lane == 0) xq = xl;
-			const bool st2 = j < n && ((xj >> 32 != xq >> 32) || xj > xq + (uint64_t)(int64_t)mdx);
-			const unsigned long long m2 = __ballot(st2);
-			if (m2) { fend = pos + __builtin_ctzll(m2); break; }
-			xl = __shfl(xj, 63);
+		for (int pos = base + 64; pos < n && fend == n; pos += 512) {
+			uint64_t xj[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) { const int j = pos + 64 * u + lane; xj[u] = j < n? a[j].x : 0; }
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				const int j = pos + 64 * u + lane;
+				uint64_t xq = __shfl_up(xj[u], 1);
+				if (lane == 0) xq = xl;
+				const bool st2 = j < n && ((xj[u] >> 32 != xq >> 32) || xj[u] > xq + (uint64_t)(int64_t)mdx);
+				const unsigned long long m2 = __ballot(st2);
+				if (m2) { fend = pos + 64 * u + __builtin_ctzll(m2); break; }
+				xl = __shfl(xj[u], 63);
+			}
 		}
 		if (lane == last) end = fend;
 		chain_seg_emit(start, an, a, o, r, i, end - i, small, big, ctr, small_max);
