@@ -10,7 +10,8 @@ struct DBuf {
 	int ensure(size_t bytes) {
 		if (bytes <= cap) return 0;
 		if (p) (void)hipFree(p);
-		size_t want = bytes + bytes / 4 + 256;
+		const size_t slack = bytes / 4 < ((size_t)256 << 20)? bytes / 4 : ((size_t)256 << 20);   // grow-only with headroom, but no more than 256 MB of it:
+		size_t want = bytes + slack + 256;                                                       // several contexts hold multi-GB buffers side by side
 		if (hipMalloc(&p, want) != hipSuccess) { p = 0; cap = 0; return -1; }
 		cap = want; return 0;
 	}
