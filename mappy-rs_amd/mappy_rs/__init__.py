@@ -31,7 +31,7 @@ __all__ = ["Aligner", "Mapping", "shard_by_bases"]
 _CIGAR_OPS = "MIDNSHP=X"
 
 # capacity constants of the reference (lib.rs:429-430, 950)
-SUB_BATCH_READS, SUB_BATCH_BASES = 4096, 32_000_000   # one GPU sub-batch of map_batch
+SUB_BATCH_READS, SUB_BATCH_BASES = 6144, 64_000_000   # one GPU sub-batch of map_batch (bench.py's default shape)
 WORK_QUEUE_CAP = 50000
 RESULT_CHANNEL_CAP = 20000
 
@@ -443,7 +443,7 @@ class Aligner:
         sb_fixed = None if n_known is None else min(SUB_BATCH_READS, max(1024, -(-n_known // (2 * max_workers))))
 
         def sb_size(k):
-            return sb_fixed if sb_fixed is not None else min(SUB_BATCH_READS, 512 << min(3, k // max_workers))
+            return sb_fixed if sb_fixed is not None else min(SUB_BATCH_READS, 512 << min(4, k // max_workers))
 
         work = collections.deque()          # sub-batches (reads, items) waiting for a worker
         cv = threading.Condition()
