@@ -353,7 +353,7 @@ def main():
         # the extension kernel that takes the most time, timed alone with HIP events on its own stream (group = 2 * size class + exact)
         # (the long-target classes are two launches, approx and exact alignments together: targets <= 4096 timed as group 8, longer ones as 10)
         gnames = ["k_ksw_reg<%d, %s>" % (np_, ex) for np_ in (1, 2, 4, 8) for ex in ("false", "true")] + \
-                 ["k_ksw_extd2<512> (targets 1025..4096)", "-", "k_ksw_extd2<512> (targets > 4096)", "-", "-", "-", "k_ksw_row<2>", "k_ksw_row<4>", "k_ksw_row<8>"]
+                 ["k_ksw_extd2<512> (targets 1025..4096)", "-", "k_ksw_extd2<512> (targets > 4096)", "-", "-", "-", "k_ksw_row<2>", "k_ksw_row<4>", "k_ksw_row<8>", "k_ksw_rowl (targets 1025..4096)", "k_ksw_regw (exact, band <= 832, targets > 1024)"]
         cells_g = np.array(agg["dp_cells_group"], dtype=np.float64); cells_g[8] = cells_g[8:10].sum(); cells_g[10] = cells_g[10:14].sum(); cells_g[9] = 0; cells_g[11:14] = 0
         nl_g = np.array(agg["n_launch_group"], dtype=np.float64); nl_g[8] = nl_g[8:10].max(); nl_g[10] = nl_g[10:14].max(); nl_g[9] = 0; nl_g[11:14] = 0
         gi = int(np.argmax(agg["ms_dp_group"]))
@@ -392,8 +392,8 @@ def main():
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
             "resident_mbases_per_s": None if dt_res is None else round(aligned_res / dt_res / 1e6, 3),
             "roofline": roof[dom], "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
-            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(17) if nl_g[i] > 0},
-            "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(17) if nl_g[i] > 0},
+            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(19) if nl_g[i] > 0},
+            "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(19) if nl_g[i] > 0},
             "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
                                       n_dp_jobs=int(agg["n_dp_jobs"] / K)),
         }

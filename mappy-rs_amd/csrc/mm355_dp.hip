@@ -431,10 +431,27 @@ struct DpClass { int cap, kind, np; };   // kind 0: k_ksw_reg, 1: k_ksw_extd2<64
 static const DpClass DP_CLASSES[] = { {128, 0, 1}, {256, 0, 2}, {512, 0, 4}, {1024, 0, 8}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 static const DpClass DP_CLASSES_LEGACY[] = { {256, 1, 0}, {512, 1, 0}, {1024, 1, 0}, {1024, 1, 0}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 #define DP_N_CLASS 7
-#define DP_N_GROUP 17                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills)
+#define DP_N_GROUP 19                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills), 17 = k_ksw_rowl (the same, targets 1025..4096)
 #define DP_G_ROW2 14
 #define DP_G_ROW4 15
 #define DP_G_ROW8 16
+#define DP_G_ROWL 17
+#define DP_G_REGW 18                    // k_ksw_regw: exact, narrow band (w <= DP_WIN_MAX_W), targets > 1024 -- the register kernel with a moving window
+
+// value range of the row sweep on a qlen x tlen problem (int16 halves; ROW_NEG must stay below every real value, differences of two real
+// values and the shifted prefix terms G + t e must not wrap)
+static bool rowl_range_ok(const DpConst &dc, int qlen, int tlen)
+{
+	const int tl = (tlen + 127) & ~127;       // the lanes beyond the target compute cells of a wider matrix
+	auto cost = [&](int k) { const int c1 = dc.q + k * dc.e, c2 = dc.q2 + k * dc.e2; return c1 < c2? c1 : c2; };
+	const int emax = dc.e > dc.e2? dc.e : dc.e2;
+	const int hi = dc.sc_mch * (qlen < tl? qlen : tl);
+	int step = dc.q + dc.e > dc.q2 + dc.e2? dc.q + dc.e : dc.q2 + dc.e2;
+	if (-dc.sc_mis > step) step = -dc.sc_mis;
+	if (-dc.sc_N > step) step = -dc.sc_N;
+	const int lo = cost(qlen + 1) + cost(tl + 1) + step + emax + 64;
+	return hi + emax * (tl + 1) <= 32000 && lo <= -ROW_NEG - 64 && hi + lo <= 32000;
+}
 
 template <int NP>
 static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc, const DpJobDev *jobs, const int32_t *ids, const uint8_t *d_q, const uint8_t *d_t,
@@ -458,6 +475,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	DpConst dc = mm355_dp_const(mo);
 	static const bool legacy = [] { const char *e = getenv("MM355_DP_LEGACY"); return e && atoi(e) != 0; }();
 	static const bool use_row = [] { const char *e = getenv("MM355_DP_ROW"); return !legacy && !(e && atoi(e) == 0); }();   // MM355_DP_ROW=0: anti-diagonal kernels only
+	static const bool use_rowl = [] { const char *e = getenv("MM355_DP_ROWL"); return !(e && atoi(e) == 0); }();                           // MM355_DP_ROWL=0: no eight-wave row sweep
+	static const bool use_regw = [] { const char *e = getenv("MM355_DP_REGW"); return !legacy && !(e && atoi(e) == 0); }();               // MM355_DP_REGW=0: no windowed register kernel
 	const DpClass *classes = legacy? DP_CLASSES_LEGACY : DP_CLASSES;
 	// lay out per-job work areas; group = size class * 2 + exact
 	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
@@ -483,18 +502,22 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			// them, the kernel's clamp `z = min(z, sc_mch)` becomes active and the result is no longer the plain recurrence the row sweep
 			// computes (found by the option fuzzer: scoring=(4,10,3,3,12,3)); those options keep the literal anti-diagonal kernels.
 			const bool regular = dc.e > dc.e2 || (dc.e == dc.e2 && dc.q == dc.q2);
-			const bool row = use_row && regular && (j.flag & EZ_APPROX_MAX) && !(j.flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= j.qlen + j.tlen &&
-			                 j.tlen <= ROW_MAX_T && j.qlen + j.tlen <= ROW_MAX_QT;
-			if (row) {
+			const bool row_kind = use_row && regular && (j.flag & EZ_APPROX_MAX) && !(j.flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= j.qlen + j.tlen;
+			const bool row = row_kind && j.tlen <= ROW_MAX_T && j.qlen + j.tlen <= ROW_MAX_QT;
+			const bool rowl = row_kind && use_rowl && j.tlen > ROW_MAX_T && j.tlen <= ROWL_MAX_T && j.qlen <= ROWL_MAX_Q && rowl_range_ok(dc, j.qlen, j.tlen);
+			if (row || rowl) {
 				j.pad = 1;
 				p_tot += (size_t)j.qlen * ((size_t)T + 16) + 16;
-				g = j.tlen <= 256? DP_G_ROW2 : j.tlen <= 512? DP_G_ROW4 : DP_G_ROW8;
+				g = rowl? DP_G_ROWL : j.tlen <= 256? DP_G_ROW2 : j.tlen <= 512? DP_G_ROW4 : DP_G_ROW8;
 			} else {
 				p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
 				int cls = 0;
 				while (cls < DP_N_CLASS - 1 && T > classes[cls].cap) ++cls;
-				if (cls == DP_N_CLASS - 1) { j.st_off = (int64_t)st_tot; st_tot += T; }
-				g = cls * 2 + ((j.flag & EZ_APPROX_MAX)? 0 : 1);
+				if (use_regw && T > 1024 && !(j.flag & EZ_APPROX_MAX) && w <= DP_WIN_MAX_W) g = DP_G_REGW;
+				else {
+					if (cls == DP_N_CLASS - 1) { j.st_off = (int64_t)st_tot; st_tot += T; }
+					g = cls * 2 + ((j.flag & EZ_APPROX_MAX)? 0 : 1);
+				}
 			}
 		}
 		grp[i] = (uint8_t)g; ++n_grp[g];
@@ -612,6 +635,22 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		}
 		if ((rc2 = group_end(ll.g0, gst, false))) return rc2;
 	}
+	if (n_grp[DP_G_REGW]) {   // the long narrow-band extensions: one wave each, thousands of anti-diagonals -- the longest latency chain of a round
+		hipStream_t gst; int rc2;
+		if ((rc2 = group_stream(7, &gst))) return rc2;
+		if ((rc2 = group_begin(DP_G_REGW, gst))) return rc2;
+		hipLaunchKernelGGL(k_ksw_regw, dim3((unsigned)n_grp[DP_G_REGW]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
+		                   c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_G_REGW);
+		if ((rc2 = group_end(DP_G_REGW, gst, false))) return rc2;
+	}
+	if (n_grp[DP_G_ROWL]) {   // the eight-wave row sweep of the long full-band fills: a few hundred blocks at most, outside the turn as well
+		hipStream_t gst; int rc2;
+		if ((rc2 = group_stream(6, &gst))) return rc2;
+		if ((rc2 = group_begin(DP_G_ROWL, gst))) return rc2;
+		hipLaunchKernelGGL(k_ksw_rowl, dim3((unsigned)n_grp[DP_G_ROWL]), dim3(64 * ROWL_WAVES), 0, gst, dc, dj, d_ids + grp_off[DP_G_ROWL], (int)n_grp[DP_G_ROWL], d_q, d_t,
+		                   c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_G_ROWL);
+		if ((rc2 = group_end(DP_G_ROWL, gst, false))) return rc2;
+	}
 	// (the launches above -- the long-target kernels -- are not part of the turn: a few dozen latency-bound alignments that leave the GPU
 	// almost empty; started BEFORE the turn is taken they run while this context waits for it)
 	// everything this round depends on (code-string gather, descriptor uploads) is finished BEFORE the turn is taken: the turn then holds
@@ -621,7 +660,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	{
 		EvTimer2 tm(c, &c->stats.ms_dp);
 		for (int g = DP_N_GROUP - 1; g >= 0; --g) {   // big problems first
-			if (n_grp[g] == 0) continue;
+			if (n_grp[g] == 0 || g == DP_G_ROWL || g == DP_G_REGW) continue;
 			if (g >= DP_G_ROW2) {   // the row sweep of the full-band approximate fills: the wide throughput grids of a round
 				hipStream_t gst; int rc2;
 				if ((rc2 = group_stream(g == DP_G_ROW2? 0 : g == DP_G_ROW4? 3 : 2, &gst))) return rc2;
@@ -660,6 +699,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// (only the wide register-kernel grids count: the few long alignments of the eight-wave classes are latency chains that
 		// leave the GPU almost empty; they keep running while the next context's round starts)
 		if (take_turns) { const double tl1 = mm355_now_ms(); HIPCHK(mm355_wait_stream(c->st)); turn.unlock(); const double tl2 = mm355_now_ms(); mm355_trace_add(c, "dpk", t_turn0, tl2); mm355_trace_add(c, "dpk_launch", t_turn0, tl1); }
+		if (n_grp[DP_G_ROWL]) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[DP_G_ROWL], 0));
+		if (n_grp[DP_G_REGW]) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[DP_G_REGW], 0));
 		if (!legacy && !legacy_groups) { for (int li = 0; li < 2; ++li) if (long_used[li]) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[long_launch[li].g0], 0)); }
 		else { for (int g = 0; g < 2 * DP_N_CLASS; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0)); }
 		for (int g = 1; g < 8; g += 2) if (n_grp[g] && classes[g >> 1].kind == 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the exact register classes

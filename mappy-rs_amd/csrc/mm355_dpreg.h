@@ -54,8 +54,9 @@ struct DpSt { DP_MEMB(0) DP_MEMB(1) DP_MEMB(2) DP_MEMB(3) DP_MEMB(4) DP_MEMB(5) 
 struct DpK { uint32_t nqe, nq2e2, q, q2, qe, q2e2, mch, dmis_v, N, one, c256, m256, two, three, four, f8, f16, f32, f64, dx1, dx21; };
 struct DpRun {             // wave-uniform state of the sweep
 	int qlen, tlen, w, T, n_col, flag, zdrop, end_bonus, q, e, q2, e2, qe, long_thres, long_diff, r_total;
-	const uint8_t *query; uint8_t *p;
+	const uint8_t *query, *target; uint8_t *p;
 	int r, st, en, st0, en0, last_st, last_en;
+	int base;              // WIN: target position of cell 0 of block 0 (a multiple of 128); 0 otherwise
 	int32_t H0, last_H0_t;
 	unsigned long long cells;
 	uint32_t qv;
@@ -86,7 +87,7 @@ __device__ __forceinline__ bool dp_bounds(DpRun &R)   // U:ksw2_extd2_sse.c: st/
 }
 
 struct DpDiag {            // wave-uniform description of one anti-diagonal
-	int r, st, en, st0, jq, lane_st, lane_r;
+	int r, st, en, st0, jq, jst, lane_st, lane_r;   // jq / jst: block of the top-row cell t = r / of st
 	uint32_t sclen, dv1, edge_u8, qc_hi;
 	bool use_def, edge, any_n;
 	size_t prow;           // r * n_col - st
@@ -108,7 +109,7 @@ __device__ __forceinline__ void dp_score(const DpDiag &g, const DpK &k, const in
 }
 
 // one block of one anti-diagonal; pX/pV/pX2 = registers of block J-1 (previous anti-diagonal)
-template <int J, bool IS_LO, bool IS_HI, bool RIGHT>
+template <int J, bool IS_LO, bool IS_HI, bool RIGHT, bool ANYBLK>
 __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int lane, uint8_t *p,
                                         uint32_t &U, uint32_t &V, uint32_t &X, uint32_t &Y, uint32_t &X2, uint32_t &Y2, const uint32_t SC,
                                         const uint32_t pX, const uint32_t pV, const uint32_t pX2)
@@ -118,13 +119,15 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 	uint32_t nx_, nv_, nx2_;
 	if (J > 0) { nx_ = lane_shr1(fx, X); nv_ = lane_shr1(fv, V); nx2_ = lane_shr1(fx2, X2); }
 	else { nx_ = lane_shr1_z(X); nv_ = lane_shr1_z(V); nx2_ = lane_shr1_z(X2); }   // lane 0 of block 0: t-1 = -1, always a boundary value (IS_LO below)
-	if (IS_LO) {   // x[st-1], v[st-1], x2[st-1] are boundary values when that cell was outside the previous anti-diagonal
+	// (ANYBLK: the catch-all instance, whose first / last ACTIVE block is only known at run time -- every block tests, wave-uniformly,
+	// whether it holds st or the top-row cell)
+	if (IS_LO && (!ANYBLK || J == g.jst)) {   // x[st-1], v[st-1], x2[st-1] are boundary values when that cell was outside the previous anti-diagonal
 		const bool at = lane == g.lane_st;   // (lane_st = -1 when the neighbour's state is to be used: no uniform-bool x lane-mask AND)
 		nx_ = at? k.dx1 : nx_; nv_ = at? g.dv1 : nv_; nx2_ = at? k.dx21 : nx2_;
 	}
 	const uint32_t XT = __builtin_amdgcn_alignbit(X, nx_, 16), VT = __builtin_amdgcn_alignbit(V, nv_, 16), X2T = __builtin_amdgcn_alignbit(X2, nx2_, 16);
 	uint32_t yi = Y, y2i = Y2, ui = U;
-	if (IS_HI) {   // top row (query position 0, only ever in the last active block): y, y2 and u are the boundary values
+	if (IS_HI && (!ANYBLK || J == g.jq)) {   // top row (query position 0, only ever in the last active block): y, y2 and u are the boundary values
 		const uint32_t hm = (g.r & 1)? 0xffff0000u : 0xffffu, m = (lane == (J == g.jq? g.lane_r : -1))? hm : 0u;   // lane_r = -1 without edge
 		yi = bfi(m, k.nqe, yi); y2i = bfi(m, k.nq2e2, y2i); ui = bfi(m, g.edge_u8, ui);
 	}
@@ -210,12 +213,14 @@ __device__ __forceinline__ void dp_block_h(const int lane, const int st0, const 
 
 // one anti-diagonal with active blocks JLO..JHI (a superset of the blocks that intersect [st, en] is fine: lanes outside are
 // masked); returns false when the sweep ends here (z-drop)
-template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI>
+template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI, bool WIN, bool WIDE>
 __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const int lane)
 {
 	const int r = R.r, st = R.st, en = R.en, st0 = R.st0, en0 = R.en0;
+	const int base = WIN? R.base : 0;                  // the registers hold target positions [base, base + 128 NP): `_r` = relative to base
+	const int st0_r = st0 - base, en0_r = en0 - base;
 	DpDiag g;
-	g.r = r; g.st = st; g.en = en; g.st0 = st0; g.any_n = R.any_n;
+	g.r = r; g.st = st - base; g.en = en - base; g.st0 = st0_r; g.any_n = R.any_n;
 	g.use_def = st == 0 || !(st - 1 >= R.last_st && st - 1 <= R.last_en);
 	const int edge_u = r == 0? -R.q - R.e : r < R.long_thres? -R.e : r == R.long_thres? R.long_diff : -R.e2;
 	g.edge_u8 = pk8(edge_u);
@@ -224,12 +229,12 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 	int sce = st0 + ((en0 - st0) / 16 + 1) * 16;   // scores are (re)written for t in [st0, sce), clipped to the padded target
 	if (sce > R.T) sce = R.T;
 	g.sclen = (uint32_t)(sce - st0);
-	if ((r & 63) == 0) R.qv = r + lane < R.qlen? R.query[r + lane] : 0;   // query[r] enters at t = 0
+	if ((r & 63) == 0) R.qv = r - base + lane < R.qlen? R.query[r - base + lane] : 0;   // query[r - base] enters at cell 0
 	g.qc_hi = rdlane(R.qv, r & 63) << 16;
-	g.jq = r >> 7;
+	g.jq = (r - base) >> 7; g.jst = (st - base) >> 7;
 	g.lane_st = g.use_def? (st & 127) >> 1 : -1; g.lane_r = g.edge? (r & 127) >> 1 : -1;
-	g.prow = (size_t)r * R.n_col - st;
-	const int jsh = (sce - 1) >> 7;
+	g.prow = (size_t)r * R.n_col - (st - base);
+	const int jsh = (sce - 1 - base) >> 7;
 	// 1. the query moves (descending: block J takes the last cell of block J-1 before that one moves); blocks beyond t = r hold zeros
 #define DP_SLIDE(k, m) if constexpr (NP > k) { if (k <= JHI || k <= g.jq) dp_slide(S.QQ##k, k > 0? rdlane(S.QQ##m, 63) : g.qc_hi); }
 	DP_SLIDE(7, 6) DP_SLIDE(6, 5) DP_SLIDE(5, 4) DP_SLIDE(4, 3) DP_SLIDE(3, 2) DP_SLIDE(2, 1) DP_SLIDE(1, 0) DP_SLIDE(0, 0)
@@ -237,17 +242,17 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 #define DP_SCORE(k) if constexpr (NP > k) { if (DP_IN(k) || (k == JHI + 1 && jsh > JHI)) dp_score<k>(g, K, lane, S.SC##k, S.TQ##k, S.QQ##k); }
 	DP_SCORE(0) DP_SCORE(1) DP_SCORE(2) DP_SCORE(3) DP_SCORE(4) DP_SCORE(5) DP_SCORE(6) DP_SCORE(7)
 	// 3. the recurrence, descending for the same reason
-#define DP_CORE(k, m) if constexpr (DP_IN(k)) dp_core<k, k == JLO, k == JHI, RIGHT>(g, K, lane, R.p, S.U##k, S.V##k, S.X##k, S.Y##k, S.X2##k, S.Y2##k, S.SC##k, S.X##m, S.V##m, S.X2##m);
+#define DP_CORE(k, m) if constexpr (DP_IN(k)) dp_core<k, WIDE || k == JLO, WIDE || k == JHI, RIGHT, WIDE>(g, K, lane, R.p, S.U##k, S.V##k, S.X##k, S.Y##k, S.X2##k, S.Y2##k, S.SC##k, S.X##m, S.V##m, S.X2##m);
 	DP_CORE(7, 6) DP_CORE(6, 5) DP_CORE(5, 4) DP_CORE(4, 3) DP_CORE(3, 2) DP_CORE(2, 1) DP_CORE(1, 0) DP_CORE(0, 0)
 	R.cells += (unsigned long long)(en0 - st0 + 1);
 	EzState &ez = R.ez;
 	if constexpr (EXACT) {
 		int32_t max_H, max_t, Hen0, Hst0;
 		if (r > 0) {
-			const int32_t hen = en0 > 0? DP_HAT(en0 - 1) + DP_CELL8(U, en0) : DP_HAT(en0) + DP_CELL8(V, en0);
-			const int en1 = st0 + (en0 - st0) / 4 * 4;
+			const int32_t hen = en0 > 0? DP_HAT(en0_r - 1) + DP_CELL8(U, en0_r) : DP_HAT(en0_r) + DP_CELL8(V, en0_r);
+			const int en1_r = st0_r + (en0_r - st0_r) / 4 * 4;
 			long long best = INT64_MIN;
-#define DP_STEP_H(k) if constexpr (DP_IN(k)) dp_block_h<k>(lane, st0, en0, en1, hen, S.V##k, S.Hl##k, S.Hh##k, best);
+#define DP_STEP_H(k) if constexpr (DP_IN(k)) dp_block_h<k>(lane, st0_r, en0_r, en1_r, hen, S.V##k, S.Hl##k, S.Hh##k, best);
 			DP_STEP_H(0) DP_STEP_H(1) DP_STEP_H(2) DP_STEP_H(3) DP_STEP_H(4) DP_STEP_H(5) DP_STEP_H(6) DP_STEP_H(7)
 #pragma unroll
 			for (int o = 1; o < 64; o <<= 1) {
@@ -257,9 +262,9 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 			max_H = hen; max_t = en0;
 			if (best != INT64_MIN) {
 				const int32_t ch = (int32_t)(best >> 32);
-				if (ch > hen) { max_H = ch; max_t = (int)(~(uint32_t)best & 0xffffu); }
+				if (ch > hen) { max_H = ch; max_t = (int)(~(uint32_t)best & 0xffffu) + base; }
 			}
-			Hen0 = hen; Hst0 = st0 == en0? hen : DP_HAT(st0);
+			Hen0 = hen; Hst0 = st0 == en0? hen : DP_HAT(st0_r);
 		} else {
 			const int32_t h0 = DP_CELL8(V, 0) - R.qe;
 			S.Hl0 = lane == 0? h0 : S.Hl0;
@@ -281,8 +286,8 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 			return true;
 		}
 		if (r > 0) {
-			const int lt = R.last_H0_t;
-			const bool in0 = lt >= st0 && lt <= en0, in1 = lt + 1 >= st0 && lt + 1 <= en0;
+			const int lt = R.last_H0_t - base;
+			const bool in0 = lt >= st0_r && lt <= en0_r, in1 = lt + 1 >= st0_r && lt + 1 <= en0_r;
 			if (in0 && in1) {
 				const int32_t d0 = DP_CELL8(V, lt), d1 = DP_CELL8(U, lt + 1);
 				if (d0 > d1) R.H0 += d0;
@@ -296,48 +301,71 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 	return true;
 }
 
+// WIN (NP = 8): the register window moves up by one block -- block k takes over the state of block k + 1, block 7 starts fresh on the
+// next 128 target positions.  Called between two anti-diagonals (R.r is the next one) once the band has left block 0 for good (st and en
+// never decrease): cells below st - 1 are never read again.  A fresh cell is what the SSE kernel's arrays hold for a position the band
+// has not reached yet: the initial u/v/x/y, score 0, H = -inf, and the query base the systolic register would have carried there.
+__device__ __forceinline__ void dp_rebase(DpRun &R, DpSt &S, const DpK &K, const int lane)
+{
+#define DP_SHIFT(k, m) S.U##k = S.U##m; S.V##k = S.V##m; S.X##k = S.X##m; S.Y##k = S.Y##m; S.X2##k = S.X2##m; S.Y2##k = S.Y2##m; S.SC##k = S.SC##m; \
+		S.TQ##k = S.TQ##m; S.QQ##k = S.QQ##m; S.Hl##k = S.Hl##m; S.Hh##k = S.Hh##m;
+	DP_SHIFT(0, 1) DP_SHIFT(1, 2) DP_SHIFT(2, 3) DP_SHIFT(3, 4) DP_SHIFT(4, 5) DP_SHIFT(5, 6) DP_SHIFT(6, 7)
+	R.base += 128;
+	const int t = R.base + 896 + 2 * lane;
+	S.U7 = S.V7 = S.X7 = S.Y7 = K.nqe; S.X27 = S.Y27 = K.nq2e2; S.SC7 = 0; S.Hl7 = S.Hh7 = KSW_NEG_INF;
+	S.TQ7 = (t < R.tlen? (uint32_t)R.target[t] : 0u) | (t + 1 < R.tlen? (uint32_t)R.target[t + 1] : 0u) << 16;
+	const int qi = R.r - 1 - t;                        // the registers stand at anti-diagonal r - 1: cell t holds query[r - 1 - t]
+	S.QQ7 = (qi >= 0 && qi < R.qlen? (uint32_t)R.query[qi] : 0u) | (qi - 1 >= 0 && qi - 1 < R.qlen? (uint32_t)R.query[qi - 1] : 0u) << 16;
+	const int q0 = (R.r & ~63) - R.base;               // the 64 query bases that enter at cell 0 during this 64-diagonal period
+	R.qv = q0 + lane >= 0 && q0 + lane < R.qlen? R.query[q0 + lane] : 0;
+}
+
 // all anti-diagonals whose active blocks are JLO..JHI (WIDE: the catch-all instance that covers every block, used while the
 // band spans more than DP_MAX_TIGHT blocks); returns true when the sweep is finished
 #define DP_MAX_TIGHT 4
-template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI, bool WIDE>
+template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI, bool WIDE, bool WIN>
 __device__ __forceinline__ bool dp_segment(DpRun &R, DpSt &S, const DpK &K, const int lane)
 {
 	for (;;) {
-		if (!dp_diag<NP, EXACT, RIGHT, JLO, JHI>(R, S, K, lane)) return true;
+		if (!dp_diag<NP, EXACT, RIGHT, JLO, JHI, WIN, WIDE>(R, S, K, lane)) return true;
 		R.last_st = R.st; R.last_en = R.en;
 		if (++R.r >= R.r_total) return true;
 		if (!dp_bounds(R)) { R.ez.zdropped = 1; return true; }
-		const int jlo = R.st >> 7, jhi = R.en >> 7;
-		if (WIDE? jhi - jlo < DP_MAX_TIGHT : (jlo != JLO || jhi != JHI)) return false;
+		if constexpr (WIN) { while (R.st - 1 - R.base >= 128) dp_rebase(R, S, K, lane); }
+		const int base = WIN? R.base : 0;
+		const int jlo = (R.st - base) >> 7, jhi = (R.en - base) >> 7;
+		if (WIDE? (!WIN && jhi - jlo < DP_MAX_TIGHT) : (jlo != JLO || jhi != JHI)) return false;   // (WIN runs on the catch-all instance only)
 	}
 }
 
-template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI>
+template <int NP, bool EXACT, bool RIGHT, int JLO, int JHI, bool WIN>
 __device__ __forceinline__ bool dp_dispatch(const int jlo, const int jhi, DpRun &R, DpSt &S, const DpK &K, const int lane)
 {
-	if (jlo == JLO && jhi == JHI) return dp_segment<NP, EXACT, RIGHT, JLO, JHI, false>(R, S, K, lane);
-	if constexpr (JHI + 1 < NP && JHI + 1 - JLO < DP_MAX_TIGHT) return dp_dispatch<NP, EXACT, RIGHT, JLO, JHI + 1>(jlo, jhi, R, S, K, lane);
-	else if constexpr (JLO + 1 < NP) return dp_dispatch<NP, EXACT, RIGHT, JLO + 1, JLO + 1>(jlo, jhi, R, S, K, lane);
+	if (jlo == JLO && jhi == JHI) return dp_segment<NP, EXACT, RIGHT, JLO, JHI, false, WIN>(R, S, K, lane);
+	if constexpr (JHI + 1 < NP && JHI + 1 - JLO < DP_MAX_TIGHT) return dp_dispatch<NP, EXACT, RIGHT, JLO, JHI + 1, WIN>(jlo, jhi, R, S, K, lane);
+	else if constexpr (JLO + 1 < NP) return dp_dispatch<NP, EXACT, RIGHT, JLO + 1, JLO + 1, WIN>(jlo, jhi, R, S, K, lane);
 	else return true;   // not reached
 }
 
-template <int NP, bool EXACT, bool RIGHT>
+template <int NP, bool EXACT, bool RIGHT, bool WIN>
 __device__ __forceinline__ void dp_sweep(DpRun &R, DpSt &S, const DpK &K, const int lane)
 {
 	if (R.r_total <= 0) return;
 	if (!dp_bounds(R)) { R.ez.zdropped = 1; return; }
 	for (;;) {
-		const int jlo = R.st >> 7, jhi = R.en >> 7;
+		const int base = WIN? R.base : 0;
+		const int jlo = (R.st - base) >> 7, jhi = (R.en - base) >> 7;
 		bool done;
-		if (NP > DP_MAX_TIGHT && jhi - jlo >= DP_MAX_TIGHT) done = dp_segment<NP, EXACT, RIGHT, 0, NP - 1, true>(R, S, K, lane);
-		else done = dp_dispatch<NP, EXACT, RIGHT, 0, 0>(jlo, jhi, R, S, K, lane);
+		if constexpr (WIN) done = dp_segment<NP, EXACT, RIGHT, 0, NP - 1, true, true>(R, S, K, lane);
+		else if (NP > DP_MAX_TIGHT && jhi - jlo >= DP_MAX_TIGHT) done = dp_segment<NP, EXACT, RIGHT, 0, NP - 1, true, false>(R, S, K, lane);
+		else done = dp_dispatch<NP, EXACT, RIGHT, 0, 0, false>(jlo, jhi, R, S, K, lane);
 		if (done) break;
 	}
 }
 
-template <int NP, bool EXACT>
-__global__ __launch_bounds__(64) void k_ksw_reg(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
-                                                 const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr)
+template <int NP, bool EXACT, bool WIN>
+__device__ __forceinline__ void dp_reg_body(const DpConst &dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+                                            const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr)
 {
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_jobs) return;
@@ -357,7 +385,7 @@ __global__ __launch_bounds__(64) void k_ksw_reg(DpConst dc, const DpJobDev *jobs
 		return;
 	}
 	const uint8_t *target = tbase + jb.toff;
-	R.query = qbase + jb.qoff;
+	R.query = qbase + jb.qoff; R.target = target; R.base = 0;
 	R.q = dc.q; R.e = dc.e; R.q2 = dc.q2; R.e2 = dc.e2; R.qe = dc.qe_preswap; R.long_thres = dc.long_thres; R.long_diff = dc.long_diff;
 	const int qlen = R.qlen, tlen = R.tlen;
 	R.w = jb.w < 0? (tlen > qlen? tlen : qlen) : jb.w;
@@ -385,8 +413,8 @@ __global__ __launch_bounds__(64) void k_ksw_reg(DpConst dc, const DpJobDev *jobs
 		for (int i = lane; i < qlen; i += 64) n |= R.query[i] > 3;
 		R.any_n = __ballot(n) != 0;
 	}
-	if (R.flag & EZ_RIGHT) dp_sweep<NP, EXACT, true>(R, S, K, lane);
-	else dp_sweep<NP, EXACT, false>(R, S, K, lane);
+	if (R.flag & EZ_RIGHT) dp_sweep<NP, EXACT, true, WIN>(R, S, K, lane);
+	else dp_sweep<NP, EXACT, false, WIN>(R, S, K, lane);
 	if (lane == 0) {
 		const int flag = R.flag;
 		int i0 = -1, j0 = -1;
@@ -400,4 +428,20 @@ __global__ __launch_bounds__(64) void k_ksw_reg(DpConst dc, const DpJobDev *jobs
 		res[jid] = o;
 		if (R.cells) atomicAdd(cells_ctr, R.cells);
 	}
+}
+
+template <int NP, bool EXACT>
+__global__ __launch_bounds__(64) void k_ksw_reg(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+                                                 const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr)
+{
+	dp_reg_body<NP, EXACT, false>(dc, jobs, job_ids, n_jobs, qbase, tbase, pbase, res, cells_ctr);
+}
+
+// Targets of any length whose band is narrow (w <= DP_WIN_MAX_W: the extensions of a read's ends, w = 751 with the ONT preset): the same
+// sweep with the eight blocks as a WINDOW of 1024 target positions that follows the band (dp_rebase).  Exact score tracking only.
+#define DP_WIN_MAX_W 832                // live positions per anti-diagonal: st - 1 - base < 128, en + 16 (score spill) <= st + 15 + w + 31 -> < 1024
+__global__ __launch_bounds__(64) void k_ksw_regw(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+                                                  const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr)
+{
+	dp_reg_body<8, true, true>(dc, jobs, job_ids, n_jobs, qbase, tbase, pbase, res, cells_ctr);
 }

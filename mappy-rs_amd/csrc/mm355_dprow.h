@@ -77,6 +77,58 @@ __device__ __forceinline__ uint32_t row_scan(const uint32_t A, int32_t &C, const
 	return (uint32_t)((ex - sub) & 0xffff) | (uint32_t)(hi - sub) << 16;
 }
 
+// one register set (128 target cells) of one row: in: the row above (Hp, Fp, F2p), the cell to the left of the set's first cell in the row
+// above (hi half of carry_h), the prefix maxima of everything to the left in this row (C1, C2); out: this row's H / F / F2 in their place,
+// carries for the next set, the direction bytes of the two cells of this lane at pcell
+template <bool RIGHT>
+__device__ __forceinline__ void row_set(const RowK &K, const uint32_t dmis, const bool any_n, const uint32_t qc2, uint32_t &Hp, uint32_t &Fp, uint32_t &F2p,
+                                        const uint32_t TQ, const uint32_t KE1, const uint32_t KE2, uint32_t &carry_h, int32_t &C1, int32_t &C2, uint8_t *pcell, const bool store)
+{
+	// H(t-1, q-1): the row above, shifted one cell to the right
+	const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_h, (int)Hp, 0x138, 0xf, 0xf, false);
+	const uint32_t Hd = __builtin_amdgcn_alignbit(Hp, sh, 16);
+	carry_h = (uint32_t)__builtin_amdgcn_readlane((int)Hp, 63);
+	// substitution score
+	uint32_t s = pk_mad_vvs(pk_minu_s(TQ ^ qc2, K.one), dmis, K.mch);
+	if (any_n) s = pk_mad(pk_shr2(TQ | qc2), pk_rsub_s(K.N, s), s);   // either base ambiguous (code 4): sc_N
+	const uint32_t M = pk_add(Hd, s);
+	const uint32_t F = pk_max(pk_sub_s(Hp, K.qe1), pk_sub_s(Fp, K.e1));
+	const uint32_t F2 = pk_max(pk_sub_s(Hp, K.qe2), pk_sub_s(F2p, K.e2));
+	const uint32_t G = pk_max(pk_max(M, F), F2);
+	// E(t) = max_{k<t} (G(k) + k e) - (q + e) - (t - 1) e = [prefix - q] - t e
+	const uint32_t E = pk_sub(row_scan(pk_add(G, KE1), C1, K.q1i), KE1);
+	const uint32_t E2 = pk_sub(row_scan(pk_add(G, KE2), C2, K.q2i), KE2);
+	const uint32_t H = pk_max(pk_max(G, E), E2);
+	// direction byte
+	const uint32_t n1 = pk_minu_s(pk_sub(H, E), K.one), n2 = pk_minu_s(pk_sub(H, F), K.one), n3 = pk_minu_s(pk_sub(H, E2), K.one);
+	uint32_t d;
+	if (!RIGHT) {   // first maximum
+		const uint32_t n0 = pk_minu_s(pk_sub(H, M), K.one);
+		d = pk_mad_vss(n3, K.one);
+		d = pk_mad_vvs(n2, d, K.one);
+		d = pk_mad_vvs(n1, d, K.one);
+		d = pk_mul(n0, d);
+	} else {        // last maximum
+		const uint32_t n4 = pk_minu_s(pk_sub(H, F2), K.one);
+		d = pk_rsub_s(K.one, n1);
+		d = pk_mad_vvs(n2, pk_sub_s(d, K.two), K.two);
+		d = pk_mad_vvs(n3, pk_sub_s(d, K.three), K.three);
+		d = pk_mad_vvs(n4, pk_sub_s(d, K.four), K.four);
+	}
+	const uint32_t t1 = pk_sub_s(H, K.q1), t2 = pk_sub_s(H, K.q2);
+	uint32_t fa, fb, fa2, fb2;
+	if (!RIGHT) {   // > 0: the sign of the reversed difference (plain int16 halves: any positive value, not only multiples of 256)
+		fa = K.f8 & pk_sign16(pk_sub(t1, E)); fb = K.f16 & pk_sign16(pk_sub(t1, F));
+		fa2 = K.f32 & pk_sign16(pk_sub(t2, E2)); fb2 = K.f64 & pk_sign16(pk_sub(t2, F2));
+	} else {        // >= 0
+		fa = K.f8 & ~pk_sign16(pk_sub(E, t1)); fb = K.f16 & ~pk_sign16(pk_sub(F, t1));
+		fa2 = K.f32 & ~pk_sign16(pk_sub(E2, t2)); fb2 = K.f64 & ~pk_sign16(pk_sub(F2, t2));
+	}
+	d = d | fa | fb; d = d | fa2 | fb2;
+	if (store) *(uint16_t*)pcell = (uint16_t)__builtin_amdgcn_perm(0, d, 0x0c0c0200);
+	Hp = H; Fp = F; F2p = F2;
+}
+
 template <int NS, bool RIGHT>
 __device__ __forceinline__ void row_sweep(const DpConst &dc, const RowK &K, const DpJobDev &jb, const uint8_t *query, const uint8_t *target, uint8_t *p, const int tstride,
                                           const bool any_n, const int lane, int32_t &score_out)
@@ -105,49 +157,7 @@ __device__ __forceinline__ void row_sweep(const DpConst &dc, const RowK &K, cons
 #pragma unroll
 		for (int k = 0; k < NS; ++k) {
 			if (128 * k >= tlen) break;                // (wave-uniform) sets beyond the target
-			// H(t-1, q-1): the row above, shifted one cell to the right
-			const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_h, (int)Hp[k], 0x138, 0xf, 0xf, false);
-			const uint32_t Hd = __builtin_amdgcn_alignbit(Hp[k], sh, 16);
-			carry_h = (uint32_t)__builtin_amdgcn_readlane((int)Hp[k], 63);
-			// substitution score
-			uint32_t s = pk_mad_vvs(pk_minu_s(TQ[k] ^ qc2, K.one), dmis, K.mch);
-			if (any_n) s = pk_mad(pk_shr2(TQ[k] | qc2), pk_rsub_s(K.N, s), s);   // either base ambiguous (code 4): sc_N
-			const uint32_t M = pk_add(Hd, s);
-			const uint32_t F = pk_max(pk_sub_s(Hp[k], K.qe1), pk_sub_s(Fp[k], K.e1));
-			const uint32_t F2 = pk_max(pk_sub_s(Hp[k], K.qe2), pk_sub_s(F2p[k], K.e2));
-			const uint32_t G = pk_max(pk_max(M, F), F2);
-			// E(t) = max_{k<t} (G(k) + k e) - (q + e) - (t - 1) e = [prefix - q] - t e
-			const uint32_t E = pk_sub(row_scan(pk_add(G, KE1[k]), C1, K.q1i), KE1[k]);
-			const uint32_t E2 = pk_sub(row_scan(pk_add(G, KE2[k]), C2, K.q2i), KE2[k]);
-			const uint32_t H = pk_max(pk_max(G, E), E2);
-			// direction byte
-			const uint32_t n1 = pk_minu_s(pk_sub(H, E), K.one), n2 = pk_minu_s(pk_sub(H, F), K.one), n3 = pk_minu_s(pk_sub(H, E2), K.one);
-			uint32_t d;
-			if (!RIGHT) {   // first maximum
-				const uint32_t n0 = pk_minu_s(pk_sub(H, M), K.one);
-				d = pk_mad_vss(n3, K.one);
-				d = pk_mad_vvs(n2, d, K.one);
-				d = pk_mad_vvs(n1, d, K.one);
-				d = pk_mul(n0, d);
-			} else {        // last maximum
-				const uint32_t n4 = pk_minu_s(pk_sub(H, F2), K.one);
-				d = pk_rsub_s(K.one, n1);
-				d = pk_mad_vvs(n2, pk_sub_s(d, K.two), K.two);
-				d = pk_mad_vvs(n3, pk_sub_s(d, K.three), K.three);
-				d = pk_mad_vvs(n4, pk_sub_s(d, K.four), K.four);
-			}
-			const uint32_t t1 = pk_sub_s(H, K.q1), t2 = pk_sub_s(H, K.q2);
-			uint32_t fa, fb, fa2, fb2;
-			if (!RIGHT) {   // > 0: the sign of the reversed difference (plain int16 halves: any positive value, not only multiples of 256)
-				fa = K.f8 & pk_sign16(pk_sub(t1, E)); fb = K.f16 & pk_sign16(pk_sub(t1, F));
-				fa2 = K.f32 & pk_sign16(pk_sub(t2, E2)); fb2 = K.f64 & pk_sign16(pk_sub(t2, F2));
-			} else {        // >= 0
-				fa = K.f8 & ~pk_sign16(pk_sub(E, t1)); fb = K.f16 & ~pk_sign16(pk_sub(F, t1));
-				fa2 = K.f32 & ~pk_sign16(pk_sub(E2, t2)); fb2 = K.f64 & ~pk_sign16(pk_sub(F2, t2));
-			}
-			d = d | fa | fb; d = d | fa2 | fb2;
-			if (128 * k + 2 * lane < tlen) *(uint16_t*)(prow + 128 * k) = (uint16_t)__builtin_amdgcn_perm(0, d, 0x0c0c0200);
-			Hp[k] = H; Fp[k] = F; F2p[k] = F2;
+			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], carry_h, C1, C2, prow + 128 * k, 128 * k + 2 * lane < tlen);
 		}
 		prow += tstride;
 		hl_prev = hl;
@@ -185,6 +195,115 @@ __global__ __launch_bounds__(64) void k_ksw_row(DpConst dc, const DpJobDev *jobs
 	if (jb.flag & EZ_RIGHT) row_sweep<NS, true>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, score);
 	else row_sweep<NS, false>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, score);
 	if (lane == 0) {
+		mm355_dpres_t o;
+		o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = KSW_NEG_INF; o.score = score; o.reach_end = 0;
+		o.n_cigar = jb.tlen - 1; o.cigar_off = jb.qlen - 1;   // start cell for k_ksw_backtrack (not z-dropped, not KSW_EZ_EXTZ_ONLY)
+		res[jid] = o;
+		atomicAdd(cells_ctr, (unsigned long long)jb.qlen * (unsigned long long)jb.tlen);
+	}
+}
+
+// ------------------------------------------------------------------ long targets: eight waves, one 512-column panel each
+// The same row sweep for full-band approximate fills with targets of 1025..4096 bases (on GRCh38-scale ONT batches: the fills between
+// distant anchors, ~3000 x 3000, that used to be the latency tail of every extension round on the eight-wave anti-diagonal kernel).  Wave w
+// owns columns [512 w, 512 w + 512) and sweeps the rows like k_ksw_row<4>; what a row needs from the panels to its left is three numbers --
+// the two running prefix maxima (E, E2) at the panel edge and H of the panel's last column (for the diagonal of the next row) -- which
+// the left neighbour leaves in LDS (one slot per row, rewritten in place by every panel in turn: a panel reads row q before it writes it,
+// and its right neighbour reads it only after that).  Panels run 64 rows apart: `done[w]` = rows finished by wave w, published every 64
+// rows; wave w waits for done[w - 1] before it loads the next 64 slots.  No barrier after the first one, every wave ends after qlen rows.
+#define ROWL_NS 4
+#define ROWL_PANEL (128 * ROWL_NS)
+#define ROWL_WAVES 8
+#define ROWL_MAX_T (ROWL_PANEL * ROWL_WAVES)
+#define ROWL_MAX_Q 5120
+
+template <bool RIGHT>
+__device__ __forceinline__ void rowl_panel(const DpConst &dc, const RowK &K, const DpJobDev &jb, const uint8_t *query, const uint8_t *target, uint8_t *p, const int tstride,
+                                           const bool any_n, const int lane, const int pw, int32_t *colC1, int32_t *colC2, int32_t *colH, int *done, int32_t &score_out)
+{
+	const int qlen = jb.qlen, tlen = jb.tlen, tb = pw * ROWL_PANEL;
+	uint32_t Hp[ROWL_NS], Fp[ROWL_NS], F2p[ROWL_NS], TQ[ROWL_NS], KE1[ROWL_NS], KE2[ROWL_NS];
+#pragma unroll
+	for (int k = 0; k < ROWL_NS; ++k) {
+		const int t0 = tb + 128 * k + 2 * lane;
+		Hp[k] = pk2(row_hb(t0, dc), row_hb(t0 + 1, dc));
+		Fp[k] = F2p[k] = pk2(ROW_NEG, ROW_NEG);
+		TQ[k] = (t0 < tlen? (uint32_t)target[t0] : 0u) | (t0 + 1 < tlen? (uint32_t)target[t0 + 1] : 0u) << 16;
+		KE1[k] = pk2(t0 * dc.e, (t0 + 1) * dc.e);
+		KE2[k] = pk2(t0 * dc.e2, (t0 + 1) * dc.e2);
+	}
+	const uint32_t dmis = vreg_const(pk8w(dc.sc_mis - dc.sc_mch));
+	const bool last = tb + ROWL_PANEL >= tlen;         // nobody reads this panel's edge
+	int32_t hl_prev = row_hb(tb - 1, dc);              // H(tb - 1, q - 1): the boundary row above the first row
+	int32_t vC1 = 0, vC2 = 0, vH = 0;                  // lane l: the left neighbour's edge values of row (q & ~63) + l
+	uint32_t qv = 0;
+	uint8_t *prow = p + tb + 2 * lane;
+	for (int q = 0; q < qlen; ++q) {
+		if ((q & 63) == 0) {
+			qv = q + lane < qlen? query[q + lane] : 0;
+			if (pw > 0) {
+				const int need = q + 64 < qlen? q + 64 : qlen;
+				while (__hip_atomic_load(&done[pw - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+				if (q + lane < qlen) { vC1 = colC1[q + lane]; vC2 = colC2[q + lane]; vH = colH[q + lane]; }
+			}
+		}
+		const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
+		const uint32_t qc2 = qc | qc << 16;
+		int32_t C1, C2, hl_cur;
+		if (pw == 0) { hl_cur = row_hb(q, dc); C1 = hl_cur - dc.e; C2 = hl_cur - dc.e2; }      // the k = -1 term: a gap opened at the left border
+		else { C1 = __builtin_amdgcn_readlane(vC1, q & 63); C2 = __builtin_amdgcn_readlane(vC2, q & 63); hl_cur = __builtin_amdgcn_readlane(vH, q & 63); }
+		uint32_t carry_h = pk2(0, hl_prev);
+#pragma unroll
+		for (int k = 0; k < ROWL_NS; ++k) {
+			if (tb + 128 * k >= tlen) break;            // (wave-uniform) sets beyond the target
+			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], carry_h, C1, C2, prow + 128 * k, tb + 128 * k + 2 * lane < tlen);
+		}
+		if (!last) {
+			const int32_t he = (int32_t)__builtin_amdgcn_readlane((int)Hp[ROWL_NS - 1], 63) >> 16;     // H(tb + 511, q)
+			if (lane == 0) { colC1[q] = C1; colC2[q] = C2; colH[q] = he; }
+			if ((q & 63) == 63 || q == qlen - 1) __hip_atomic_store(&done[pw], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		prow += tstride;
+		hl_prev = hl_cur;
+	}
+	if (last) {
+		const int tl = tlen - 1 - tb;
+		uint32_t hv = 0;
+#pragma unroll
+		for (int k = 0; k < ROWL_NS; ++k) if ((tl >> 7) == k) hv = (uint32_t)__builtin_amdgcn_readlane((int)Hp[k], (tl >> 1) & 63);
+		score_out = (int32_t)(int16_t)(tl & 1? hv >> 16 : hv & 0xffff) + (dc.q + dc.e) - dc.qe_preswap;
+	}
+}
+
+__global__ __launch_bounds__(64 * ROWL_WAVES) void k_ksw_rowl(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+                                                              const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr)
+{
+	__shared__ int32_t colC1[ROWL_MAX_Q], colC2[ROWL_MAX_Q], colH[ROWL_MAX_Q];
+	__shared__ int done[ROWL_WAVES], s_n;
+	const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
+	if ((int)blockIdx.x >= n_jobs) return;
+	const int jid = job_ids[blockIdx.x];
+	const DpJobDev jb = jobs[jid];
+	const uint8_t *target = tbase + jb.toff, *query = qbase + jb.qoff;
+	if (threadIdx.x < ROWL_WAVES) done[threadIdx.x] = 0;
+	if (threadIdx.x == 0) s_n = 0;
+	__syncthreads();
+	bool n = false;
+	for (int i = threadIdx.x; i < jb.tlen; i += 64 * ROWL_WAVES) n |= target[i] > 3;
+	for (int i = threadIdx.x; i < jb.qlen; i += 64 * ROWL_WAVES) n |= query[i] > 3;
+	if (n) s_n = 1;
+	__syncthreads();                                   // the only barriers: every wave is still here
+	const bool any_n = s_n != 0;
+	if (pw * ROWL_PANEL >= jb.tlen) return;            // no panel for this wave
+	RowK K;
+	K.qe1 = pk8w(dc.q + dc.e); K.e1 = pk8w(dc.e); K.qe2 = pk8w(dc.q2 + dc.e2); K.e2 = pk8w(dc.e2); K.q1 = pk8w(dc.q); K.q2 = pk8w(dc.q2);
+	K.mch = pk8w(dc.sc_mch); K.N = pk8w(dc.sc_N); K.one = 0x00010001u; K.two = 0x00020002u; K.three = 0x00030003u; K.four = 0x00040004u;
+	K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u; K.q1i = dc.q; K.q2i = dc.q2;
+	const int tstride = (jb.tlen + 15) / 16 * 16 + 16;
+	int32_t score = KSW_NEG_INF;
+	if (jb.flag & EZ_RIGHT) rowl_panel<true>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, pw, colC1, colC2, colH, done, score);
+	else rowl_panel<false>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, pw, colC1, colC2, colH, done, score);
+	if (lane == 0 && (pw + 1) * ROWL_PANEL >= jb.tlen) {   // the wave of the last panel
 		mm355_dpres_t o;
 		o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = KSW_NEG_INF; o.score = score; o.reach_end = 0;
 		o.n_cigar = jb.tlen - 1; o.cigar_off = jb.qlen - 1;   // start cell for k_ksw_backtrack (not z-dropped, not KSW_EZ_EXTZ_ONLY)

@@ -977,32 +977,7 @@ __device__ inline void chain_dist(const DevParams &pr, int qlen, int32_t &max_di
 	if (max_dist_y < pr.bw) max_dist_y = pr.bw;
 }
 
-// One 256-thread block per read sweeps the anchors in tiles of 256: a lane flags "segment start" for its anchor (O(1): only the left
-// neighbour is looked at), the block's four ballots form the tile's start mask, and every start finds the next start with bit scans on
-// that mask -- no lane ever walks a segment.  A segment that is still open at the end of a tile is carried to the next tile as a
-// block-uniform (open_i0) and closed by the first start found there (or by the end of the read).
-// Segments are appended to the two lists with ONE atomic per wave and list (ballot + prefix inside the wave): millions of single-address
-// atomics would otherwise be the kernel (one word takes ~88 atomics per microsecond), and the lists stay in anchor order inside a
-// wave's batch, so neighbouring lanes of k_chain_small read neighbouring anchors.
 struct ChainSeg { int32_t read, i0, len, pad; };
-__device__ __forceinline__ void chain_seg_emit(bool have, DevAnchors &an, const mm128 *a, int64_t o, int r, int i0, int len, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
-{
-	const int lane = threadIdx.x & 63;
-	if (have && len == 1) {
-		const int32_t sp = (int32_t)(a[i0].y >> 32 & 0xff);
-		an.f[o + i0] = sp; an.p[o + i0] = -1; an.v[o + i0] = sp;
-	}
-	const bool to_small = have && len > 1 && len <= small_max, to_big = have && len > small_max;
-	const unsigned long long ms = __ballot(to_small), mb = __ballot(to_big);
-	unsigned int base_s = 0, base_b = 0;
-	if (ms) { if (lane == (int)__builtin_ctzll(ms)) base_s = atomicAdd(&ctr[0], (unsigned int)__popcll(ms)); base_s = __shfl(base_s, (int)__builtin_ctzll(ms)); }
-	if (mb) { if (lane == (int)__builtin_ctzll(mb)) base_b = atomicAdd(&ctr[1], (unsigned int)__popcll(mb)); base_b = __shfl(base_b, (int)__builtin_ctzll(mb)); }
-	if (to_small || to_big) {
-		ChainSeg sg; sg.read = r; sg.i0 = i0; sg.len = len; sg.pad = 0;
-		if (to_small) small[base_s + __popcll(ms & LANE_LT_MASK(lane))] = sg;
-		else big[base_b + __popcll(mb & LANE_LT_MASK(lane))] = sg;
-	}
-}
 
 // One 256-thread block per CHUNK of SEG_CHUNK anchors of a read (chunk table from the host, which knows the anchor counts); a wave takes
 // the chunk's 64-anchor strips one after the other.  A lane flags "segment start" for its anchor (only the left neighbour is looked at);
@@ -1011,6 +986,12 @@ __device__ __forceinline__ void chain_seg_emit(bool have, DevAnchors &an, const 
 #define SEG_CHUNK 4096
 __global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch bt, DevAnchors an, const int2 *chunks, int n_chunks, ChainSeg *small, ChainSeg *big, unsigned int *ctr, int small_max)
 {
+	// The two lists are appended to with ONE atomic per block and list: with ~100 M anchors per batch (GRCh38-scale ONT reads) one atomic
+	// per 64-anchor strip was still 1.6 M strips x 2 on two words -- at ~88 atomics/us per address that WAS the kernel (17 ms of 17.5).
+	// Pass 1 leaves every start's segment length in LDS and the strip's two counts; wave 0 turns the counts into offsets (one scan, one
+	// atomic per list); pass 2 writes the segments, in anchor order over the whole chunk.
+	__shared__ int32_t s_len[SEG_CHUNK];
+	__shared__ uint32_t s_ns[SEG_CHUNK / 64], s_nb[SEG_CHUNK / 64];
 	if ((int)blockIdx.x >= n_chunks) return;
 	const int2 ck = chunks[blockIdx.x];
 	const int r = ck.x, c0 = ck.y;
@@ -1021,6 +1002,8 @@ __global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch b
 	chain_dist(pr, bt.rlen[r], mdx, mdy);
 	const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 	const int c1 = c0 + SEG_CHUNK < n? c0 + SEG_CHUNK : n;
+	if (threadIdx.x < SEG_CHUNK / 64) s_ns[threadIdx.x] = s_nb[threadIdx.x] = 0;
+	__syncthreads();
 	for (int base = c0 + wv * 64; base < c1; base += 256) {
 		const int i = base + lane;
 		uint64_t xi = 0;
@@ -1029,6 +1012,7 @@ __global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch b
 		if (lane == 0 && base > 0) xp = a[base - 1].x;
 		const bool start = i < n && (i == 0 || (xi >> 32 != xp >> 32) || xi > xp + (uint64_t)(int64_t)mdx);
 		const unsigned long long m = __ballot(start);
+		s_len[i - c0] = 0;
 		if (m == 0) continue;                                  // (wave-uniform)
 		int end = -1;
 		if (start) { const unsigned long long rest = lane == 63? 0ULL : (m >> (lane + 1)) << (lane + 1); if (rest) end = base + __builtin_ctzll(rest); }
@@ -1053,7 +1037,39 @@ __global__ __launch_bounds__(256) void k_chain_segments(DevParams pr, DevBatch b
 			}
 		}
 		if (lane == last) end = fend;
-		chain_seg_emit(start, an, a, o, r, i, end - i, small, big, ctr, small_max);
+		const int len = end - i;
+		if (start) {
+			s_len[i - c0] = len;
+			if (len == 1) {   // finished on the spot
+				const int32_t sp = (int32_t)(a[i].y >> 32 & 0xff);
+				an.f[o + i] = sp; an.p[o + i] = -1; an.v[o + i] = sp;
+			}
+		}
+		const unsigned long long ms = __ballot(start && len > 1 && len <= small_max), mb = __ballot(start && len > small_max);
+		if (lane == 0) { s_ns[(base - c0) >> 6] = (uint32_t)__popcll(ms); s_nb[(base - c0) >> 6] = (uint32_t)__popcll(mb); }
+	}
+	__syncthreads();
+	if (wv == 0) {   // strip counts -> list offsets
+		const uint32_t cs = s_ns[lane], cb = s_nb[lane];
+		uint32_t is = cs, ib = cb;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const uint32_t us = __shfl_up(is, d), ub = __shfl_up(ib, d); if (lane >= d) { is += us; ib += ub; } }
+		uint32_t bs = 0, bb = 0;
+		if (lane == 63) { if (is) bs = atomicAdd(&ctr[0], is); if (ib) bb = atomicAdd(&ctr[1], ib); }
+		bs = __shfl(bs, 63); bb = __shfl(bb, 63);
+		s_ns[lane] = bs + is - cs; s_nb[lane] = bb + ib - cb;
+	}
+	__syncthreads();
+	for (int base = c0 + wv * 64; base < c1; base += 256) {
+		const int i = base + lane;
+		const int len = s_len[i - c0];
+		const bool to_small = len > 1 && len <= small_max, to_big = len > small_max;
+		const unsigned long long ms = __ballot(to_small), mb = __ballot(to_big);
+		if (to_small || to_big) {
+			ChainSeg sg; sg.read = r; sg.i0 = i; sg.len = len; sg.pad = 0;
+			if (to_small) small[s_ns[(base - c0) >> 6] + __popcll(ms & LANE_LT_MASK(lane))] = sg;
+			else big[s_nb[(base - c0) >> 6] + __popcll(mb & LANE_LT_MASK(lane))] = sg;
+		}
 	}
 }
 

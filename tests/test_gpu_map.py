@@ -314,6 +314,64 @@ def test_dp_kernel_parity(ont):
             q = S.random_codes(rng, 1)
         flag = APPROX | (RIGHT if i % 2 else 0) | (REV if i % 4 == 1 else 0)
         jobs.append((len(q), tl, len(q) + tl + int(rng.integers(0, 50)), 400, -1, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
+    # the same with targets of 1025..4096 bases: the eight-wave row sweep k_ksw_rowl (one 512-column panel per wave, 64-row batches):
+    # every panel border, one to eight panels, queries shorter than / equal to / just over one batch and up to the LDS limit of 5120 rows
+    n_short = len(jobs)
+    for i in range(44):
+        tl = int([1025, 1536, 1537, 2047, 2048, 2049, 2560, 2561, 3000, 3583, 3584, 3585, 4000, 4095, 4096][i % 15]) if i < 30 else int(rng.integers(1025, 4097))
+        t = S.random_codes(rng, tl)
+        q = S.mutate(t, rng, 0.06, 0.03, 0.03)
+        if i % 5 == 0:
+            cut = int(rng.integers(5, len(q) - 600)); q = np.concatenate([q[:cut], q[cut + int(rng.integers(1, 500)):]])        # deletion
+        if i % 5 == 3:
+            cut = int(rng.integers(0, len(q) + 1)); q = np.concatenate([q[:cut], S.random_codes(rng, int(rng.integers(1, 700))), q[cut:]])   # insertion
+        if i % 8 == 1:
+            q = q[:int([1, 63, 64, 65, 128, 700][(i // 8) % 6])]               # a few rows only
+        if i % 8 == 6:
+            q = S.random_codes(rng, int(rng.integers(1, 5121)))                # unrelated query, any length ratio
+        if i % 6 == 0:
+            q[len(q) // 2:len(q) // 2 + 3] = 4
+        if i % 7 == 0:
+            t[tl // 3:tl // 3 + 2] = 4
+        flag = APPROX | (RIGHT if i % 2 else 0) | (REV if i % 4 == 1 else 0)
+        jobs.append((len(q), tl, len(q) + tl + int(rng.integers(0, 50)), 400, -1, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
+    # exact sweeps with a narrow band over long targets: k_ksw_regw, the register kernel whose 1024-position window follows the band
+    # (extensions of read ends: w = 751; the widest band it takes, 832; narrow ones; band-limited global fills; z-drop half way; queries
+    # much shorter / longer than the target, so that the band leaves the matrix early; ambiguous bases across a window move)
+    n_rowl = len(jobs)
+    for i in range(40):
+        tl = int([1025, 1100, 1151, 1152, 1153, 2000, 2047, 2048, 3000, 5000, 7000, 9000][i % 12]) if i < 24 else int(rng.integers(1025, 6000))
+        t = S.random_codes(rng, tl)
+        q = S.mutate(t, rng, 0.05, 0.03, 0.03)
+        if i % 6 == 1:
+            cut = int(rng.integers(400, len(q) - 400)); q = np.concatenate([q[:cut], q[cut + int(rng.integers(20, 300)):]])        # deletion: the path moves off the main diagonal
+        if i % 6 == 4:
+            cut = int(rng.integers(400, len(q) - 400)); q = np.concatenate([q[:cut], S.random_codes(rng, int(rng.integers(20, 300))), q[cut:]])
+        if i % 7 == 2:
+            q = np.concatenate([q[:len(q) * 2 // 3], S.random_codes(rng, 900)])      # z-drop after two thirds
+        if i % 9 == 3:
+            q = q[:int(rng.integers(1, 900))]                                      # short query: band limited by the query
+        if i % 9 == 5:
+            q = np.concatenate([q, S.random_codes(rng, 1500)])                     # query runs past the target
+        if i % 5 == 0:
+            q[len(q) // 2:len(q) // 2 + 3] = 4; t[tl // 2 + 100:tl // 2 + 102] = 4
+        flag, w, zd = [(EXTZ, 751, 400), (EXTZ | RIGHT | REV, 751, 200), (0, 832, 400), (RIGHT, 300, 400), (EXTZ, 16, 100), (0, 751, 10000)][i % 6]
+        jobs.append((len(q), tl, w, zd, -1 if i % 4 else 10, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
+    # paths along the matrix border and along the band edge while the band spans five or more 128-cell blocks (the catch-all instance
+    # of the register kernels): a global alignment that opens with a 560-base deletion runs through the top-row cells t = r >= 512, whose
+    # y / u are boundary values; one that opens with a (w - 1)-base insertion rides the lower band edge, where x[st - 1] / v[st - 1] are
+    # defaults whenever st did not move
+    for i in range(24):
+        tl = int([1020, 1000, 900, 3000, 2500, 5000][i % 6])
+        t = S.random_codes(rng, tl)
+        m = S.mutate(t, rng, 0.03, 0.01, 0.01)
+        w = 751
+        if i % 4 == 0: q = m[int([560, 600, 700, 520][(i // 4) % 4]):]
+        elif i % 4 == 1: q = np.concatenate([S.random_codes(rng, w - 1 - (i // 4) % 3), m])
+        elif i % 4 == 2: q = np.concatenate([m[:len(m) // 2], S.random_codes(rng, 700), m[len(m) // 2:]])   # the same in the middle of the matrix
+        else: q = np.concatenate([m[:len(m) // 3], m[len(m) // 3 + 650:]])
+        flag = [0, RIGHT, EXTZ, EXTZ | RIGHT | REV][(i // 2) % 4]
+        jobs.append((len(q), tl, w, 100000, -1, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
     qcat = np.concatenate(qs); tcat = np.concatenate(ts)
     ja = (_ffi.DpJob * len(jobs))()
     qo = to = 0
@@ -325,6 +383,9 @@ def test_dp_kernel_parity(ont):
     cig = np.zeros(cap, np.uint32)
     sr = al._stage_runner()
     _ffi.check(L.mm355_stage_dp(sr.ctx, C.byref(al._mo), len(jobs), ja, qcat.ctypes.data, qcat.size, tcat.ctypes.data, tcat.size, res, cig.ctypes.data, cap))
+    st = sr.stats()
+    assert st.n_launch_group[17] == 1 and st.dp_cells_group[17] >= sum(j[0] * j[1] for j in jobs[n_short:n_rowl]), "long full-band fills must run on k_ksw_rowl"
+    assert st.n_launch_group[18] == 1 and st.dp_cells_group[18] > 0, "long narrow-band exact sweeps must run on k_ksw_regw"
     mat = np.zeros(25, np.int8)
     mo = al._mo
     OL.mmo_ksw_gen_simple_mat(5, mat.ctypes.data, mo.a, mo.b, mo.sc_ambi)
@@ -365,6 +426,9 @@ def test_dp_row_kernel_with_reordered_gap_costs(ont):
             if i % 9 == 0 and len(x) > 6: x[len(x) // 2:len(x) // 2 + 2] = 4
             if len(x) == 0: x = S.random_codes(rng, 1)
             qs.append(x.astype(np.uint8)); ts.append(t.astype(np.uint8)); jobs.append((len(x), tl, len(x) + tl + 1, 8 | (2 if i % 2 else 0)))
+        for i, tl in enumerate((1300, 2100, 4090)):   # long targets: k_ksw_rowl where its int16 range allows (checked per problem on the host)
+            t = S.random_codes(rng, tl); x = S.mutate(t, rng, 0.06, 0.03, 0.03)
+            qs.append(x.astype(np.uint8)); ts.append(t.astype(np.uint8)); jobs.append((len(x), tl, len(x) + tl + 1, 8 | (2 if i % 2 else 0)))
         qcat = np.concatenate(qs); tcat = np.concatenate(ts)
         ja = (_ffi.DpJob * len(jobs))()
         qo = to = 0
@@ -376,6 +440,18 @@ def test_dp_row_kernel_with_reordered_gap_costs(ont):
         _ffi.check(L.mm355_stage_dp(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, tcat.ctypes.data, tcat.size, res, cig.ctypes.data, cap))
         groups = list(sr.stats().n_launch_group)
         assert (groups[14] + groups[15] + groups[16] > 0) == expect_row, (groups, (q, e, q2, e2))
+        # k_ksw_rowl takes a long problem only where its int16 range allows (mm355_dp.hip::rowl_range_ok, restated here): with
+        # (4, 6, 1, 10, 1, 3, 4) -- match 4, e = 4 after ksw2's ordering -- 4096 columns do not fit, nor with the single piece (5, 2)
+        def range_ok(ql, tl):
+            qq, ee, qq2, ee2 = (q, e, q2, e2) if q + e <= q2 + e2 else (q2, e2, q, e)
+            tlr = (tl + 127) & ~127
+            cost = lambda k: min(qq + k * ee, qq2 + k * ee2)
+            emax, hi = max(ee, ee2), a * min(ql, tlr)
+            lo = cost(ql + 1) + cost(tlr + 1) + max(qq + ee, qq2 + ee2, b, amb) + emax + 64
+            return hi + emax * (tlr + 1) <= 32000 and lo <= 16384 - 64 and hi + lo <= 32000
+        cells17 = sr.stats().dp_cells_group[17]
+        want17 = sum(j[0] * j[1] for j in jobs[-3:] if range_ok(j[0], j[1])) if expect_row else 0
+        assert cells17 == want17 and (not expect_row or 0 < want17 < sum(j[0] * j[1] for j in jobs[-3:])), (cells17, want17, (q, e, q2, e2))
         mat = np.zeros(25, np.int8); OL.mmo_ksw_gen_simple_mat(5, mat.ctypes.data, a, b, amb)
         for i, (ql, tl, w, fl) in enumerate(jobs):
             ez = O.Extz()
