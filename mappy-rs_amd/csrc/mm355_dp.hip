@@ -64,6 +64,9 @@ __device__ inline int8_t SB(uint64_t w, int i) { return (int8_t)(w >> (8 * i)); 
 // NT = threads per alignment: 64 (one wave; x[t-1]/v[t-1] by a lane shuffle) for the short problems, 512 (eight waves share
 // one anti-diagonal; neighbours are re-read from LDS between two barriers) for long ones, whose single-wave sweep would
 // otherwise be the tail of the whole launch.
+// per-launch-group cell counters are spread over DP_CTR_SPREAD words (slot = block & 15): every alignment adds once, and a single word
+// takes only ~88 atomics per microsecond -- 150 000 alignments of one launch on one word were 1.7 ms of atomics
+#define DP_CTR_SPREAD 16
 template <int NT>
 __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
                                                     const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, int32_t *offbase,
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jo
 		res[jid] = o;
 		// cells_ctr: one counter per launch group, or (cls_base >= 0: the merged launch of every long-target class) the base of the
 		// per-group counters, indexed by the job's own size class
-		if (cells) atomicAdd(cls_base >= 0? cells_ctr + 2 * (cls_base + (T > 4096) + (T > 12288)) + (approx_max? 0 : 1) : cells_ctr, cells);
+		if (cells) atomicAdd((cls_base >= 0? cells_ctr + DP_CTR_SPREAD * (2 * (cls_base + (T > 4096) + (T > 12288)) + (approx_max? 0 : 1)) : cells_ctr) + (blockIdx.x & (DP_CTR_SPREAD - 1)), cells);
 	}
 }
 
@@ -367,7 +370,19 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 		if (run_len) cigar[n_cigar++] = run_len << 4 | run_op;
 #undef BT_PUSH
 	}
-	const long long dst = (long long)atomicAdd(dense_ctr, (unsigned long long)n_cigar);   // dense arena: only real ops travel to the host
+	// dense arena (only real ops travel to the host): one atomic per wave -- the lanes' counts are prefix-summed first (the lanes that left
+	// above are the top ones of the last wave, never read by a lower lane)
+	long long dst;
+	{
+		const int lane = threadIdx.x & 63;
+		unsigned int inc = (unsigned int)n_cigar;
+		for (int d = 1; d < 64; d <<= 1) { const unsigned int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+		const int last = 63 - __builtin_clzll(__ballot(1));
+		unsigned long long base = 0;
+		if (lane == last) base = atomicAdd(dense_ctr, (unsigned long long)inc);
+		base = __shfl(base, last);
+		dst = (long long)(base + inc - (unsigned int)n_cigar);
+	}
 	if (jb.flag & EZ_REV_CIGAR) for (int k = 0; k < n_cigar; ++k) dense[dst + k] = cigar[k];
 	else for (int k = 0; k < n_cigar; ++k) dense[dst + k] = cigar[n_cigar - 1 - k];
 	o.n_cigar = n_cigar; o.cigar_off = dst;
@@ -571,9 +586,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4, *d_dense = c->counters.as<unsigned long long>() + 5;
 	double t_turn0 = 0;
 	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
-	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + 8;   // cells per group [24]
+	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + 64;   // cells per group [24][DP_CTR_SPREAD]
 	HIPCHK(hipMemsetAsync(d_cells, 0, 8, c->st));
-	HIPCHK(hipMemsetAsync(d_gcells, 0, 192, c->st));
+	HIPCHK(hipMemsetAsync(d_gcells, 0, 192 * DP_CTR_SPREAD, c->st));
 	// every group gets its own HIP stream: the few long alignments of the big classes run concurrently with the thousands of
 	// short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
 	HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
@@ -640,7 +655,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		if ((rc2 = group_stream(7, &gst))) return rc2;
 		if ((rc2 = group_begin(DP_G_REGW, gst))) return rc2;
 		hipLaunchKernelGGL(k_ksw_regw, dim3((unsigned)n_grp[DP_G_REGW]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
-		                   c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_G_REGW);
+		                   c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * DP_G_REGW);
 		if ((rc2 = group_end(DP_G_REGW, gst, false))) return rc2;
 	}
 	if (n_grp[DP_G_ROWL]) {   // the eight-wave row sweep of the long full-band fills: a few hundred blocks at most, outside the turn as well
@@ -648,7 +663,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		if ((rc2 = group_stream(6, &gst))) return rc2;
 		if ((rc2 = group_begin(DP_G_ROWL, gst))) return rc2;
 		hipLaunchKernelGGL(k_ksw_rowl, dim3((unsigned)n_grp[DP_G_ROWL]), dim3(64 * ROWL_WAVES), 0, gst, dc, dj, d_ids + grp_off[DP_G_ROWL], (int)n_grp[DP_G_ROWL], d_q, d_t,
-		                   c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_G_ROWL);
+		                   c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * DP_G_ROWL);
 		if ((rc2 = group_end(DP_G_ROWL, gst, false))) return rc2;
 	}
 	// (the launches above -- the long-target kernels -- are not part of the turn: a few dozen latency-bound alignments that leave the GPU
@@ -665,9 +680,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 				hipStream_t gst; int rc2;
 				if ((rc2 = group_stream(g == DP_G_ROW2? 0 : g == DP_G_ROW4? 3 : 2, &gst))) return rc2;
 				if ((rc2 = group_begin(g, gst))) return rc2;
-				if (g == DP_G_ROW2) hipLaunchKernelGGL(k_ksw_row<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
-				else if (g == DP_G_ROW4) hipLaunchKernelGGL(k_ksw_row<4>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
-				else hipLaunchKernelGGL(k_ksw_row<8>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + g);
+				if (g == DP_G_ROW2) hipLaunchKernelGGL(k_ksw_row<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g);
+				else if (g == DP_G_ROW4) hipLaunchKernelGGL(k_ksw_row<4>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g);
+				else hipLaunchKernelGGL(k_ksw_row<8>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g);
 				if ((rc2 = group_end(g, gst, true))) return rc2;
 				continue;
 			}
@@ -677,7 +692,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			hipStream_t gst; int rc2;
 			if ((rc2 = group_stream(sidx, &gst))) return rc2;
 			if ((rc2 = group_begin(g, gst))) return rc2;
-			unsigned long long *gc = d_gcells + g;
+			unsigned long long *gc = d_gcells + DP_CTR_SPREAD * g;
 			const unsigned nj = (unsigned)n_grp[g];
 			const int32_t *gid = d_ids + grp_off[g];
 			if (k.kind == 0) {
@@ -709,10 +724,10 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
 	}
 	HIPCHK(hipGetLastError());
-	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 256)) return MM355_ENOMEM;
+	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 64 + 192 * DP_CTR_SPREAD)) return MM355_ENOMEM;
 	unsigned long long *ctr = (unsigned long long*)((char*)c->h_res.p + n * sizeof(mm355_dpres_t));   // pinned landing zone of the counters
 	HIPCHK(hipMemcpyAsync(ctr, d_cells, 16, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, 192, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, 192 * DP_CTR_SPREAD, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
 	if (const char *dump = getenv("MM355_DP_DUMP_BT")) {   // diagnostics: the direction matrices of this launch group, raw
@@ -732,8 +747,10 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			float ms = 0.f;
 			if (timed_here && hipEventElapsedTime(&ms, c->dp_ev0[g], c->dp_ev1[g]) == hipSuccess) c->stats.ms_dp_group[g] += ms;
 			if (n_grp[g] == 0) continue;
-			c->stats.dp_cells_group[g] += (int64_t)ctr[2 + g]; ++c->stats.n_launch_group[g];
-			tot += (int64_t)ctr[2 + g];
+			int64_t gc = 0;
+			for (int k = 0; k < DP_CTR_SPREAD; ++k) gc += (int64_t)ctr[2 + DP_CTR_SPREAD * g + k];
+			c->stats.dp_cells_group[g] += gc; ++c->stats.n_launch_group[g];
+			tot += gc;
 		}
 		c->stats.dp_cells += tot; c->stats.n_dp_jobs += (int64_t)n; ++c->stats.n_launch_dp;
 	}

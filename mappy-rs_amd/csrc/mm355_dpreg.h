@@ -185,6 +185,30 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 	if (act) *(uint16_t*)(p + g.prow + tl) = (uint16_t)(__builtin_amdgcn_perm(0, d, 0x0c0c0200));
 }
 
+// lane 63 <- maximum over the wave (inclusive scan by row shifts and row broadcasts; the other lanes hold prefix maxima)
+__device__ __forceinline__ int32_t dp_wave_max_i32(int32_t x)
+{
+	int32_t y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x111, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x112, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x114, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x118, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x142, 0xa, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x143, 0xc, 0xf, false); x = x > y? x : y;
+	return x;
+}
+__device__ __forceinline__ uint32_t dp_wave_max_u32(uint32_t x)
+{
+	uint32_t y;
+	y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); x = x > y? x : y;
+	y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); x = x > y? x : y;
+	y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); x = x > y? x : y;
+	y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); x = x > y? x : y;
+	y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); x = x > y? x : y;
+	y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); x = x > y? x : y;
+	return x;
+}
+
 // exact score tracking of one block: H[t] += v[t] on [st0, en0), H[en0] = hen, best (H, priority) candidate of the lane
 template <int J>
 __device__ __forceinline__ void dp_block_h(const int lane, const int st0, const int en0, const int en1, const int32_t hen, const uint32_t V, int32_t &Hl, int32_t &Hh, long long &best)
@@ -254,10 +278,14 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 			long long best = INT64_MIN;
 #define DP_STEP_H(k) if constexpr (DP_IN(k)) dp_block_h<k>(lane, st0_r, en0_r, en1_r, hen, S.V##k, S.Hl##k, S.Hh##k, best);
 			DP_STEP_H(0) DP_STEP_H(1) DP_STEP_H(2) DP_STEP_H(3) DP_STEP_H(4) DP_STEP_H(5) DP_STEP_H(6) DP_STEP_H(7)
-#pragma unroll
-			for (int o = 1; o < 64; o <<= 1) {
-				const long long other = __shfl_xor(best, o);
-				best = other > best? other : best;
+			// wave maximum of the 64-bit keys in two 32-bit DPP reductions (H first, then the priority word among the lanes that hold that H):
+			// six row-shift / row-broadcast steps each, instead of six dependent 64-bit ds_bpermute exchanges (~1000 cycles per anti-diagonal)
+			{
+				const int32_t bh = (int32_t)(best >> 32);
+				const int32_t mh = (int32_t)rdlane((uint32_t)dp_wave_max_i32(bh), 63);
+				const uint32_t bl = bh == mh? (uint32_t)best : 0u;
+				const uint32_t ml = rdlane(dp_wave_max_u32(bl), 63);
+				best = (long long)(((unsigned long long)(uint32_t)mh << 32) | ml);
 			}
 			max_H = hen; max_t = en0;
 			if (best != INT64_MIN) {
@@ -426,7 +454,7 @@ __device__ __forceinline__ void dp_reg_body(const DpConst &dc, const DpJobDev *j
 		o.mte = ez.mte; o.mte_q = ez.mte_q; o.score = ez.score; o.reach_end = ez.reach_end;
 		o.n_cigar = i0; o.cigar_off = j0;   // start cell for k_ksw_backtrack
 		res[jid] = o;
-		if (R.cells) atomicAdd(cells_ctr, R.cells);
+		if (R.cells) atomicAdd(cells_ctr + (blockIdx.x & (DP_CTR_SPREAD - 1)), R.cells);
 	}
 }
 

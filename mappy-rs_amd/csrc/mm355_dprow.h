@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64) void k_ksw_row(DpConst dc, const DpJobDev *jobs
 		o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = KSW_NEG_INF; o.score = score; o.reach_end = 0;
 		o.n_cigar = jb.tlen - 1; o.cigar_off = jb.qlen - 1;   // start cell for k_ksw_backtrack (not z-dropped, not KSW_EZ_EXTZ_ONLY)
 		res[jid] = o;
-		atomicAdd(cells_ctr, (unsigned long long)jb.qlen * (unsigned long long)jb.tlen);
+		atomicAdd(cells_ctr + (blockIdx.x & (DP_CTR_SPREAD - 1)), (unsigned long long)jb.qlen * (unsigned long long)jb.tlen);
 	}
 }
 
@@ -308,6 +308,6 @@ __global__ __launch_bounds__(64 * ROWL_WAVES) void k_ksw_rowl(DpConst dc, const 
 		o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = KSW_NEG_INF; o.score = score; o.reach_end = 0;
 		o.n_cigar = jb.tlen - 1; o.cigar_off = jb.qlen - 1;   // start cell for k_ksw_backtrack (not z-dropped, not KSW_EZ_EXTZ_ONLY)
 		res[jid] = o;
-		atomicAdd(cells_ctr, (unsigned long long)jb.qlen * (unsigned long long)jb.tlen);
+		atomicAdd(cells_ctr + (blockIdx.x & (DP_CTR_SPREAD - 1)), (unsigned long long)jb.qlen * (unsigned long long)jb.tlen);
 	}
 }

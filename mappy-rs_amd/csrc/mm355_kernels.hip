@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_chain_small(DevParams pr, DevBatch bt, 
 		}
 	}
 	for (int o2 = 32; o2 > 0; o2 >>= 1) pairs += __shfl_down(pairs, o2);
-	if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(pairs_ctr, pairs);
+	if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(pairs_ctr + (blockIdx.x & 63), pairs);
 }
 
 // one wave per long segment
@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 	}
 #undef CH_SYNC
 	KPROF(12);
-	if (lane == 0 && pairs) atomicAdd(pairs_ctr, pairs);
+	if (lane == 0 && pairs) atomicAdd(pairs_ctr + (blockIdx.x & 63), pairs);
 }
 
 // ------------------------------------------------------------------ a8: mg_chain_backtrack + compact_a

@@ -276,7 +276,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	c->n_arena = 0;
 	c->stats.n_reads = n_reads; c->stats.n_bases = c->hb.n_bases;
-	HIPCHK(hipMemsetAsync(c->counters.p, 0, 256, c->st));
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, 4096, c->st));
 	HIPCHK(hipMemsetAsync(c->err.p, 0, 16, c->st));
 	const std::vector<int32_t> &status = c->hb.status;
 	std::vector<int32_t> dl(c->hb.rlen);

@@ -105,7 +105,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	c->dix.pos = (const uint64_t*)rp.pos; c->dix.S = (const uint32_t*)rp.S;
 	c->dix.seq_off = (const uint64_t*)rp.seq_off; c->dix.seq_len = (const uint32_t*)rp.seq_len;
 	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
-	if (c->counters.ensure(256) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
+	if (c->counters.ensure(4096) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
 	if (getenv("MM355_KPROF")) { if (c->kprof.ensure(512)) { delete c; return MM355_ENOMEM; } HIPCHK(hipMemset(c->kprof.p, 0, 512)); }
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	*out = c;
@@ -270,7 +270,7 @@ int mm355_run_pack(mm355_ctx *c, int64_t n_reads, const char *const *seqs, const
 		HIPCHK(hipMemcpyAsync(c->rlen.p, hb.rlen.data(), n_reads * 4, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipMemcpyAsync(c->order.p, hb.order.data(), n_reads * 4, hipMemcpyHostToDevice, c->st));
 	}
-	HIPCHK(hipMemsetAsync(c->counters.p, 0, 256, c->st));
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, 4096, c->st));
 	HIPCHK(hipMemsetAsync(c->err.p, 0, 16, c->st));
 	c->stats.n_reads = n_reads; c->stats.n_bases = bases;
 	{   // chunk table of the sketch kernel: longest reads first so that a wave holds chunks of similar cost
@@ -422,12 +422,13 @@ int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
 		if (n_chunks) HIPCHK(hipMemcpyAsync(c->d_chunks.p, hc, n_chunks * 8, hipMemcpyHostToDevice, c->st));
 	}
 	// segment lists live in scratch that is free at this point: z (8 B/anchor) and wk (16 B/anchor) hold >= tot_a/2 16-byte entries each
-	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + 3, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->d_chunks.p, (int)n_chunks, c->st)) return MM355_EHIP; }
+	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + 448, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->d_chunks.p, (int)n_chunks, c->st)) return MM355_EHIP; }
 	HIPCHK(hipGetLastError());
-	unsigned long long pairs = 0;
-	HIPCHK(hipMemcpyAsync(&pairs, c->counters.as<unsigned long long>() + 3, 8, hipMemcpyDeviceToHost, c->st));
+	unsigned long long pairs[64];   // spread over 64 words (slot = block & 63): one word takes ~88 atomics per microsecond
+	HIPCHK(hipMemcpyAsync(pairs, c->counters.as<unsigned long long>() + 448, 512, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
-	c->stats.chain_pairs = (int64_t)pairs;
+	c->stats.chain_pairs = 0;
+	for (int k = 0; k < 64; ++k) c->stats.chain_pairs += (int64_t)pairs[k];
 	return 0;
 }
 
