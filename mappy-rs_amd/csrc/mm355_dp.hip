@@ -79,6 +79,7 @@ __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jo
 	__shared__ int32_t s_rh[NT / WAVE][4], s_rt[NT / WAVE][4];
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_jobs) return;
+	if (NT > WAVE) __builtin_amdgcn_s_setprio(3);      // the long-target launches: a few barrier-chained blocks beside the wide grids of the round
 	const int jid = job_ids[blockIdx.x];
 	const DpJobDev jb = jobs[jid];
 	const int qlen = jb.qlen, tlen = jb.tlen, flag = jb.flag, zdrop = jb.zdrop, end_bonus = jb.end_bonus;

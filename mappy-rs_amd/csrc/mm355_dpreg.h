@@ -87,10 +87,11 @@ __device__ __forceinline__ bool dp_bounds(DpRun &R)   // U:ksw2_extd2_sse.c: st/
 }
 
 struct DpDiag {            // wave-uniform description of one anti-diagonal
-	int r, st, en, st0, jq, jst, lane_st, lane_r;   // jq / jst: block of the top-row cell t = r / of st
+	int r, st, en, st0, jq, lane_st, lane_r, pos_st, pos_r;   // jq: block of the top-row cell t = r; pos_st / pos_r: (even) cell of st / of t = r, or -1 (catch-all instance)
 	uint32_t sclen, dv1, edge_u8, qc_hi;
 	bool use_def, edge, any_n;
-	size_t prow;           // r * n_col - st
+	uint64_t rowp;         // p + r * n_col - st: where cell 0 of block 0 would be stored (wave-uniform, made so explicitly: an "s" asm operand the
+	                       // compiler believes divergent is silently given VGPRs)
 };
 
 __device__ __forceinline__ void dp_slide(uint32_t &QQ, const uint32_t first_hi)   // the query moves one cell to the right
@@ -102,7 +103,10 @@ template <int J>
 __device__ __forceinline__ void dp_score(const DpDiag &g, const DpK &k, const int lane, uint32_t &SC, const uint32_t TQ, const uint32_t QQ)
 {
 	uint32_t s = pk_mad_vvs(pk_minu_s(TQ ^ QQ, k.one), k.dmis_v, k.mch);
-	if (g.any_n) s = pk_mad(pk_shr2(TQ | QQ), pk_rsub_s(k.N, s), s);
+	// either base ambiguous (code 4): sc_N.  Unconditional -- (TQ | QQ) >> 2 is 0 for plain bases and the multiply-add then returns s; under
+	// `if (any_n)` this was a wave-uniform branch in the middle of every block of every anti-diagonal, i.e. a basic-block boundary the
+	// scheduler cannot move the neighbouring blocks' instructions across (three instructions saved, the interleaving of eight chains lost)
+	s = pk_mad(pk_shr2(TQ | QQ), pk_rsub_s(k.N, s), s);
 	const uint32_t tl = (uint32_t)(128 * J + 2 * lane - g.st0);
 	const uint32_t m = (tl < g.sclen? 0xffffu : 0u) | (tl + 1 < g.sclen? 0xffff0000u : 0u);
 	SC = bfi(m, s, SC);
@@ -119,21 +123,23 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 	uint32_t nx_, nv_, nx2_;
 	if (J > 0) { nx_ = lane_shr1(fx, X); nv_ = lane_shr1(fv, V); nx2_ = lane_shr1(fx2, X2); }
 	else { nx_ = lane_shr1_z(X); nv_ = lane_shr1_z(V); nx2_ = lane_shr1_z(X2); }   // lane 0 of block 0: t-1 = -1, always a boundary value (IS_LO below)
-	// (ANYBLK: the catch-all instance, whose first / last ACTIVE block is only known at run time -- every block tests, wave-uniformly,
-	// whether it holds st or the top-row cell)
-	if (IS_LO && (!ANYBLK || J == g.jst)) {   // x[st-1], v[st-1], x2[st-1] are boundary values when that cell was outside the previous anti-diagonal
-		const bool at = lane == g.lane_st;   // (lane_st = -1 when the neighbour's state is to be used: no uniform-bool x lane-mask AND)
+	// (ANYBLK: the catch-all instance, whose first / last ACTIVE block is only known at run time -- every block compares its cells'
+	// position with that of st / of the top-row cell: selects, no branch, so that the eight blocks of an anti-diagonal stay ONE
+	// basic block and the scheduler can interleave their dependency chains -- a single wave has nothing else to hide latency with)
+	const int tl = 128 * J + 2 * lane;
+	if (IS_LO) {   // x[st-1], v[st-1], x2[st-1] are boundary values when that cell was outside the previous anti-diagonal
+		const bool at = ANYBLK? tl == g.pos_st : lane == g.lane_st;   // (lane_st / pos_st = -1 when the neighbour's state is to be used)
 		nx_ = at? k.dx1 : nx_; nv_ = at? g.dv1 : nv_; nx2_ = at? k.dx21 : nx2_;
 	}
 	const uint32_t XT = __builtin_amdgcn_alignbit(X, nx_, 16), VT = __builtin_amdgcn_alignbit(V, nv_, 16), X2T = __builtin_amdgcn_alignbit(X2, nx2_, 16);
 	uint32_t yi = Y, y2i = Y2, ui = U;
-	if (IS_HI && (!ANYBLK || J == g.jq)) {   // top row (query position 0, only ever in the last active block): y, y2 and u are the boundary values
-		const uint32_t hm = (g.r & 1)? 0xffff0000u : 0xffffu, m = (lane == (J == g.jq? g.lane_r : -1))? hm : 0u;   // lane_r = -1 without edge
+	if (IS_HI) {   // top row (query position 0, only ever in the last active block): y, y2 and u are the boundary values
+		const uint32_t hm = (g.r & 1)? 0xffff0000u : 0xffffu;
+		const uint32_t m = (ANYBLK? tl == g.pos_r : lane == (J == g.jq? g.lane_r : -1))? hm : 0u;   // lane_r / pos_r = -1 without edge
 		yi = bfi(m, k.nqe, yi); y2i = bfi(m, k.nq2e2, y2i); ui = bfi(m, g.edge_u8, ui);
 	}
 	// every lane computes; the six state registers are then overwritten under an EXEC mask (lanes outside [st, en] keep theirs).
 	// The masked writes are one asm block: written as C++ under `if (act)`, or as selects, the compiler copies/selects all six.
-	const int tl = 128 * J + 2 * lane;
 	const bool act = (uint32_t)(tl - g.st) <= (uint32_t)(g.en - g.st);   // st <= tl <= en in one compare
 	const uint32_t z0 = SC;
 	uint32_t a = pk_add(XT, VT), b = pk_add(yi, ui), a2 = pk_add(X2T, VT), b2 = pk_add(y2i, ui);
@@ -166,8 +172,10 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 		fa2 = pk_minu_s(pk_add_s(pk_max_s(a2, k.m256), k.c256), k.f32); fb2 = pk_minu_s(pk_add_s(pk_max_s(b2, k.m256), k.c256), k.f64);
 	}
 	d = d | fa | fb; d = d | fa2 | fb2;
-	{
+	{   // ... and the two direction bytes of the lane leave in the same EXEC region (written as C++ under `if (act)` the compiler opens its own
+		// EXEC region with a branch around it: a scheduling boundary after every block)
 		const uint64_t actm = __builtin_amdgcn_ballot_w64(act);
+		const uint32_t dd = __builtin_amdgcn_perm(0, d, 0x0c0c0200);
 		uint64_t saved;
 		asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\t"
 		             "v_pk_sub_u16 %[X], %[pa], %[qe]\n\t"
@@ -176,13 +184,13 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 		             "v_pk_sub_u16 %[Y2], %[pb2], %[q2e2]\n\t"
 		             "v_pk_sub_u16 %[U], %[z], %[VT]\n\t"
 		             "v_pk_sub_u16 %[V], %[z], %[ui]\n\t"
+		             "global_store_short %[off], %[dd], %[rowp]\n\t"
 		             "s_mov_b64 exec, %[sv]"
 		             : [X] "+&v"(X), [Y] "+&v"(Y), [X2] "+&v"(X2), [Y2] "+&v"(Y2), [U] "+&v"(U), [V] "+&v"(V), [sv] "=&s"(saved)
 		             : [m] "s"(actm), [pa] "v"(pa), [pb] "v"(pb), [pa2] "v"(pa2), [pb2] "v"(pb2), [z] "v"(z), [VT] "v"(VT), [ui] "v"(ui),
-		               [qe] "s"(k.qe), [q2e2] "s"(k.q2e2)
+		               [qe] "s"(k.qe), [q2e2] "s"(k.q2e2), [off] "v"(tl), [dd] "v"(dd), [rowp] "s"(g.rowp)
 		             : "scc");
 	}
-	if (act) *(uint16_t*)(p + g.prow + tl) = (uint16_t)(__builtin_amdgcn_perm(0, d, 0x0c0c0200));
 }
 
 // lane 63 <- maximum over the wave (inclusive scan by row shifts and row broadcasts; the other lanes hold prefix maxima)
@@ -227,12 +235,26 @@ __device__ __forceinline__ void dp_block_h(const int lane, const int st0, const 
 	}
 }
 
-// value of register R of block j (wave-uniform j) at lane l
-#define DP_PICK(R, j, l) ((NP <= 1 || (j) == 0)? rdlane(S.R##0, l) : (NP <= 2 || (j) == 1)? rdlane(S.R##1, l) : (NP <= 3 || (j) == 2)? rdlane(S.R##2, l) : \
-                          (NP <= 4 || (j) == 3)? rdlane(S.R##3, l) : (NP <= 5 || (j) == 4)? rdlane(S.R##4, l) : (NP <= 6 || (j) == 5)? rdlane(S.R##5, l) : \
-                          (NP <= 7 || (j) == 6)? rdlane(S.R##6, l) : rdlane(S.R##7, l))
+// value of register R of block j (wave-uniform j) at lane l: the block's register is chosen with selects (one v_cndmask per block on a
+// scalar condition), then ONE v_readlane -- as nested `j == k? readlane(Rk)` the compiler built a branch tree per pick, ~100 tiny basic
+// blocks per anti-diagonal in the exact kernels
+template <int NP>
+__device__ __forceinline__ uint32_t dp_sel8(const int j, uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, uint32_t r4, uint32_t r5, uint32_t r6, uint32_t r7)
+{
+	uint32_t x = r0;
+	if (NP > 1) x = j == 1? r1 : x;
+	if (NP > 2) x = j == 2? r2 : x;
+	if (NP > 3) x = j == 3? r3 : x;
+	if (NP > 4) x = j == 4? r4 : x;
+	if (NP > 5) x = j == 5? r5 : x;
+	if (NP > 6) x = j == 6? r6 : x;
+	if (NP > 7) x = j == 7? r7 : x;
+	return x;
+}
+#define DP_PICK(R, j, l) rdlane(dp_sel8<NP>((j), (uint32_t)S.R##0, (uint32_t)S.R##1, (uint32_t)S.R##2, (uint32_t)S.R##3, (uint32_t)S.R##4, (uint32_t)S.R##5, (uint32_t)S.R##6, (uint32_t)S.R##7), l)
 #define DP_CELL8(R, t) ((int)(int8_t)(DP_PICK(R, (t) >> 7, ((t) >> 1) & 63) >> (((t) & 1)? 24 : 8)))
-#define DP_HAT(t) (int32_t)(((t) & 1)? DP_PICK(Hh, (t) >> 7, ((t) >> 1) & 63) : DP_PICK(Hl, (t) >> 7, ((t) >> 1) & 63))
+#define DP_SEL(R, j) dp_sel8<NP>((j), (uint32_t)S.R##0, (uint32_t)S.R##1, (uint32_t)S.R##2, (uint32_t)S.R##3, (uint32_t)S.R##4, (uint32_t)S.R##5, (uint32_t)S.R##6, (uint32_t)S.R##7)
+#define DP_HAT(t) (int32_t)rdlane(((t) & 1)? DP_SEL(Hh, (t) >> 7) : DP_SEL(Hl, (t) >> 7), ((t) >> 1) & 63)
 #define DP_IN(k) (NP > k && k >= JLO && k <= JHI)
 
 // one anti-diagonal with active blocks JLO..JHI (a superset of the blocks that intersect [st, en] is fine: lanes outside are
@@ -255,9 +277,13 @@ __device__ __forceinline__ bool dp_diag(DpRun &R, DpSt &S, const DpK &K, const i
 	g.sclen = (uint32_t)(sce - st0);
 	if ((r & 63) == 0) R.qv = r - base + lane < R.qlen? R.query[r - base + lane] : 0;   // query[r - base] enters at cell 0
 	g.qc_hi = rdlane(R.qv, r & 63) << 16;
-	g.jq = (r - base) >> 7; g.jst = (st - base) >> 7;
+	g.jq = (r - base) >> 7;
 	g.lane_st = g.use_def? (st & 127) >> 1 : -1; g.lane_r = g.edge? (r & 127) >> 1 : -1;
-	g.prow = (size_t)r * R.n_col - (st - base);
+	g.pos_st = g.use_def? st - base : -1; g.pos_r = g.edge? (r - base) & ~1 : -1;
+	{
+		const uint64_t rp = (uint64_t)(R.p + ((size_t)r * R.n_col - (size_t)(st - base)));
+		g.rowp = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rp) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rp >> 32)) << 32;
+	}
 	const int jsh = (sce - 1 - base) >> 7;
 	// 1. the query moves (descending: block J takes the last cell of block J-1 before that one moves); blocks beyond t = r hold zeros
 #define DP_SLIDE(k, m) if constexpr (NP > k) { if (k <= JHI || k <= g.jq) dp_slide(S.QQ##k, k > 0? rdlane(S.QQ##m, 63) : g.qc_hi); }
@@ -397,6 +423,8 @@ __device__ __forceinline__ void dp_reg_body(const DpConst &dc, const DpJobDev *j
 {
 	const int lane = threadIdx.x;
 	if ((int)blockIdx.x >= n_jobs) return;
+	// the exact classes are small grids of long dependent sweeps next to the wide row-sweep grids of the round: issue priority over them
+	if constexpr (EXACT) __builtin_amdgcn_s_setprio(3);
 	const int jid = job_ids[blockIdx.x];
 	const DpJobDev jb = jobs[jid];
 	DpRun R;

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(64 * ROWL_WAVES) void k_ksw_rowl(DpConst dc, const 
 	__shared__ int done[ROWL_WAVES], s_n;
 	const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
 	if ((int)blockIdx.x >= n_jobs) return;
+	__builtin_amdgcn_s_setprio(3);                     // a few hundred long sweeps beside the wide grids of the round
 	const int jid = job_ids[blockIdx.x];
 	const DpJobDev jb = jobs[jid];
 	const uint8_t *target = tbase + jb.toff, *query = qbase + jb.qoff;
