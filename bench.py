@@ -361,13 +361,19 @@ def main():
         n_lfront = float(n_str)                            # one launch of every front kernel per sub-batch
         cand = {   # name: (algorithmic bytes per step, summed kernel ms per step, launches per step, formula)
             gnames[gi]: (g_cells, g_ms, g_nl, "1 B/cell direction matrix written to HBM, %.4g cells per launch (HIP events on the kernel's own stream)" % (g_cells / g_nl)),
+        }
+        for i in range(19):   # every extension kernel that ran, each timed alone on its own stream (the dominant one is also `roofline`)
+            if i != gi and nl_g[i] > 0 and agg["ms_dp_group"][i] > 0:
+                cand[gnames[i]] = (cells_g[i] / K, agg["ms_dp_group"][i] / K, max(1.0, nl_g[i] / K),
+                                   "1 B/cell direction matrix written to HBM, %.4g cells per launch (HIP events on the kernel's own stream)" % (cells_g[i] / max(1.0, nl_g[i])))
+        cand.update({
             "extension launch group": (cells, kern_ms["dp"], n_ldp, "1 B/cell x %.4g cells per group = all k_ksw_reg<NP,exact> / k_ksw_extd2 size classes "
                                        "on their streams + k_ksw_backtrack; one HIP-event pair around the group" % (cells / n_ldp)),
             "k_seed_lookup": (lookup_bytes, kern_ms["seed_lookup"], n_lfront, "16*n_mz + 16*n_hit (minimizer read + one table slot)"),
             "k_seed_expand": (expand_bytes, kern_ms["seed_expand"], n_lfront, "8*n_a_multi + 16*n_a (pos[] entry read + anchor written)"),
             "anchor sort": (32 * n_a, kern_ms["sort"], n_lfront, "2*16*n_a (one read + one write of every anchor; the radix passes actually needed are not counted)"),
             "k_chain": (36 * n_a, kern_ms["chain"], n_lfront, "16*n_a read + 20*n_a written"),
-        }
+        })
         # dominant kernel = the extension kernel with the largest summed duration (each is timed alone with HIP events on the stream it is launched
         # on; the rocprofv3 kernel statistics of the same command, profiles/, name the same kernel at the top).  The front stages are timed as
         # event spans on the context's main stream, where kernels of other contexts interleave: they stay in roofline_all.

@@ -14,3 +14,4 @@ python tools/pmcsum.py $(find $out/pmc_write -name "*counter_collection.csv") > 
 find $out -name "*counter_collection.csv" -size +20M -delete
 find $out -name "*kernel_trace.csv" -size +30M -delete
 head -c 600 $out/bench_default.json; echo; head -12 $out/pmc_fetch_by_kernel.txt
+python tools/pmc2json.py human/6144 $out/pmc_fetch_by_kernel.txt $out/pmc_write_by_kernel.txt $out/pmc_traffic.json
