@@ -1,7 +1,8 @@
 """DP kernel micro-benchmark through mm355_stage_dp: n jobs of ~L x L (5 % divergence), approx or exact.
 usage: python tools/dpbench.py [L=210] [n=100000] [flag=8] [w=500]   (w=30001: the full band of a gap fill)"""
 import sys, os, time, ctypes as C
-sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "mappy-rs_amd"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "mappy-rs_amd"))
 import numpy as np
 import synthdata as S
 from mappy_rs import _ffi
