@@ -75,11 +75,10 @@ if _ARGS is not None:
 
 def _host_pool_threads():
     """size of the library's shared host pool (MM355_HOST_THREADS) for this rank: the CPUs this process may use (cgroup quota or
-    affinity mask) divided by the ranks of the node, minus the threads that sit in the HIP runtime; 16 (the library default, one
-    GPU's CPU share on the bench boxes) when the rank is alone.  Over-subscribing a CPU quota stalls every thread of the cgroup."""
+    affinity mask) divided by the ranks of the node, minus two for the context threads and the HIP runtime (the library's own default
+    does the same for a single rank).  The path is host-bound: fewer threads starve the GPU, over-subscribing a CPU quota stalls every
+    thread of the cgroup (16-CPU quota, one rank: 10 threads 790, 14: 860, 16: 845, 20: 747 Mbases/s)."""
     local_world = int(_os.environ.get("LOCAL_WORLD_SIZE", _os.environ.get("WORLD_SIZE", "1")))
-    if local_world <= 1:
-        return 16
     try:
         cpus = float(len(_os.sched_getaffinity(0)))
     except (AttributeError, OSError):
@@ -90,7 +89,7 @@ def _host_pool_threads():
             cpus = min(cpus, float(q) / float(per))
     except (OSError, ValueError):
         pass
-    return max(6, min(16, int(cpus / local_world) - 4))
+    return max(4, min(32, int(cpus / max(1, local_world)) - 2))
 
 
 _os.environ.setdefault("MM355_HOST_THREADS", str(_host_pool_threads()))

@@ -49,7 +49,8 @@ static int64_t bk_end(int32_t max_drop, const mm128 *z, const int32_t *f, const 
 static void chain_backtrack(int64_t n, const int32_t *f, const int64_t *p, std::vector<int32_t> &v, int32_t *t, int32_t min_cnt, int32_t min_sc,
                             int32_t max_drop, std::vector<uint64_t> &u)
 {
-	std::vector<mm128> z;
+	static thread_local std::vector<mm128> z;   // (scratch kept per host thread: this runs once per read)
+	z.clear();
 	u.clear(); v.clear();
 	for (int64_t i = 0; i < n; ++i) if (f[i] >= min_sc) { mm128 e; e.x = (uint64_t)f[i]; e.y = (uint64_t)i; z.push_back(e); }
 	if (z.empty()) return;
@@ -71,8 +72,9 @@ static void chain_backtrack(int64_t n, const int32_t *f, const int64_t *p, std::
 static void compact_chains(std::vector<uint64_t> &u, const std::vector<int32_t> &v, std::vector<mm128> &a)
 {
 	const int n_u = (int)u.size();
-	std::vector<mm128> b(v.size()), w(n_u), out(v.size());
-	std::vector<uint64_t> u2(n_u);
+	static thread_local std::vector<mm128> b, w, out;   // (scratch kept per host thread; `out` / `u2` trade storage with the caller's vectors)
+	static thread_local std::vector<uint64_t> u2;
+	b.resize(v.size()); w.resize(n_u); out.resize(v.size()); u2.resize(n_u);
 	int64_t k = 0;
 	for (int i = 0; i < n_u; ++i) {
 		int32_t k0 = (int32_t)k, ni = (int32_t)u[i];
@@ -313,12 +315,17 @@ static int krmq_itr_prev(KrmqItr *itr)
 	return itr->top < itr->stack? 0 : 1;
 }
 
-struct LcPool {
-	std::vector<LcElem*> blocks; LcElem *free_list = 0; int used = 4096;
+struct LcPool {   // one per host thread, blocks kept between reads (a fresh 4096-node block per read was a 200 KB malloc/free -- mmap, page faults -- per read)
+	std::vector<LcElem*> blocks; LcElem *free_list = 0; int used = 4096; size_t cur = 0;
+	void reset() { free_list = 0; cur = 0; used = blocks.empty()? 4096 : 0; }
 	LcElem *alloc() {
 		if (free_list) { LcElem *q = free_list; free_list = q->c[0]; return q; }
-		if (used == 4096) { blocks.push_back((LcElem*)malloc(4096 * sizeof(LcElem))); used = 0; }
-		return &blocks.back()[used++];
+		if (used == 4096) {
+			if (!blocks.empty() && cur + 1 < blocks.size()) ++cur;
+			else { blocks.push_back((LcElem*)malloc(4096 * sizeof(LcElem))); cur = blocks.size() - 1; }
+			used = 0;
+		}
+		return &blocks[cur][used++];
 	}
 	void release(LcElem *q) { q->c[0] = free_list; free_list = q; }
 	~LcPool() { for (LcElem *b : blocks) free(b); }
@@ -353,11 +360,13 @@ static void rechain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 	int32_t max_drop = bw;
 	int64_t i0, st = 0, st_inner = 0;
 	LcElem *root = 0, *root_inner = 0;
-	LcPool mp;
+	static thread_local LcPool mp;
+	mp.reset();
 	if (max_dist < bw) max_dist = bw;
 	if (max_dist_inner < 0) max_dist_inner = 0;
 	if (max_dist_inner > max_dist) max_dist_inner = max_dist;
-	std::vector<int64_t> p(n); std::vector<int32_t> f(n), t(n, 0), vv;
+	static thread_local std::vector<int64_t> p; static thread_local std::vector<int32_t> f, t, vv;
+	p.resize(n); f.resize(n); t.assign(n, 0); vv.clear();
 	i0 = 0;
 	for (int64_t i = 0; i < n; ++i) {
 		int64_t max_j = -1;
@@ -814,8 +823,11 @@ void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, Read
 			for (int i = 0; i < n_regs0; ++i) n_a += (int32_t)rs.u[i];
 			rs.a.resize(n_a);
 			mm_radix_sort(rs.a.data(), rs.a.data() + n_a, mm_key_x());
+			static const bool dbg_rmq = getenv("MM355_PROF_RMQ") != 0;
+			const auto t_dbg = std::chrono::steady_clock::now();
 			rechain_rmq(opt->max_gap, opt->rmq_inner_dist, opt->bw_long, opt->max_chain_skip, opt->rmq_size_cap, opt->min_cnt, opt->min_chain_score,
 			            pen_gap, pen_skip, rs.a, rs.u);
+			if (dbg_rmq) fprintf(stderr, "[rmq] n_a %lld n_regs0 %d qlen %d: %.3f ms\n", (long long)n_a, n_regs0, qlen, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dbg).count());
 		}
 	}
 	}

@@ -6,6 +6,8 @@
 //   host   : the O(#chains) sequential tail of mm355_glue.cpp on a few threads, never any per-base loop of the hot path.
 // Reads are independent, so a node shards them over its GPUs with one context per GPU and no collective.
 #include <stdio.h>
+#include <stdlib.h>
+#include <sched.h>
 #include <string.h>
 #include <thread>
 #include <atomic>
@@ -64,8 +66,25 @@ public:
 	}
 private:
 	HostPool() {
+		// Default: the CPUs this process may use (cgroup quota, else the affinity mask) minus two for the context threads and the HIP runtime,
+		// at most 32.  The path is host-bound on a 16-core share: fewer threads leave the GPU waiting, more than the
+		// quota gets the whole cgroup throttled (measured on a 16-CPU quota: 10 threads 790, 14: 860, 16: 845, 20: 747 Mbases/s).
 		const char *e = getenv("MM355_HOST_THREADS");
-		int n = e? atoi(e) : 16;   // the GPU box gives one GPU a 16-core CPU share
+		int n = 14;
+		if (e) n = atoi(e);
+		else {
+			double cpus = 0;
+			cpu_set_t cs; CPU_ZERO(&cs);
+			if (sched_getaffinity(0, sizeof(cs), &cs) == 0) cpus = (double)CPU_COUNT(&cs);
+			if (FILE *fp = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+				char qb[64]; double per = 0;
+				if (fscanf(fp, "%63s %lf", qb, &per) == 2 && strcmp(qb, "max") != 0 && per > 0) { const double qv = atof(qb) / per; if (cpus <= 0 || qv < cpus) cpus = qv; }
+				fclose(fp);
+			}
+			if (cpus > 0) n = (int)cpus - 2;
+			if (n > 32) n = 32;
+			if (n < 4) n = 4;
+		}
 		if (n < 1) n = 1;
 		if (n > 64) n = 64;
 		for (int i = 1; i < n; ++i) th.emplace_back([this]() { worker(); });
