@@ -359,7 +359,7 @@ static void rechain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 	mm128 *a = av.data();
 	int32_t max_drop = bw;
 	int64_t i0, st = 0, st_inner = 0;
-	LcElem *root = 0, *root_inner = 0;
+	LcElem *root = 0;
 	static thread_local LcPool mp;
 	mp.reset();
 	if (max_dist < bw) max_dist = bw;
@@ -367,17 +367,23 @@ static void rechain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 	if (max_dist_inner > max_dist) max_dist_inner = max_dist;
 	static thread_local std::vector<int64_t> p; static thread_local std::vector<int32_t> f, t, vv;
 	p.resize(n); f.resize(n); t.assign(n, 0); vv.clear();
+	// The second tree of U:lchain.c (root_inner: the anchors within max_dist_inner) is only ever walked in key order -- krmq_interval for
+	// the largest key <= (y - 1, n), then krmq_itr_prev -- and asked for its size: nothing of it depends on the tree's shape.  It is kept as
+	// a sorted vector of keys (y << 32 | i; a few dozen entries): same members, same order, half of the AVL work of a read gone.
+	static thread_local std::vector<int64_t> inn;
+	inn.clear();
+	auto ikey = [](int32_t y, int64_t j) { return (int64_t)((uint64_t)(int64_t)y << 32 | (uint64_t)(uint32_t)j); };
 	i0 = 0;
 	for (int64_t i = 0; i < n; ++i) {
 		int64_t max_j = -1;
 		int32_t q_span = (int32_t)(a[i].y >> 32 & 0xff), max_f = q_span;
-		LcElem s, *q, *r, lo, hi;
+		LcElem s, *q, lo, hi;
 		if (i0 < i && a[i0].x != a[i].x) {
 			for (int64_t j = i0; j < i; ++j) {
 				q = mp.alloc();
 				q->y = (int32_t)a[j].y, q->i = j, q->pri = -(f[j] + 0.5 * pen_gap * ((int32_t)a[j].x + (int32_t)a[j].y));
 				krmq_insert(&root, q);
-				if (max_dist_inner > 0) { r = mp.alloc(); *r = *q; krmq_insert(&root_inner, r); }
+				if (max_dist_inner > 0) { const int64_t k = ikey((int32_t)a[j].y, j); inn.insert(std::lower_bound(inn.begin(), inn.end(), k), k); }
 			}
 			i0 = i;
 		}
@@ -387,9 +393,10 @@ static void rechain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 			++st;
 		}
 		if (max_dist_inner > 0) {
-			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + (uint64_t)max_dist_inner || lc_size(root_inner) > (unsigned)cap_rmq_size)) {
-				s.y = (int32_t)a[st_inner].y, s.i = st_inner;
-				if ((q = krmq_find(root_inner, &s)) != 0) { q = krmq_erase(&root_inner, q); mp.release(q); }
+			while (st_inner < i && (a[i].x >> 32 != a[st_inner].x >> 32 || a[i].x > a[st_inner].x + (uint64_t)max_dist_inner || inn.size() > (size_t)(unsigned)cap_rmq_size)) {
+				const int64_t k = ikey((int32_t)a[st_inner].y, st_inner);
+				auto it = std::lower_bound(inn.begin(), inn.end(), k);
+				if (it != inn.end() && *it == k) inn.erase(it);
 				++st_inner;
 			}
 		}
@@ -400,25 +407,20 @@ static void rechain_rmq(int max_dist, int max_dist_inner, int bw, int max_chn_sk
 			int64_t j = q->i;
 			sc = f[j] + comput_sc_simple(&a[i], &a[j], pen_gap, pen_skip, &exact, &width);
 			if (width <= bw && sc > max_f) max_f = sc, max_j = j;
-			if (!exact && root_inner && (int32_t)a[i].y > 0) {
-				LcElem *lo2, *hi2;
-				s.y = (int32_t)a[i].y - 1, s.i = n;
-				krmq_interval(root_inner, &s, &lo2, &hi2);
-				if (lo2) {
-					const LcElem *q2;
+			if (!exact && !inn.empty() && (int32_t)a[i].y > 0) {
+				// largest key <= (y - 1, n), then downwards
+				size_t idx = (size_t)(std::upper_bound(inn.begin(), inn.end(), ikey((int32_t)a[i].y - 1, n)) - inn.begin());
+				while (idx > 0) {
+					--idx;
+					const int32_t y2 = (int32_t)(inn[idx] >> 32);
 					int32_t width2;
-					KrmqItr itr;
-					krmq_itr_find(root_inner, lo2, &itr);
-					while ((q2 = (itr.top < itr.stack? 0 : *itr.top)) != 0) {
-						if (q2->y < (int32_t)a[i].y - max_dist_inner) break;
-						j = q2->i;
-						sc = f[j] + comput_sc_simple(&a[i], &a[j], pen_gap, pen_skip, 0, &width2);
-						if (width2 <= bw) {
-							if (sc > max_f) { max_f = sc, max_j = j; if (n_skip > 0) --n_skip; }
-							else if (t[j] == (int32_t)i) { if (++n_skip > max_chn_skip) break; }
-							if (p[j] >= 0) t[p[j]] = (int32_t)i;
-						}
-						if (!krmq_itr_prev(&itr)) break;
+					if (y2 < (int32_t)a[i].y - max_dist_inner) break;
+					j = (int64_t)(uint32_t)inn[idx];
+					sc = f[j] + comput_sc_simple(&a[i], &a[j], pen_gap, pen_skip, 0, &width2);
+					if (width2 <= bw) {
+						if (sc > max_f) { max_f = sc, max_j = j; if (n_skip > 0) --n_skip; }
+						else if (t[j] == (int32_t)i) { if (++n_skip > max_chn_skip) break; }
+						if (p[j] >= 0) t[p[j]] = (int32_t)i;
 					}
 				}
 			}
