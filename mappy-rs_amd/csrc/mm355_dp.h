@@ -31,3 +31,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
                  const mm355_dpres_t **res_out, const uint32_t **cigar_out);   // results live in pinned host buffers (c->h_res, *arena)
 int mm355_dp_gather(mm355_ctx *c, const DpGather *g, size_t n, size_t q_tot, size_t t_tot);   // g: pinned, valid until the next call
 int mm355_run_read_codes(mm355_ctx *c);
+
+#include "mm355_extra.h"
+// segs / seg_first / cig: pinned host arrays (mm355_glue_extra_fill); results: out[n_regions] (pinned, c->h_xout) and the compacted cs bytes (c->h_xcs)
+int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob *segs, size_t n_segs, const int64_t *seg_first, size_t n_regions,
+                    const uint32_t *cig, size_t n_cig, size_t cs_cap, bool want_cs, const Mm355ExtraOut **out, const char **cs);

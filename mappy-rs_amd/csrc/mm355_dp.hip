@@ -759,6 +759,168 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	return 0;
 }
 
+// ------------------------------------------------------------------ row f2: mm_update_extra's walk + cs on the device
+// U:align.c::mm_update_extra (after mm_fix_cigar, which stays on the host: it edits the CIGAR) walks every aligned column of a region for
+// mlen / blen / n_ambi and the local-maximum score dp_max; U:format.c::write_cs_core (short form) walks the same columns again for the cs
+// string.  On the host that was ~17 us of CPU per GRCh38-scale read.  Here: all regions of a batch in one launch after the last extension
+// round, one LANE per SEGMENT of 64 CIGAR operations (~500 columns) -- a lane per region was a 45 ms tail on a 100 kb read, every column
+// two dependent-latency loads; ~150 000 equal segments hide that latency behind one another.  What makes the cut exact:
+//   * counts and cs pieces simply add up / concatenate (write_cs_core flushes its match run at the end of every M operation);
+//   * the score walk s <- max(0, s + d) with running maximum is a max-plus map: a segment leaves (A, m, C, P) (Mm355ExtraSegOut) and
+//     k_extra_compose replays the segments of a region in order.  s is a double as in the reference; every partial sum of integer match
+//     scores and float-valued log gap costs is exact in double (< 2^20 in magnitude, fractions of 2^-23), so regrouping the additions
+//     changes nothing.
+// The cs bytes go to worst-case sized slots and are compacted afterwards (k_extra_scan / k_extra_compact): only real bytes cross PCIe.
+__global__ __launch_bounds__(WAVE) void k_extra(DevIndex ix, const uint8_t *rq, const Mm355ExtraJob *segs, int n_segs, const uint32_t *cig, Mm355ExtraScore sc,
+                                                 char *cs, Mm355ExtraSegOut *out, int want_cs)
+{
+	const int k = blockIdx.x * WAVE + threadIdx.x;
+	if (k >= n_segs) return;
+	const Mm355ExtraJob jb = segs[k];
+	const uint8_t *q = rq + jb.q_src;
+	const uint64_t tb = ix.seq_off[jb.rid] + (uint64_t)jb.t_st;
+	const uint32_t *cg = cig + jb.cig_off;
+	char *o = cs + jb.cs_off;
+	int32_t n_out = 0, qoff = 0, toff = 0, mlen = 0, blen = 0, n_ambi_tot = 0;
+	double A = 0.0, m = 1e300, C = -1e300, P = -1e300;
+	const char *nt = "acgtn";
+#define EX_T(off) ((uint32_t)(ix.S[(tb + (uint64_t)(off)) >> 3] >> (((tb + (uint64_t)(off)) & 7) << 2)) & 0xfu)
+#define EX_NUM(lead, v) do { char bf_[12]; int nb_ = 0; unsigned v_ = (v); do { bf_[nb_++] = (char)('0' + v_ % 10); v_ /= 10; } while (v_); o[n_out++] = (lead); while (nb_ > 0) o[n_out++] = bf_[--nb_]; } while (0)
+#define EX_STEP(d) do { A += (d); m = A < m? A : m; C = A > C? A : C; const double am_ = A - m; P = am_ > P? am_ : P; } while (0)
+	for (int c = 0; c < jb.n_cigar; ++c) {
+		const uint32_t op = cg[c] & 0xf, len = cg[c] >> 4;
+		if (op == 0) {
+			int n_ambi = 0, n_diff = 0;
+			unsigned run = 0;
+			for (uint32_t l = 0; l < len; ++l) {
+				const uint32_t cq = q[qoff + l], ct = EX_T(toff + l);
+				if (ct > 3 || cq > 3) ++n_ambi;
+				else if (ct != cq) ++n_diff;
+				EX_STEP((double)sc.mat[ct * 5 + cq]);
+				if (want_cs) {
+					if (cq == ct) ++run;
+					else { if (run) { EX_NUM(':', run); run = 0; } o[n_out++] = '*'; o[n_out++] = nt[ct]; o[n_out++] = nt[cq]; }
+				}
+			}
+			if (want_cs && run) EX_NUM(':', run);
+			blen += (int32_t)len - n_ambi; mlen += (int32_t)len - (n_ambi + n_diff); n_ambi_tot += n_ambi;
+			toff += (int32_t)len; qoff += (int32_t)len;
+		} else if (op == 1) {
+			int n_ambi = 0;
+			if (want_cs) o[n_out++] = '+';
+			for (uint32_t l = 0; l < len; ++l) { const uint32_t cq = q[qoff + l]; if (cq > 3) ++n_ambi; if (want_cs) o[n_out++] = nt[cq]; }
+			blen += (int32_t)len - n_ambi; n_ambi_tot += n_ambi;
+			EX_STEP(-((double)sc.q + (double)sc.e * (double)mm_log2f_approx((float)(1.0 + (double)len))));
+			qoff += (int32_t)len;
+		} else if (op == 2) {
+			int n_ambi = 0;
+			if (want_cs) o[n_out++] = '-';
+			for (uint32_t l = 0; l < len; ++l) { const uint32_t ct = EX_T(toff + l); if (ct > 3) ++n_ambi; if (want_cs) o[n_out++] = nt[ct]; }
+			blen += (int32_t)len - n_ambi; n_ambi_tot += n_ambi;
+			EX_STEP(-((double)sc.q + (double)sc.e * (double)mm_log2f_approx((float)(1.0 + (double)len))));
+			toff += (int32_t)len;
+		} else if (op == 3) toff += (int32_t)len;
+	}
+#undef EX_T
+#undef EX_NUM
+#undef EX_STEP
+	Mm355ExtraSegOut r;
+	r.A = A; r.m = m; r.C = C; r.P = P; r.mlen = mlen; r.blen = blen; r.n_ambi = n_ambi_tot; r.cs_len = n_out; r.cs_dense = 0;
+	out[k] = r;
+}
+
+// exclusive prefix sum of the segments' cs lengths (one block: a batch has ~10^5 segments)
+__global__ __launch_bounds__(1024) void k_extra_scan(Mm355ExtraSegOut *out, int n)
+{
+	__shared__ long long part[1024];
+	const int t = threadIdx.x, per = (n + 1023) / 1024, lo = t * per < n? t * per : n, hi = lo + per < n? lo + per : n;
+	long long sum = 0;
+	for (int i = lo; i < hi; ++i) sum += out[i].cs_len;
+	part[t] = sum;
+	__syncthreads();
+	if (t == 0) { long long acc = 0; for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = acc; acc += v; } }
+	__syncthreads();
+	long long acc = part[t];
+	for (int i = lo; i < hi; ++i) { out[i].cs_dense = acc; acc += out[i].cs_len; }
+}
+
+// one lane per region: its segments in order (U:align.c::mm_update_extra's `s` and `max`, `dp_max = (int32_t)(max + .499)`)
+__global__ __launch_bounds__(256) void k_extra_compose(const Mm355ExtraSegOut *seg, const int64_t *seg_first, int n_regions, Mm355ExtraOut *out)
+{
+	const int k = blockIdx.x * 256 + threadIdx.x;
+	if (k >= n_regions) return;
+	double s = 0.0, mx = 0.0;
+	Mm355ExtraOut r; r.mlen = r.blen = r.n_ambi = 0; r.cs_len = 0; r.cs_dense = 0; r.pad = 0;
+	const int64_t g0 = seg_first[k], g1 = seg_first[k + 1];
+	for (int64_t g = g0; g < g1; ++g) {
+		const Mm355ExtraSegOut e = seg[g];
+		if (g == g0) r.cs_dense = e.cs_dense;
+		r.mlen += e.mlen; r.blen += e.blen; r.n_ambi += e.n_ambi; r.cs_len += e.cs_len;
+		if (e.C > -1e299) {   // the segment had score steps
+			const double a = s + e.C, hi = a > e.P? a : e.P;
+			mx = hi > mx? hi : mx;
+			const double nm = -e.m;
+			s = e.A + (s > nm? s : nm);
+		}
+	}
+	r.dp_max = (int32_t)(mx + .499);
+	out[k] = r;
+}
+
+__global__ __launch_bounds__(256) void k_extra_compact(const Mm355ExtraJob *segs, const Mm355ExtraSegOut *out, int n, const char *cs, char *dense)
+{
+	const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per segment
+	if (k >= n) return;
+	const char *src = cs + segs[k].cs_off; char *dst = dense + out[k].cs_dense;
+	for (int i = lane; i < out[k].cs_len; i += 64) dst[i] = src[i];
+}
+
+int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob *segs, size_t n_segs, const int64_t *seg_first, size_t n_regions,
+                    const uint32_t *cig, size_t n_cig, size_t cs_cap, bool want_cs, const Mm355ExtraOut **out, const char **cs)
+{
+	*out = 0; *cs = 0;
+	if (n_regions == 0) return 0;
+	const size_t seg_b = (n_segs * sizeof(Mm355ExtraJob) + 63) & ~(size_t)63, first_b = (n_regions + 1) * 8;
+	if (c->x_jobs.ensure(seg_b + first_b + 64) || c->x_cig.ensure((n_cig + 16) * 4) || c->x_cs.ensure(cs_cap + 64) ||
+	    c->x_out.ensure((n_segs + 1) * sizeof(Mm355ExtraSegOut) + n_regions * sizeof(Mm355ExtraOut)) || c->h_xout.ensure(n_regions * sizeof(Mm355ExtraOut) + 64)) return MM355_ENOMEM;
+	Mm355ExtraScore sc;
+	{
+		int a = mo->a < 0? -mo->a : mo->a, b = mo->b > 0? -mo->b : mo->b, amb = mo->sc_ambi > 0? -mo->sc_ambi : mo->sc_ambi;   // U:ksw2.h::ksw_gen_simple_mat
+		for (int i = 0; i < 4; ++i) { for (int j = 0; j < 4; ++j) sc.mat[i * 5 + j] = (int8_t)(i == j? a : b); sc.mat[i * 5 + 4] = (int8_t)amb; }
+		for (int j = 0; j < 5; ++j) sc.mat[4 * 5 + j] = (int8_t)amb;
+		sc.q = (int8_t)mo->q; sc.e = (int8_t)mo->e;
+	}
+	Mm355ExtraJob *d_segs = c->x_jobs.as<Mm355ExtraJob>();
+	int64_t *d_first = (int64_t*)((char*)c->x_jobs.p + seg_b);
+	Mm355ExtraSegOut *d_so = c->x_out.as<Mm355ExtraSegOut>();
+	Mm355ExtraOut *d_ro = (Mm355ExtraOut*)(d_so + n_segs + 1);
+	if (n_segs) HIPCHK(hipMemcpyAsync(d_segs, segs, n_segs * sizeof(Mm355ExtraJob), hipMemcpyHostToDevice, c->st));
+	HIPCHK(hipMemcpyAsync(d_first, seg_first, first_b, hipMemcpyHostToDevice, c->st));
+	if (n_cig) HIPCHK(hipMemcpyAsync(c->x_cig.p, cig, n_cig * 4, hipMemcpyHostToDevice, c->st));
+	if (n_segs) {
+		hipLaunchKernelGGL(k_extra, dim3((unsigned)((n_segs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dix, c->rq.as<uint8_t>(), d_segs, (int)n_segs,
+		                   c->x_cig.as<uint32_t>(), sc, c->x_cs.as<char>(), d_so, want_cs? 1 : 0);
+		if (want_cs) hipLaunchKernelGGL(k_extra_scan, dim3(1), dim3(1024), 0, c->st, d_so, (int)n_segs);
+	}
+	hipLaunchKernelGGL(k_extra_compose, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, c->st, d_so, d_first, (int)n_regions, d_ro);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(c->h_xout.p, d_ro, n_regions * sizeof(Mm355ExtraOut), hipMemcpyDeviceToHost, c->st));
+	HIPCHK(mm355_wait_stream(c->st));
+	const Mm355ExtraOut *ho = (const Mm355ExtraOut*)c->h_xout.p;
+	if (want_cs) {
+		size_t tot = 0;
+		for (size_t k = 0; k < n_regions; ++k) tot += (size_t)ho[k].cs_len;
+		if (c->x_dense.ensure(tot + 64) || c->h_xcs.ensure(tot + 64)) return MM355_ENOMEM;
+		if (n_segs) hipLaunchKernelGGL(k_extra_compact, dim3((unsigned)((n_segs + 3) / 4)), dim3(256), 0, c->st, d_segs, d_so, (int)n_segs, c->x_cs.as<char>(), c->x_dense.as<char>());
+		HIPCHK(hipGetLastError());
+		if (tot) HIPCHK(hipMemcpyAsync(c->h_xcs.p, c->x_dense.p, tot, hipMemcpyDeviceToHost, c->st));
+		HIPCHK(mm355_wait_stream(c->st));
+		*cs = (const char*)c->h_xcs.p;
+	}
+	*out = ho;
+	return 0;
+}
+
 // gather descriptors g[0..n) live in pinned host memory of the context until the next call
 int mm355_dp_gather(mm355_ctx *c, const DpGather *g, size_t n, size_t q_tot, size_t t_tot)
 {

@@ -1117,7 +1117,7 @@ static void cigar_eqx(Reg *r, const uint8_t *qseq, const uint8_t *tseq)
 	cg.swap(nc);
 }
 
-static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int out_flags, bool eqx)
+static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int out_flags, bool eqx, const ExtraLoc *loc = 0)
 {
 	int32_t qshift, tshift, toff = 0, qoff = 0;
 	double s = 0.0, max = 0.0;
@@ -1126,6 +1126,11 @@ static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const
 	{ ProfScope pf2(PF_X2); fix_cigar(r, qseq, tseq, &qshift, &tshift); }
 	qseq += qshift, tseq += tshift;
 	r->blen = r->mlen = 0;
+	if (loc && !(out_flags & MM355_OUT_MD) && !eqx) {   // the walk below and cs: on the device, for all regions of the batch at once (k_extra)
+		p->deferred = true;
+		p->x_strand = loc->strand; p->x_qst = loc->q_st + qshift; p->x_rid = loc->rid; p->x_tst = loc->t_st + tshift;
+		return;
+	}
 	ProfScope *pf3 = new ProfScope(PF_X3);
 	for (size_t k = 0; k < p->cigar.size(); ++k) {
 		uint32_t op = p->cigar[k] & 0xf, len = p->cigar[k] >> 4, l;
@@ -1504,7 +1509,8 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 		r->p = new Extra(tmp);
 		tseq.resize((size_t)(re1 - rs1) + 1);
 		getseq(mi, (uint32_t)rid, rs1, re1, tseq.data()); }
-		update_extra(r, rs.qc[r->rev].data() + qs1, tseq.data(), mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags, (opt->flag & MMF_EQX) != 0);
+		const ExtraLoc loc = { (int32_t)r->rev, qs1, rid, rs1 };
+		update_extra(r, rs.qc[r->rev].data() + qs1, tseq.data(), mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags, (opt->flag & MMF_EQX) != 0, rs.defer_extra? &loc : 0);
 	}
 	return true;
 }
@@ -1579,7 +1585,8 @@ static int align1_inv(const mm355_index *mi, const mm355_mapopt_t *opt, int read
 	else { r_inv->qe = r2->qs - q_off; r_inv->qs = r_inv->qe - (ez.max_q + 1); }
 	r_inv->rs = r1->re + t_off;
 	r_inv->re = r_inv->rs + ez.max_t + 1;
-	update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags, (opt->flag & MMF_EQX) != 0);
+	const ExtraLoc loc = { q_strand, q_base + q_off, r1->rid, r1->re + t_off };
+	update_extra(r_inv, &qseq[q_off], &tseq[t_off], mat, (int8_t)opt->q, (int8_t)opt->e, rs.out_flags, (opt->flag & MMF_EQX) != 0, rs.defer_extra? &loc : 0);
 	return 1;
 }
 
@@ -1756,6 +1763,61 @@ void mm355_glue_finish(const mm355_index *mi, const mm355_mapopt_t *opt, ReadSta
 			if (flags & MM355_OUT_MD) { h.md_off = (int64_t)str.size(); h.md_len = (int64_t)r->p->md.size(); str += r->p->md; str += '\0'; }
 		}
 		hits.push_back(h);
+	}
+}
+
+// ---- regions whose mm_update_extra walk / cs were left to the device
+static inline int64_t extra_cs_cap(const std::vector<uint32_t> &cg)   // worst case: "*xy" per aligned base, "+" / "-" and the bases per gap, ":<number>" per match run
+{
+	int64_t tot = 0;
+	for (uint32_t c : cg) tot += c >> 4;
+	return (3 * tot + 12 * (int64_t)cg.size() + 31) & ~(int64_t)15;
+}
+void mm355_glue_extra_count(const ReadState &rs, int64_t *n_regions, int64_t *n_segs, int64_t *n_cig, int64_t *n_cs)
+{
+	*n_regions = *n_segs = *n_cig = *n_cs = 0;
+	for (const Reg &r : rs.regs) if (r.p && r.p->deferred) {
+		++*n_regions; *n_segs += ((int64_t)r.p->cigar.size() + MM355_EXTRA_SEG - 1) / MM355_EXTRA_SEG;
+		*n_cig += (int64_t)r.p->cigar.size(); *n_cs += extra_cs_cap(r.p->cigar);
+	}
+}
+// segs: this read's segment descriptors (global index seg0 + ...); seg_first[reg0 + k]: global index of region k's first segment
+void mm355_glue_extra_fill(const ReadState &rs, int64_t q_base, Mm355ExtraJob *segs, int64_t *seg_first, int64_t reg0, int64_t seg0, uint32_t *cig, int64_t cig0, int64_t cs0)
+{
+	int64_t k = 0, g = 0;
+	for (const Reg &r : rs.regs) if (r.p && r.p->deferred) {
+		const std::vector<uint32_t> &cg = r.p->cigar;
+		const int n = (int)cg.size();
+		seg_first[reg0 + k] = seg0 + g;
+		if (n) memcpy(cig + cig0, cg.data(), (size_t)n * 4);
+		int64_t qoff = 0, toff = 0, cso = 0;
+		for (int c0 = 0; c0 < n; c0 += MM355_EXTRA_SEG) {
+			const int c1 = c0 + MM355_EXTRA_SEG < n? c0 + MM355_EXTRA_SEG : n;
+			Mm355ExtraJob j; memset(&j, 0, sizeof(j));
+			j.q_src = q_base + (r.p->x_strand? rs.qlen : 0) + r.p->x_qst + qoff;
+			j.cig_off = cig0 + c0; j.cs_off = cs0 + cso; j.rid = (uint32_t)r.p->x_rid; j.t_st = (int32_t)(r.p->x_tst + toff); j.n_cigar = c1 - c0; j.region = (int32_t)(reg0 + k);
+			segs[g++] = j;
+			int64_t tot = 0;
+			for (int c = c0; c < c1; ++c) {
+				const uint32_t op = cg[c] & 0xf, len = cg[c] >> 4;
+				if (op == 0 || op == 7 || op == 8) qoff += len, toff += len;
+				else if (op == 1) qoff += len;
+				else if (op == 2 || op == 3) toff += len;
+				tot += len;
+			}
+			cso += 3 * tot + 12 * (int64_t)(c1 - c0);
+		}
+		++k; cig0 += n; cs0 += extra_cs_cap(cg);
+	}
+}
+void mm355_glue_extra_apply(ReadState &rs, const Mm355ExtraOut *out, const char *cs, bool want_cs)
+{
+	int64_t k = 0;
+	for (Reg &r : rs.regs) if (r.p && r.p->deferred) {
+		const Mm355ExtraOut &o = out[k++];
+		r.mlen = o.mlen; r.blen = o.blen; r.p->n_ambi += (uint32_t)o.n_ambi; r.p->dp_max = o.dp_max;
+		if (want_cs) r.p->cs.assign(cs + o.cs_dense, (size_t)o.cs_len);
+		r.p->deferred = false;
 	}
 }
 

@@ -2,6 +2,7 @@
 // a13): long-join re-chaining, chains -> regions, primary/secondary selection, the DP work generator that feeds
 // k_ksw_extd2 in rounds, CIGAR stitching, MAPQ, cs/MD.  Batch-oriented: one ReadState per read of the batch.
 #pragma once
+#include "mm355_extra.h"
 #include <stdint.h>
 #include <vector>
 #include <string>
@@ -12,7 +13,14 @@ struct Extra {
 	uint32_t n_ambi = 0;
 	std::vector<uint32_t> cigar;
 	std::string cs, md;     // written when the region is committed (the code strings are at hand there)
+	// deferred = the per-base walk of U:align.c::mm_update_extra (mlen / blen / n_ambi / dp_max) and the cs string are left to the device
+	// (k_extra, one launch for all regions of the batch after the last extension round): where the walk starts in the read's code strings
+	// and in the reference (after mm_fix_cigar's shifts)
+	bool deferred = false;
+	int32_t x_strand = 0, x_qst = 0, x_rid = 0, x_tst = 0;
 };
+
+struct ExtraLoc { int32_t strand, q_st, rid, t_st; };   // start of a region's query / target strings
 
 struct Reg {                // U:minimap.h::mm_reg1_t
 	int32_t id = 0, cnt = 0, rid = 0, score = 0;
@@ -69,6 +77,7 @@ struct ReadState {
 	int cursor = 0;                    // U:align.c::mm_align_skeleton loop index
 	bool aligned = false;
 	int next_uid = 0;
+	bool defer_extra = false;          // leave mm_update_extra's walk and cs to the device (set per batch by the caller)
 };
 
 struct GlueStats { int64_t n_rmq = 0, n_rounds = 0, n_jobs = 0; };
@@ -84,3 +93,9 @@ bool mm355_glue_align_step(const mm355_index *mi, const mm355_mapopt_t *opt, int
 void mm355_glue_finish(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs, int flags,
                        std::vector<mm355_hit_t> &hits, std::vector<uint32_t> &cigar, std::string &str);
 void mm355_glue_release(ReadState &rs);
+// between the last extension round and stage 3, when rs.defer_extra: the regions whose walk was left to the device.
+// count: number of such regions, of their CIGAR operations and of cs bytes to reserve; fill: descriptors + CIGARs at the given offsets;
+// apply: results back into the regions (same order as fill)
+void mm355_glue_extra_count(const ReadState &rs, int64_t *n_regions, int64_t *n_segs, int64_t *n_cig, int64_t *n_cs);
+void mm355_glue_extra_fill(const ReadState &rs, int64_t q_base, Mm355ExtraJob *segs, int64_t *seg_first, int64_t reg0, int64_t seg0, uint32_t *cig, int64_t cig0, int64_t cs0);
+void mm355_glue_extra_apply(ReadState &rs, const Mm355ExtraOut *out, const char *cs, bool want_cs);

@@ -305,7 +305,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	for (int64_t i = 0; i < n_reads; ++i) seqs[i] = (const char*)&c->hb.seq[c->hb.roff[i]];
 	const bool verbose = getenv("MM355_VERBOSE") != 0;
 	const bool rmq_chain = (mo->flag & MMF_RMQ) != 0;
-	double tv0 = now_ms(), tv_front, tv_pack, tv_pre, tv_steps = 0, tv_dp = 0, tv_fin, tv_asm;
+	double tv0 = now_ms(), tv_front, tv_pack, tv_pre, tv_steps = 0, tv_dp = 0, tv_fin, tv_asm, tv_extra = 0;
 	{
 		double ts = now_ms();
 #define FRONT_STAGE(name, call) do { if ((rc = (call))) return rc; if (g_trace_path) { const double te = now_ms(); trace_add(c, name, ts, te); ts = te; } } while (0)
@@ -354,10 +354,14 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	tv_pack = now_ms() - tv0; trace_add(c, "pack", tv0, now_ms()); tv0 = now_ms();
 	const double t_host0 = now_ms();
 	const int nt = host_threads();
+	// mm_update_extra's per-base walk and the cs string: on the device for all regions of the batch at once (k_extra), unless MD or '=' / 'X'
+	// CIGARs are asked for (those stay with the host walk) or MM355_EXTRA_HOST=1
+	static const bool extra_host = [] { const char *e = getenv("MM355_EXTRA_HOST"); return e && atoi(e) != 0; }();
+	const bool defer_extra = !extra_host && !(flags & MM355_OUT_MD) && !(mo->flag & MMF_EQX);
 	std::vector<ReadState> rs(n_reads);
 	parallel_for(n_reads, nt, [&](int64_t i, int) {
 		ReadState &r = rs[i];
-		r.qlen = dl[i]; r.seq = seqs[i]; r.rep_len = hb.rep_len[i];
+		r.qlen = dl[i]; r.seq = seqs[i]; r.rep_len = hb.rep_len[i]; r.defer_extra = defer_extra;
 		{ ProfScope pf(PF_PRE_COPY);
 		r.u.assign(pu + uo[i], pu + uo[i + 1]);
 		r.a.assign(pa + vo[i], pa + vo[i + 1]);
@@ -388,6 +392,34 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		if ((rc = run_dp_round(c, mo, rs, reqs, arenas))) return rc;
 		tv_dp += now_ms() - td0; ++n_rounds; trace_add(c, "dp", td0, now_ms());
 		if (verbose) fprintf(stderr, "[mm355]   round %d: %zu jobs, %lld reads open\n", round, reqs.size(), (long long)n_open.load());
+	}
+	if (defer_extra && n_reads > 0) {   // row f2: one launch for every aligned region of the batch
+		const double tx0 = now_ms();
+		std::vector<int64_t> xr((size_t)n_reads + 1), xg((size_t)n_reads + 1), xc((size_t)n_reads + 1), xs((size_t)n_reads + 1);
+		parallel_for(n_reads, nt, [&](int64_t i, int) { mm355_glue_extra_count(rs[i], &xr[i], &xg[i], &xc[i], &xs[i]); });
+		int64_t tr = 0, tg = 0, tc = 0, ts = 0;
+		for (int64_t i = 0; i < n_reads; ++i) {
+			const int64_t a = xr[i], g = xg[i], b = xc[i], d = xs[i];
+			xr[i] = tr; xg[i] = tg; xc[i] = tc; xs[i] = ts; tr += a; tg += g; tc += b; ts += d;
+		}
+		xr[n_reads] = tr; xg[n_reads] = tg; xc[n_reads] = tc; xs[n_reads] = ts;
+		if (tr > 0) {
+			const size_t seg_b = ((size_t)tg * sizeof(Mm355ExtraJob) + 63) & ~(size_t)63;
+			if (c->h_xjobs.ensure(seg_b + ((size_t)tr + 1) * 8 + 64) || c->h_xcig.ensure(((size_t)tc + 16) * 4)) return MM355_ENOMEM;
+			Mm355ExtraJob *xsegs = (Mm355ExtraJob*)c->h_xjobs.p; int64_t *xfirst = (int64_t*)((char*)c->h_xjobs.p + seg_b); uint32_t *xcig = (uint32_t*)c->h_xcig.p;
+			xfirst[tr] = tg;
+			parallel_for(n_reads, nt, [&](int64_t i, int) {
+				if (xr[i + 1] > xr[i]) mm355_glue_extra_fill(rs[i], 2 * c->hb.roff[i], xsegs + xg[i], xfirst, xr[i], xg[i], xcig, xc[i], xs[i]);
+			});
+			const Mm355ExtraOut *xo = 0; const char *xcs = 0;
+			const bool want_cs = (flags & MM355_OUT_CS) != 0;
+			ms_host += now_ms() - tx0;
+			if ((rc = mm355_extra_run(c, mo, xsegs, (size_t)tg, xfirst, (size_t)tr, xcig, (size_t)tc, (size_t)ts, want_cs, &xo, &xcs))) return rc;
+			const double tx1 = now_ms();
+			parallel_for(n_reads, nt, [&](int64_t i, int) { if (xr[i + 1] > xr[i]) mm355_glue_extra_apply(rs[i], xo + xr[i], xcs, want_cs); });
+			ms_host += now_ms() - tx1;
+		}
+		tv_extra = now_ms() - tx0; trace_add(c, "extra", tx0, now_ms());
 	}
 	const double th1 = now_ms();
 	std::vector<std::vector<mm355_hit_t>> rh(n_reads);
@@ -423,8 +455,8 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	}
 	ms_host += now_ms() - th1;
 	tv_asm = now_ms() - tv0; trace_add(c, "asm", tv0, now_ms());
-	if (verbose) fprintf(stderr, "[mm355] map_resident: front %.1f ms | pack+d2h %.1f | pre_align %.1f | align_steps %.1f | dp rounds(%d) %.1f (kernel %.1f) | finish %.1f | assemble %.1f | total %.1f\n",
-	                     tv_front, tv_pack, tv_pre, tv_steps, n_rounds, tv_dp, c->stats.ms_dp, tv_fin, tv_asm, now_ms() - t_start);
+	if (verbose) fprintf(stderr, "[mm355] map_resident: front %.1f ms | pack+d2h %.1f | pre_align %.1f | align_steps %.1f | dp rounds(%d) %.1f (kernel %.1f) | extra %.1f | finish %.1f | assemble %.1f | total %.1f\n",
+	                     tv_front, tv_pack, tv_pre, tv_steps, n_rounds, tv_dp, c->stats.ms_dp, tv_extra, tv_fin, tv_asm, now_ms() - t_start);
 	c->stats.ms_host = ms_host; c->stats.n_ext_rounds = n_rounds;
 	c->stats.ms_total = now_ms() - t_start;
 	if (verbose) mm355_prof_dump(n_reads);

@@ -67,6 +67,7 @@ struct mm355_ctx {
 	hipEvent_t dp_up_ev = 0;      // dense CIGAR arenas of the launches of the current batch (results point into them)
 	DBuf kprof;    // MM355_KPROF phase counters (64 x u64)
 	DBuf rq;       // per-read query codes fwd|rev
+	DBuf x_jobs, x_cig, x_cs, x_out, x_dense; HBuf h_xjobs, h_xcig, h_xout, h_xcs;   // k_extra (mm_update_extra's walk + cs on the device)
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
 	std::vector<hipEvent_t> tev; std::vector<double*> tacc; int n_tpend = 0;   // lazy stage timers (EvTimer)
