@@ -973,3 +973,41 @@ extern "C" int mm355_stage_dp(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t 
 	}
 	return 0;
 }
+
+// C-ABI: the device form of mm_update_extra's walk + cs on caller-provided regions (parity tests)
+extern "C" int mm355_stage_extra(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t n_regions, const mm355_extrajob_t *jobs,
+                                 const uint8_t *qcodes, int64_t n_q, const uint32_t *cigar, int64_t n_cigar, int want_cs,
+                                 mm355_extrares_t *res, char *cs, int64_t cs_cap)
+{
+	if (c == 0 || mo == 0 || n_regions < 0) return MM355_EINVAL;
+	if (n_regions == 0) return 0;
+	HIPCHK(hipSetDevice(c->dev));
+	if (c->rq.ensure((size_t)n_q + 64)) return MM355_ENOMEM;
+	if (n_q) HIPCHK(hipMemcpyAsync(c->rq.p, qcodes, (size_t)n_q, hipMemcpyHostToDevice, c->st));
+	size_t n_segs = 0, slot = 0;
+	for (int64_t k = 0; k < n_regions; ++k) {
+		if (jobs[k].n_cigar < 0 || jobs[k].cigar_off < 0 || jobs[k].cigar_off + jobs[k].n_cigar > n_cigar || (uint32_t)jobs[k].rid >= c->mi->n_seq) return MM355_EINVAL;
+		n_segs += ((size_t)jobs[k].n_cigar + MM355_EXTRA_SEG - 1) / MM355_EXTRA_SEG;
+		slot += (size_t)mm355_extra_cs_cap(cigar + jobs[k].cigar_off, jobs[k].n_cigar);
+	}
+	const size_t seg_b = (n_segs * sizeof(Mm355ExtraJob) + 63) & ~(size_t)63;
+	if (c->h_xjobs.ensure(seg_b + ((size_t)n_regions + 1) * 8 + 64) || c->h_xcig.ensure(((size_t)n_cigar + 16) * 4)) return MM355_ENOMEM;
+	Mm355ExtraJob *segs = (Mm355ExtraJob*)c->h_xjobs.p; int64_t *first = (int64_t*)((char*)c->h_xjobs.p + seg_b);
+	if (n_cigar) memcpy(c->h_xcig.p, cigar, (size_t)n_cigar * 4);
+	size_t g = 0; int64_t cso = 0;
+	for (int64_t k = 0; k < n_regions; ++k) {
+		first[k] = (int64_t)g;
+		g += (size_t)mm355_extra_split(cigar + jobs[k].cigar_off, jobs[k].n_cigar, jobs[k].q_off, (uint32_t)jobs[k].rid, jobs[k].t_st, jobs[k].cigar_off, cso, (int32_t)k, segs + g);
+		cso += mm355_extra_cs_cap(cigar + jobs[k].cigar_off, jobs[k].n_cigar);
+	}
+	first[n_regions] = (int64_t)g;
+	const Mm355ExtraOut *xo = 0; const char *xcs = 0;
+	int rc = mm355_extra_run(c, mo, segs, n_segs, first, (size_t)n_regions, (const uint32_t*)c->h_xcig.p, (size_t)n_cigar, slot, want_cs != 0, &xo, &xcs);
+	if (rc) return rc;
+	for (int64_t k = 0; k < n_regions; ++k) {
+		mm355_extrares_t o; o.mlen = xo[k].mlen; o.blen = xo[k].blen; o.n_ambi = xo[k].n_ambi; o.dp_max = xo[k].dp_max; o.cs_off = xo[k].cs_dense; o.cs_len = want_cs? xo[k].cs_len : 0; o.pad = 0;
+		if (want_cs) { if (o.cs_off + o.cs_len > cs_cap) return MM355_ENOMEM; memcpy(cs + o.cs_off, xcs + o.cs_off, (size_t)o.cs_len); }
+		res[k] = o;
+	}
+	return 0;
+}

@@ -16,3 +16,33 @@ struct Mm355ExtraJob {      // one SEGMENT (up to MM355_EXTRA_SEG consecutive CI
 struct Mm355ExtraSegOut { double A, m, C, P; int32_t mlen, blen, n_ambi, cs_len; int64_t cs_dense; };
 struct Mm355ExtraOut { int32_t mlen, blen, n_ambi, dp_max; int64_t cs_dense; int32_t cs_len, pad; };   // cs_dense: offset in the compacted cs arena
 struct Mm355ExtraScore { int8_t mat[25]; int8_t q, e; };
+
+// worst-case cs bytes of a CIGAR: "*xy" per aligned base, "+" / "-" and the bases per gap, ":<number>" per match run
+static inline int64_t mm355_extra_cs_cap(const uint32_t *cg, int n)
+{
+	int64_t tot = 0;
+	for (int c = 0; c < n; ++c) tot += cg[c] >> 4;
+	return (3 * tot + 12 * (int64_t)n + 31) & ~(int64_t)15;
+}
+// cuts one region into segments of MM355_EXTRA_SEG operations; returns the number of segments written
+static inline int mm355_extra_split(const uint32_t *cg, int n, int64_t q_src, uint32_t rid, int64_t t_st, int64_t cig_off, int64_t cs_off, int32_t region, Mm355ExtraJob *segs)
+{
+	int g = 0;
+	int64_t qoff = 0, toff = 0, cso = 0;
+	for (int c0 = 0; c0 < n; c0 += MM355_EXTRA_SEG) {
+		const int c1 = c0 + MM355_EXTRA_SEG < n? c0 + MM355_EXTRA_SEG : n;
+		Mm355ExtraJob j;
+		j.q_src = q_src + qoff; j.cig_off = cig_off + c0; j.cs_off = cs_off + cso; j.rid = rid; j.t_st = (int32_t)(t_st + toff); j.n_cigar = c1 - c0; j.region = region;
+		segs[g++] = j;
+		int64_t tot = 0;
+		for (int c = c0; c < c1; ++c) {
+			const uint32_t op = cg[c] & 0xf, len = cg[c] >> 4;
+			if (op == 0 || op == 7 || op == 8) qoff += len, toff += len;
+			else if (op == 1) qoff += len;
+			else if (op == 2 || op == 3) toff += len;
+			tot += len;
+		}
+		cso += 3 * tot + 12 * (int64_t)(c1 - c0);
+	}
+	return g;
+}

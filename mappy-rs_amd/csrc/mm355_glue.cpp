@@ -1767,12 +1767,7 @@ void mm355_glue_finish(const mm355_index *mi, const mm355_mapopt_t *opt, ReadSta
 }
 
 // ---- regions whose mm_update_extra walk / cs were left to the device
-static inline int64_t extra_cs_cap(const std::vector<uint32_t> &cg)   // worst case: "*xy" per aligned base, "+" / "-" and the bases per gap, ":<number>" per match run
-{
-	int64_t tot = 0;
-	for (uint32_t c : cg) tot += c >> 4;
-	return (3 * tot + 12 * (int64_t)cg.size() + 31) & ~(int64_t)15;
-}
+static inline int64_t extra_cs_cap(const std::vector<uint32_t> &cg) { return mm355_extra_cs_cap(cg.data(), (int)cg.size()); }
 void mm355_glue_extra_count(const ReadState &rs, int64_t *n_regions, int64_t *n_segs, int64_t *n_cig, int64_t *n_cs)
 {
 	*n_regions = *n_segs = *n_cig = *n_cs = 0;
@@ -1790,23 +1785,7 @@ void mm355_glue_extra_fill(const ReadState &rs, int64_t q_base, Mm355ExtraJob *s
 		const int n = (int)cg.size();
 		seg_first[reg0 + k] = seg0 + g;
 		if (n) memcpy(cig + cig0, cg.data(), (size_t)n * 4);
-		int64_t qoff = 0, toff = 0, cso = 0;
-		for (int c0 = 0; c0 < n; c0 += MM355_EXTRA_SEG) {
-			const int c1 = c0 + MM355_EXTRA_SEG < n? c0 + MM355_EXTRA_SEG : n;
-			Mm355ExtraJob j; memset(&j, 0, sizeof(j));
-			j.q_src = q_base + (r.p->x_strand? rs.qlen : 0) + r.p->x_qst + qoff;
-			j.cig_off = cig0 + c0; j.cs_off = cs0 + cso; j.rid = (uint32_t)r.p->x_rid; j.t_st = (int32_t)(r.p->x_tst + toff); j.n_cigar = c1 - c0; j.region = (int32_t)(reg0 + k);
-			segs[g++] = j;
-			int64_t tot = 0;
-			for (int c = c0; c < c1; ++c) {
-				const uint32_t op = cg[c] & 0xf, len = cg[c] >> 4;
-				if (op == 0 || op == 7 || op == 8) qoff += len, toff += len;
-				else if (op == 1) qoff += len;
-				else if (op == 2 || op == 3) toff += len;
-				tot += len;
-			}
-			cso += 3 * tot + 12 * (int64_t)(c1 - c0);
-		}
+		g += mm355_extra_split(cg.data(), n, q_base + (r.p->x_strand? rs.qlen : 0) + r.p->x_qst, (uint32_t)r.p->x_rid, r.p->x_tst, cig0, cs0, (int32_t)(reg0 + k), segs + g);
 		++k; cig0 += n; cs0 += extra_cs_cap(cg);
 	}
 }

@@ -73,6 +73,14 @@ class DpJob(C.Structure):
                 ("w", C.c_int32), ("zdrop", C.c_int32), ("end_bonus", C.c_int32), ("flag", C.c_int32)]
 
 
+class ExtraJob(C.Structure):
+    _fields_ = [("q_off", C.c_int64), ("cigar_off", C.c_int64), ("rid", C.c_int32), ("t_st", C.c_int32), ("n_cigar", C.c_int32), ("pad", C.c_int32)]
+
+
+class ExtraRes(C.Structure):
+    _fields_ = [("mlen", C.c_int32), ("blen", C.c_int32), ("n_ambi", C.c_int32), ("dp_max", C.c_int32), ("cs_off", C.c_int64), ("cs_len", C.c_int32), ("pad", C.c_int32)]
+
+
 class DpRes(C.Structure):
     _fields_ = [("max", C.c_int32), ("zdropped", C.c_int32), ("max_q", C.c_int32), ("max_t", C.c_int32),
                 ("mqe", C.c_int32), ("mqe_t", C.c_int32), ("mte", C.c_int32), ("mte_q", C.c_int32),
@@ -84,7 +92,7 @@ EXPORTS = [
     "mm355_index_info", "mm355_index_seq_name", "mm355_index_seq_len", "mm355_index_name2id", "mm355_index_getseq",
     "mm355_index_get", "mm355_index_stat", "mm355_upload", "mm355_ctx_create", "mm355_ctx_destroy", "mm355_map_batch",
     "mm355_free_hits", "mm355_batch_upload", "mm355_batch_select", "mm355_map_resident", "mm355_stage_sketch", "mm355_stage_anchors", "mm355_stage_chain", "mm355_stage_chains",
-    "mm355_stage_dp", "mm355_get_stats", "mm355_device_count", "mm355_device_synchronize", "mm355_strerror", "mm355_version",
+    "mm355_stage_dp", "mm355_stage_extra", "mm355_get_stats", "mm355_device_count", "mm355_device_synchronize", "mm355_strerror", "mm355_version",
 ]
 
 _LIB = None
@@ -129,6 +137,7 @@ def lib():
     L.mm355_stage_chain.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, C.POINTER(C.c_char_p), i32p, vp, vp, vp, vp, vp, C.c_int64]
     L.mm355_stage_chains.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, C.POINTER(C.c_char_p), i32p, vp, vp, C.c_int64, vp, vp, C.c_int64]
     L.mm355_stage_dp.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64]
+    L.mm355_stage_extra.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int, vp, vp, C.c_int64]
     L.mm355_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mm355_strerror.restype = C.c_char_p
     L.mm355_strerror.argtypes = [C.c_int]

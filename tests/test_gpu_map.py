@@ -787,3 +787,105 @@ def test_multi_device_api_on_one_gpu(ont):
     got = {d["i"]: m for m, d in al.map_batch([{"seq": r, "i": i} for i, r in enumerate(reads)])}
     ref = ont["al"]._map_many(reads, 1)
     assert all([rec(m) for m in got[i]] == [rec(m) for m in ref[i]] for i in range(len(reads)))
+
+
+def _log2f_approx(x):
+    """U:mmpriv.h::mg_log2 in float32 arithmetic (the gap cost of mm_update_extra)"""
+    z = np.array([x], np.float32).view(np.uint32)
+    log_2 = np.float32(int((z[0] >> 23) & 255) - 128)
+    z[0] &= np.uint32(~(255 << 23) & 0xffffffff); z[0] += np.uint32(127 << 23)
+    f = z.view(np.float32)[0]
+    t = np.float32(-0.34484843) * f
+    t = np.float32(t + np.float32(2.02466578)); t = np.float32(t * f); t = np.float32(t - np.float32(0.67487759))
+    return np.float32(log_2 + t)
+
+
+def _update_extra_ref(q, t, cigar, a, b, amb, go, ge):
+    """plain restatement of U:align.c::mm_update_extra (the walk after mm_fix_cigar) and U:format.c::write_cs_core (short form)"""
+    s = mx = 0.0
+    mlen = blen = n_ambi_tot = 0
+    qo = to = 0
+    cs = []
+    nt = "acgtn"
+    for op, ln in cigar:
+        if op == 0:
+            n_ambi = n_diff = run = 0
+            for l in range(ln):
+                cq, ct = int(q[qo + l]), int(t[to + l])
+                if ct > 3 or cq > 3: n_ambi += 1; sc = -amb
+                elif ct != cq: n_diff += 1; sc = -b
+                else: sc = a
+                s += sc
+                if s < 0: s = 0.0
+                else: mx = max(mx, s)
+                if cq == ct: run += 1
+                else:
+                    if run: cs.append(":%d" % run); run = 0
+                    cs.append("*" + nt[ct] + nt[cq])
+            if run: cs.append(":%d" % run)
+            blen += ln - n_ambi; mlen += ln - (n_ambi + n_diff); n_ambi_tot += n_ambi; qo += ln; to += ln
+        elif op == 1:
+            n_ambi = int((q[qo:qo + ln] > 3).sum()); blen += ln - n_ambi; n_ambi_tot += n_ambi
+            cs.append("+" + "".join(nt[int(x)] for x in q[qo:qo + ln]))
+            s -= go + float(ge) * float(_log2f_approx(np.float32(1.0 + ln)))
+            if s < 0: s = 0.0
+            qo += ln
+        elif op == 2:
+            n_ambi = int((t[to:to + ln] > 3).sum()); blen += ln - n_ambi; n_ambi_tot += n_ambi
+            cs.append("-" + "".join(nt[int(x)] for x in t[to:to + ln]))
+            s -= go + float(ge) * float(_log2f_approx(np.float32(1.0 + ln)))
+            if s < 0: s = 0.0
+            to += ln
+    return mlen, blen, n_ambi_tot, int(mx + .499), "".join(cs)
+
+
+@pytest.mark.gpu
+def test_update_extra_and_cs_on_device(ont):
+    """k_extra (row f2) through its stage entry: mlen / blen / n_ambi / dp_max and the cs string of regions with given CIGARs -- one to
+    several hundred operations (1 .. 6 segments of 64), long gaps (log cost), runs of mismatches (the score clamps at 0), ambiguous bases,
+    regions that begin or end with a gap, a region without operations"""
+    from mappy_rs import _ffi
+    L = _ffi.lib()
+    rng = np.random.default_rng(41)
+    al = ont["al"]
+    t_all = np.asarray(ont["g"][0], np.uint8)     # codes 0..4 of chr1 (with N runs)
+    jobs, qs, cigs, refs = [], [], [], []
+    for i in range(60):
+        n_ops = int([0, 1, 2, 63, 64, 65, 127, 128, 129, 300][i % 10]) if i < 30 else int(rng.integers(1, 400))
+        t_st = int(rng.integers(0, len(t_all) - 60000))
+        ops, q, to = [], [], 0
+        for k in range(n_ops):
+            last = ops[-1][0] if ops else -1
+            op = 0 if (k % 2 == 0 and last != 0) else int(rng.choice([1, 2]))
+            if op == last: op = 0
+            if i % 7 == 3 and k == 0: op = int(rng.choice([1, 2]))        # region that begins with a gap
+            ln = int(rng.integers(1, 40)) if op == 0 else int(rng.choice([1, 1, 2, 3, 10, 60, 700, 3000]))
+            if op == 0:
+                seg = t_all[t_st + to:t_st + to + ln].copy()
+                mm = rng.random(ln) < (0.6 if (i % 5 == 1 and k % 8 < 4) else 0.08)     # stretches of mismatches: s falls back to 0
+                seg[mm] = (seg[mm] + rng.integers(1, 4, int(mm.sum()))) % 4
+                if i % 6 == 2: seg[rng.random(ln) < 0.05] = 4
+                q.append(seg); to += ln
+            elif op == 1: q.append(S.random_codes(rng, ln).astype(np.uint8))
+            else: to += ln
+            ops.append((op, ln))
+        qa = np.concatenate(q).astype(np.uint8) if q else np.zeros(0, np.uint8)
+        jobs.append((t_st, ops)); qs.append(qa)
+    qcat = np.concatenate(qs + [np.zeros(8, np.uint8)])
+    cig = np.array([ln << 4 | op for _, ops in jobs for op, ln in ops] + [0], np.uint32)
+    ja = (_ffi.ExtraJob * len(jobs))()
+    qo = co = 0
+    for i, (t_st, ops) in enumerate(jobs):
+        ja[i].q_off, ja[i].cigar_off, ja[i].rid, ja[i].t_st, ja[i].n_cigar = qo, co, 0, t_st, len(ops)
+        qo += len(qs[i]); co += len(ops)
+    res = (_ffi.ExtraRes * len(jobs))()
+    cap = int(3 * (qcat.size + sum(ln for _, ops in jobs for op, ln in ops)) + 64 * len(cig))
+    cs = np.zeros(cap, np.uint8)
+    mo = al._mo
+    sr = al._stage_runner()
+    _ffi.check(L.mm355_stage_extra(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, cig.ctypes.data, len(cig) - 1, 1, res, cs.ctypes.data, cap))
+    for i, (t_st, ops) in enumerate(jobs):
+        exp = _update_extra_ref(qs[i], t_all[t_st:], ops, mo.a, mo.b, mo.sc_ambi, mo.q, mo.e)
+        got = (res[i].mlen, res[i].blen, res[i].n_ambi, res[i].dp_max, bytes(cs[res[i].cs_off:res[i].cs_off + res[i].cs_len]).decode())
+        assert got == exp, (i, len(ops), got[:4], exp[:4])
+    sr.close()
