@@ -829,23 +829,24 @@ __global__ __launch_bounds__(WAVE) void k_extra(DevIndex ix, const uint8_t *rq, 
 	out[k] = r;
 }
 
-// exclusive prefix sum of the segments' cs lengths (one block: a batch has ~10^5 segments)
-__global__ __launch_bounds__(1024) void k_extra_scan(Mm355ExtraSegOut *out, int n)
+// exclusive prefix sum of the regions' cs lengths (one block of 256 threads: a batch has a few thousand regions; the per-segment offsets
+// inside a region come from k_extra_compose -- a scan over the ~10^5 segments in one 1024-thread block waited milliseconds for a CU under load)
+__global__ __launch_bounds__(256) void k_extra_scan(Mm355ExtraOut *out, int n)
 {
-	__shared__ long long part[1024];
-	const int t = threadIdx.x, per = (n + 1023) / 1024, lo = t * per < n? t * per : n, hi = lo + per < n? lo + per : n;
+	__shared__ long long part[256];
+	const int t = threadIdx.x, per = (n + 255) / 256, lo = t * per < n? t * per : n, hi = lo + per < n? lo + per : n;
 	long long sum = 0;
 	for (int i = lo; i < hi; ++i) sum += out[i].cs_len;
 	part[t] = sum;
 	__syncthreads();
-	if (t == 0) { long long acc = 0; for (int i = 0; i < 1024; ++i) { const long long v = part[i]; part[i] = acc; acc += v; } }
+	if (t == 0) { long long acc = 0; for (int i = 0; i < 256; ++i) { const long long v = part[i]; part[i] = acc; acc += v; } }
 	__syncthreads();
 	long long acc = part[t];
 	for (int i = lo; i < hi; ++i) { out[i].cs_dense = acc; acc += out[i].cs_len; }
 }
 
 // one lane per region: its segments in order (U:align.c::mm_update_extra's `s` and `max`, `dp_max = (int32_t)(max + .499)`)
-__global__ __launch_bounds__(256) void k_extra_compose(const Mm355ExtraSegOut *seg, const int64_t *seg_first, int n_regions, Mm355ExtraOut *out)
+__global__ __launch_bounds__(256) void k_extra_compose(Mm355ExtraSegOut *seg, const int64_t *seg_first, int n_regions, Mm355ExtraOut *out)
 {
 	const int k = blockIdx.x * 256 + threadIdx.x;
 	if (k >= n_regions) return;
@@ -854,7 +855,7 @@ __global__ __launch_bounds__(256) void k_extra_compose(const Mm355ExtraSegOut *s
 	const int64_t g0 = seg_first[k], g1 = seg_first[k + 1];
 	for (int64_t g = g0; g < g1; ++g) {
 		const Mm355ExtraSegOut e = seg[g];
-		if (g == g0) r.cs_dense = e.cs_dense;
+		seg[g].cs_dense = r.cs_len;   // offset of the segment's cs piece inside its region
 		r.mlen += e.mlen; r.blen += e.blen; r.n_ambi += e.n_ambi; r.cs_len += e.cs_len;
 		if (e.C > -1e299) {   // the segment had score steps
 			const double a = s + e.C, hi = a > e.P? a : e.P;
@@ -867,11 +868,11 @@ __global__ __launch_bounds__(256) void k_extra_compose(const Mm355ExtraSegOut *s
 	out[k] = r;
 }
 
-__global__ __launch_bounds__(256) void k_extra_compact(const Mm355ExtraJob *segs, const Mm355ExtraSegOut *out, int n, const char *cs, char *dense)
+__global__ __launch_bounds__(256) void k_extra_compact(const Mm355ExtraJob *segs, const Mm355ExtraSegOut *out, const Mm355ExtraOut *reg, int n, const char *cs, char *dense)
 {
 	const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per segment
 	if (k >= n) return;
-	const char *src = cs + segs[k].cs_off; char *dst = dense + out[k].cs_dense;
+	const char *src = cs + segs[k].cs_off; char *dst = dense + reg[segs[k].region].cs_dense + out[k].cs_dense;
 	for (int i = lane; i < out[k].cs_len; i += 64) dst[i] = src[i];
 }
 
@@ -900,9 +901,9 @@ int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob 
 	if (n_segs) {
 		hipLaunchKernelGGL(k_extra, dim3((unsigned)((n_segs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dix, c->rq.as<uint8_t>(), d_segs, (int)n_segs,
 		                   c->x_cig.as<uint32_t>(), sc, c->x_cs.as<char>(), d_so, want_cs? 1 : 0);
-		if (want_cs) hipLaunchKernelGGL(k_extra_scan, dim3(1), dim3(1024), 0, c->st, d_so, (int)n_segs);
 	}
 	hipLaunchKernelGGL(k_extra_compose, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, c->st, d_so, d_first, (int)n_regions, d_ro);
+	if (want_cs) hipLaunchKernelGGL(k_extra_scan, dim3(1), dim3(256), 0, c->st, d_ro, (int)n_regions);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(c->h_xout.p, d_ro, n_regions * sizeof(Mm355ExtraOut), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
@@ -911,7 +912,7 @@ int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob 
 		size_t tot = 0;
 		for (size_t k = 0; k < n_regions; ++k) tot += (size_t)ho[k].cs_len;
 		if (c->x_dense.ensure(tot + 64) || c->h_xcs.ensure(tot + 64)) return MM355_ENOMEM;
-		if (n_segs) hipLaunchKernelGGL(k_extra_compact, dim3((unsigned)((n_segs + 3) / 4)), dim3(256), 0, c->st, d_segs, d_so, (int)n_segs, c->x_cs.as<char>(), c->x_dense.as<char>());
+		if (n_segs) hipLaunchKernelGGL(k_extra_compact, dim3((unsigned)((n_segs + 3) / 4)), dim3(256), 0, c->st, d_segs, d_so, d_ro, (int)n_segs, c->x_cs.as<char>(), c->x_dense.as<char>());
 		HIPCHK(hipGetLastError());
 		if (tot) HIPCHK(hipMemcpyAsync(c->h_xcs.p, c->x_dense.p, tot, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(mm355_wait_stream(c->st));
