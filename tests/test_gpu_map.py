@@ -29,6 +29,9 @@ def check_reads(al, orc, reads, cs=True, MD=True):
     al.enable_threading(2)
     n_hits = n_sec = 0
     batch = al._map_many(reads, (1 if cs else 0) | (2 if MD else 0))
+    # an MD request keeps mm_update_extra's walk on the host; the cs-only request (what map_batch makes) leaves it to the device (k_extra):
+    # both forms are held against the same oracle records
+    batch_dev = al._map_many(reads, 1) if (cs and MD) else None
     for i, rd in enumerate(reads):
         exp = orc.map(rd, cs=cs, MD=MD)
         got = batch[i]
@@ -37,6 +40,11 @@ def check_reads(al, orc, reads, cs=True, MD=True):
             assert rec(g) == orec(e), (i, rec(g), orec(e))
             n_hits += 1
             n_sec += not e["is_primary"]
+        if batch_dev is not None:
+            assert len(batch_dev[i]) == len(exp), (i, len(batch_dev[i]), len(exp))
+            for g, e in zip(batch_dev[i], exp):
+                rg, re_ = rec(g), orec(e)
+                assert rg[:13] + rg[14:] == re_[:13] + re_[14:] and g.MD is None, (i, rg, re_)
     return n_hits, n_sec
 
 
@@ -889,3 +897,15 @@ def test_update_extra_and_cs_on_device(ont):
         got = (res[i].mlen, res[i].blen, res[i].n_ambi, res[i].dp_max, bytes(cs[res[i].cs_off:res[i].cs_off + res[i].cs_len]).decode())
         assert got == exp, (i, len(ops), got[:4], exp[:4])
     sr.close()
+
+
+def test_update_extra_host_walk(ont, monkeypatch):
+    """the host form of mm_update_extra / cs (what batches below 1024 reads, MD and EQX requests use) against the oracle and against the
+    device form on the same reads"""
+    reads, _ = S.make_reads(77, ont["g"], 60, n50=5000, lo=300)
+    al = ont["al"]
+    dev = [[(m.r_st, m.r_en, m.mlen, m.blen, m.NM, m.mapq, m.cs) for m in al.map(r, cs=True)] for r in reads]
+    monkeypatch.setenv("MM355_EXTRA_HOST", "1")
+    n_hits, _ = check_reads(al, ont["orc"], reads)
+    host = [[(m.r_st, m.r_en, m.mlen, m.blen, m.NM, m.mapq, m.cs) for m in al.map(r, cs=True)] for r in reads]
+    assert n_hits > 50 and host == dev
