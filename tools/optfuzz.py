@@ -59,12 +59,18 @@ def run(seed, n_configs, fa_path, verbose=False, noisy=False):
         al = mappy_rs.Aligner(fa_path, **kw)
         al.enable_threading(2)
         got = al._map_many(reads, 3)
+        # cs only: mm_update_extra's walk and the cs string then run on the device (k_extra; MM355_EXTRA_MIN_READS=1 set below) -- unless the
+        # configuration asks for '=' / 'X' CIGARs, which keep the host walk like an MD request
+        got_dev = al._map_many(reads, 1)
+        FD = FIELDS[:-1]
         bad = nh = 0
         for i, rd in enumerate(reads):
             exp = orc.map(rd, cs=True, MD=True)
             nh += len(exp)
             ok = len(exp) == len(got[i]) and all(tuple(getattr(m, k) for k in FIELDS) + (m.cigar_str,) == tuple(e[k] for k in FIELDS) + (e["cigar_str"],)
                                                  for m, e in zip(got[i], exp))
+            ok = ok and len(exp) == len(got_dev[i]) and all(tuple(getattr(m, k) for k in FD) + (m.cigar_str,) == tuple(e[k] for k in FD) + (e["cigar_str"],)
+                                                            for m, e in zip(got_dev[i], exp))
             bad += not ok
         tot_hits += nh; tot_bad += bad
         if verbose or bad: print("cfg %2d hits %4d mismatching reads %d %s" % (ci, nh, bad, kw), flush=True)
@@ -74,6 +80,7 @@ def run(seed, n_configs, fa_path, verbose=False, noisy=False):
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "mappy-rs_amd"), os.path.join(root, "tests")): sys.path.insert(0, p)
+    os.environ.setdefault("MM355_EXTRA_MIN_READS", "1")
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     print("configs %d, hits %d, mismatching reads %d" % run(seed, n, "/tmp/optfuzz.fa", verbose=True, noisy=len(sys.argv) > 3 and sys.argv[3] == "noisy"))
