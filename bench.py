@@ -180,9 +180,14 @@ def aggregate(dist, dt, aligned, bases):
     return float(t.item()), float(a[0].item()), float(a[1].item())
 
 
-def cpu_baseline(g, names, preset, reads, budget_s, threads):
+SIG_FIELDS = ("target_name", "target_start", "target_end", "query_start", "query_end", "strand", "mapq", "is_primary", "NM", "match_len", "block_len", "cigar_str", "cs")
+
+
+def cpu_baseline(g, names, preset, reads, budget_s, threads, gpu_sigs=None):
     """oracle (CPU restatement of the minimap2 2.26 path) on host threads, bounded sample of the same reads; the index is built from
-    the same contigs with the oracle's threaded builder (not timed: the metric excludes index construction on both sides)"""
+    the same contigs with the oracle's threaded builder (not timed: the metric excludes index construction on both sides).
+    gpu_sigs[i]: hash of the hit records the HIP path returned for read i (taken before the timed numbers were printed, outside the timed
+    region): every read of the sample is also a full-size parity check of the run itself -- the oracle as the checker."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     tb = time.time()
@@ -197,15 +202,21 @@ def cpu_baseline(g, names, preset, reads, budget_s, threads):
         if time.time() > deadline:
             return None
         h = orc.map(rd, cs=True)
-        return len(rd), (len(rd) if h else 0)
+        return len(rd), (len(rd) if h else 0), hash(tuple(tuple(x[k] for k in SIG_FIELDS) for x in h)), len(h)
 
+    par = {"reads": 0, "hits": 0, "mismatching_reads": 0}
     with ThreadPoolExecutor(threads) as ex:
-        for r in ex.map(work, reads):
+        for i, r in enumerate(ex.map(work, reads)):
             if r is None:
                 continue
             done["bases"] += r[0]; done["aligned"] += r[1]; done["n"] += 1
+            if gpu_sigs is not None and i < len(gpu_sigs):
+                par["reads"] += 1; par["hits"] += r[3]; par["mismatching_reads"] += int(gpu_sigs[i] != r[2])
     dt = time.time() - t0
-    return dict(value=round(done["aligned"] / dt / 1e6, 4), unit="aligned Mbases/s", cores=threads, kind="port",
+    if gpu_sigs is not None:
+        log("[bench] parity of the run itself: %d reads (%d hits) of the CPU sample compared with the HIP path's records, %d mismatching" %
+            (par["reads"], par["hits"], par["mismatching_reads"]))
+    return dict(parity=par if gpu_sigs is not None else None, value=round(done["aligned"] / dt / 1e6, 4), unit="aligned Mbases/s", cores=threads, kind="port",
                 sample="the first %d reads (%.2f Mbases) of rank 0's shard of the same workload in %.1f s; CPU restatement of the minimap2 2.26 "
                        "path (oracle/), scalar ksw2, one read per thread task; oracle index of the same genome built on %d threads in %.0f s "
                        "(not timed)" % (done["n"], done["bases"] / 1e6, dt, threads, t_build))
@@ -403,12 +414,25 @@ def main():
                                       n_dp_jobs=int(agg["n_dp_jobs"] / K)),
         }
     barrier()
+    gpu_sigs = None
+    if rank == 0 and not args.no_cpu and world == 1:   # (outside the timed region) the records of the reads the CPU sample will cover
+        import mappy_rs
+        gpu_sigs = []
+        n_chk = min(len(reads), 4 * 6144)
+        for lo in range(0, n_chk, 6144):
+            sub = reads[lo:min(n_chk, lo + 6144)]
+            rarr, rlens, keep = _ffi.pack_reads(sub)
+            hp = C.POINTER(_ffi.Hits)()
+            _ffi.check(L.mm355_map_batch(ctxs[0], C.byref(mo), len(sub), rarr, rlens, _ffi.OUT_CS, C.byref(hp)))
+            for ms in mappy_rs._batch_to_mappings(hp, len(sub), names):
+                gpu_sigs.append(None if isinstance(ms, Exception) else hash(tuple(tuple(getattr(m, k) for k in SIG_FIELDS) for m in ms)))
+            L.mm355_free_hits(hp)
     for ctx in ctxs:
         L.mm355_ctx_destroy(ctx)
     L.mm355_index_free(idx)
     if rank == 0:
         if not args.no_cpu and world == 1:   # after the GPU side has released its memory; rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(g, names, wl["preset"], reads, args.cpu_seconds, min(16, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(g, names, wl["preset"], reads, args.cpu_seconds, min(16, os.cpu_count() or 1), gpu_sigs)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
