@@ -988,7 +988,7 @@ extern "C" int mm355_stage_extra(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64
 	size_t n_segs = 0, slot = 0;
 	for (int64_t k = 0; k < n_regions; ++k) {
 		if (jobs[k].n_cigar < 0 || jobs[k].cigar_off < 0 || jobs[k].cigar_off + jobs[k].n_cigar > n_cigar || (uint32_t)jobs[k].rid >= c->mi->n_seq) return MM355_EINVAL;
-		n_segs += ((size_t)jobs[k].n_cigar + MM355_EXTRA_SEG - 1) / MM355_EXTRA_SEG;
+		n_segs += (size_t)mm355_extra_n_segs(cigar + jobs[k].cigar_off, jobs[k].n_cigar);
 		slot += (size_t)mm355_extra_cs_cap(cigar + jobs[k].cigar_off, jobs[k].n_cigar);
 	}
 	const size_t seg_b = (n_segs * sizeof(Mm355ExtraJob) + 63) & ~(size_t)63;

@@ -1126,7 +1126,7 @@ static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const
 	{ ProfScope pf2(PF_X2); fix_cigar(r, qseq, tseq, &qshift, &tshift); }
 	qseq += qshift, tseq += tshift;
 	r->blen = r->mlen = 0;
-	if (loc && !(out_flags & MM355_OUT_MD) && !eqx) {   // the walk below and cs: on the device, for all regions of the batch at once (k_extra)
+	if (loc && !(out_flags & MM355_OUT_MD) && !eqx && mm355_extra_device_ok(p->cigar.data(), (int)p->cigar.size())) {   // the walk below and cs: on the device, for all regions of the batch at once (k_extra)
 		p->deferred = true;
 		p->x_strand = loc->strand; p->x_qst = loc->q_st + qshift; p->x_rid = loc->rid; p->x_tst = loc->t_st + tshift;
 		return;
@@ -1772,7 +1772,7 @@ void mm355_glue_extra_count(const ReadState &rs, int64_t *n_regions, int64_t *n_
 {
 	*n_regions = *n_segs = *n_cig = *n_cs = 0;
 	for (const Reg &r : rs.regs) if (r.p && r.p->deferred) {
-		++*n_regions; *n_segs += ((int64_t)r.p->cigar.size() + MM355_EXTRA_SEG - 1) / MM355_EXTRA_SEG;
+		++*n_regions; *n_segs += mm355_extra_n_segs(r.p->cigar.data(), (int)r.p->cigar.size());
 		*n_cig += (int64_t)r.p->cigar.size(); *n_cs += extra_cs_cap(r.p->cigar);
 	}
 }
