@@ -418,7 +418,7 @@ def main():
     if rank == 0 and not args.no_cpu and world == 1:   # (outside the timed region) the records of the reads the CPU sample will cover
         import mappy_rs
         gpu_sigs = []
-        n_chk = min(len(reads), 4 * 6144)
+        n_chk = len(reads) if args.cpu_seconds >= 60 else min(len(reads), 4 * 6144)   # a long CPU leg compares the whole read set
         for lo in range(0, n_chk, 6144):
             sub = reads[lo:min(n_chk, lo + 6144)]
             rarr, rlens, keep = _ffi.pack_reads(sub)
