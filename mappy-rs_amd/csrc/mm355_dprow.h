@@ -209,12 +209,13 @@ __global__ __launch_bounds__(64) void k_ksw_row(DpConst dc, const DpJobDev *jobs
 // owns columns [512 w, 512 w + 512) and sweeps the rows like k_ksw_row<4>; what a row needs from the panels to its left is three numbers --
 // the two running prefix maxima (E, E2) at the panel edge and H of the panel's last column (for the diagonal of the next row) -- which
 // the left neighbour leaves in LDS (one slot per row, rewritten in place by every panel in turn: a panel reads row q before it writes it,
-// and its right neighbour reads it only after that).  Panels run 64 rows apart: `done[w]` = rows finished by wave w, published every 64
-// rows; wave w waits for done[w - 1] before it loads the next 64 slots.  No barrier after the first one, every wave ends after qlen rows.
+// and its right neighbour reads it only after that).  Panels run 64 rows apart: `done[p]` = rows finished of panel p, published every 64
+// rows; panel p waits for done[p - 1] before it loads the next 64 slots.  No barrier after the first one, every wave ends after qlen rows.
 #define ROWL_NS 4
 #define ROWL_PANEL (128 * ROWL_NS)
 #define ROWL_WAVES 8
-#define ROWL_MAX_T (ROWL_PANEL * ROWL_WAVES)
+#define ROWL_MAX_PANELS 16           // targets beyond 4096: wave w takes panels w and w + 8 one after the other (the fills of ~5000 x 5000 between
+#define ROWL_MAX_T (ROWL_PANEL * ROWL_MAX_PANELS)   // anchors a max_gap apart were the last single-block jobs of the eight-wave LDS kernel, 41 ms each)
 #define ROWL_MAX_Q 5120
 
 template <bool RIGHT>
@@ -279,14 +280,14 @@ __global__ __launch_bounds__(64 * ROWL_WAVES) void k_ksw_rowl(DpConst dc, const 
                                                               const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr)
 {
 	__shared__ int32_t colC1[ROWL_MAX_Q], colC2[ROWL_MAX_Q], colH[ROWL_MAX_Q];
-	__shared__ int done[ROWL_WAVES], s_n;
+	__shared__ int done[ROWL_MAX_PANELS], s_n;
 	const int lane = threadIdx.x & 63, pw = threadIdx.x >> 6;
 	if ((int)blockIdx.x >= n_jobs) return;
 	__builtin_amdgcn_s_setprio(3);                     // a few hundred long sweeps beside the wide grids of the round
 	const int jid = job_ids[blockIdx.x];
 	const DpJobDev jb = jobs[jid];
 	const uint8_t *target = tbase + jb.toff, *query = qbase + jb.qoff;
-	if (threadIdx.x < ROWL_WAVES) done[threadIdx.x] = 0;
+	if (threadIdx.x < ROWL_MAX_PANELS) done[threadIdx.x] = 0;
 	if (threadIdx.x == 0) s_n = 0;
 	__syncthreads();
 	bool n = false;
@@ -302,9 +303,13 @@ __global__ __launch_bounds__(64 * ROWL_WAVES) void k_ksw_rowl(DpConst dc, const 
 	K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u; K.q1i = dc.q; K.q2i = dc.q2;
 	const int tstride = (jb.tlen + 15) / 16 * 16 + 16;
 	int32_t score = KSW_NEG_INF;
-	if (jb.flag & EZ_RIGHT) rowl_panel<true>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, pw, colC1, colC2, colH, done, score);
-	else rowl_panel<false>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, pw, colC1, colC2, colH, done, score);
-	if (lane == 0 && (pw + 1) * ROWL_PANEL >= jb.tlen) {   // the wave of the last panel
+	bool last_mine = false;
+	for (int pn = pw; pn * ROWL_PANEL < jb.tlen; pn += ROWL_WAVES) {   // (a second panel only for targets beyond 4096)
+		if (jb.flag & EZ_RIGHT) rowl_panel<true>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, pn, colC1, colC2, colH, done, score);
+		else rowl_panel<false>(dc, K, jb, query, target, pbase + jb.p_off, tstride, any_n, lane, pn, colC1, colC2, colH, done, score);
+		last_mine = (pn + 1) * ROWL_PANEL >= jb.tlen;
+	}
+	if (lane == 0 && last_mine) {   // the wave of the last panel
 		mm355_dpres_t o;
 		o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = KSW_NEG_INF; o.score = score; o.reach_end = 0;
 		o.n_cigar = jb.tlen - 1; o.cigar_off = jb.qlen - 1;   // start cell for k_ksw_backtrack (not z-dropped, not KSW_EZ_EXTZ_ONLY)

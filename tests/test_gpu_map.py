@@ -325,8 +325,9 @@ def test_dp_kernel_parity(ont):
     # the same with targets of 1025..4096 bases: the eight-wave row sweep k_ksw_rowl (one 512-column panel per wave, 64-row batches):
     # every panel border, one to eight panels, queries shorter than / equal to / just over one batch and up to the LDS limit of 5120 rows
     n_short = len(jobs)
-    for i in range(44):
-        tl = int([1025, 1536, 1537, 2047, 2048, 2049, 2560, 2561, 3000, 3583, 3584, 3585, 4000, 4095, 4096][i % 15]) if i < 30 else int(rng.integers(1025, 4097))
+    for i in range(52):   # (the last eight: targets beyond 4096 -- a wave takes a second panel)
+        tl = int([1025, 1536, 1537, 2047, 2048, 2049, 2560, 2561, 3000, 3583, 3584, 3585, 4000, 4095, 4096][i % 15]) if i < 30 else int(rng.integers(1025, 4097)) if i < 44 else \
+             int([4097, 4608, 4609, 5000, 5120, 6000, 7000, 8192][i - 44])
         t = S.random_codes(rng, tl)
         q = S.mutate(t, rng, 0.06, 0.03, 0.03)
         if i % 5 == 0:
@@ -337,6 +338,8 @@ def test_dp_kernel_parity(ont):
             q = q[:int([1, 63, 64, 65, 128, 700][(i // 8) % 6])]               # a few rows only
         if i % 8 == 6:
             q = S.random_codes(rng, int(rng.integers(1, 5121)))                # unrelated query, any length ratio
+        if len(q) > 5120:
+            q = q[:5120]                                                       # the kernel's row limit (its LDS column buffers)
         if i % 6 == 0:
             q[len(q) // 2:len(q) // 2 + 3] = 4
         if i % 7 == 0:
