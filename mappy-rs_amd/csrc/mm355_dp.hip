@@ -447,7 +447,7 @@ struct DpClass { int cap, kind, np; };   // kind 0: k_ksw_reg, 1: k_ksw_extd2<64
 static const DpClass DP_CLASSES[] = { {128, 0, 1}, {256, 0, 2}, {512, 0, 4}, {1024, 0, 8}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 static const DpClass DP_CLASSES_LEGACY[] = { {256, 1, 0}, {512, 1, 0}, {1024, 1, 0}, {1024, 1, 0}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 #define DP_N_CLASS 7
-#define DP_N_GROUP 19                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills), 17 = k_ksw_rowl (the same, targets 1025..4096)
+#define DP_N_GROUP 19                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills), 17 = k_ksw_rowl (the same, targets 1025..8192)
 #define DP_G_ROW2 14
 #define DP_G_ROW4 15
 #define DP_G_ROW8 16

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void k_ksw_row(DpConst dc, const DpJobDev *jobs
 }
 
 // ------------------------------------------------------------------ long targets: eight waves, one 512-column panel each
-// The same row sweep for full-band approximate fills with targets of 1025..4096 bases (on GRCh38-scale ONT batches: the fills between
+// The same row sweep for full-band approximate fills with targets of 1025..8192 bases (on GRCh38-scale ONT batches: the fills between
 // distant anchors, ~3000 x 3000, that used to be the latency tail of every extension round on the eight-wave anti-diagonal kernel).  Wave w
 // owns columns [512 w, 512 w + 512) and sweeps the rows like k_ksw_row<4>; what a row needs from the panels to its left is three numbers --
 // the two running prefix maxima (E, E2) at the panel edge and H of the panel's last column (for the diagonal of the next row) -- which
