@@ -388,7 +388,10 @@ __device__ __forceinline__ bool dp_segment(DpRun &R, DpSt &S, const DpK &K, cons
 		if constexpr (WIN) { while (R.st - 1 - R.base >= 128) dp_rebase(R, S, K, lane); }
 		const int base = WIN? R.base : 0;
 		const int jlo = (R.st - base) >> 7, jhi = (R.en - base) >> 7;
-		if (WIDE? (!WIN && jhi - jlo < DP_MAX_TIGHT) : (jlo != JLO || jhi != JHI)) return false;   // (WIN runs on the catch-all instance only)
+		// (WIN runs on catch-all instances only: blocks 0..6 or 1..7 -- a 752-cell band never touches both end blocks of the window at once --
+		// and all eight for bands close to the limit; an instance is left when the band moves out of its blocks or fits a narrower one)
+		if (WIN) { if (jlo < JLO || jhi > JHI || (JHI - JLO == NP - 1 && (jhi < NP - 1 || jlo > 0))) return false; }
+		else if (WIDE? jhi - jlo < DP_MAX_TIGHT : (jlo != JLO || jhi != JHI)) return false;
 	}
 }
 
@@ -410,7 +413,11 @@ __device__ __forceinline__ void dp_sweep(DpRun &R, DpSt &S, const DpK &K, const 
 		const int base = WIN? R.base : 0;
 		const int jlo = (R.st - base) >> 7, jhi = (R.en - base) >> 7;
 		bool done;
-		if constexpr (WIN) done = dp_segment<NP, EXACT, RIGHT, 0, NP - 1, true, true>(R, S, K, lane);
+		if constexpr (WIN) {
+			if (jhi < NP - 1) done = dp_segment<NP, EXACT, RIGHT, 0, NP - 2, true, true>(R, S, K, lane);
+			else if (jlo > 0) done = dp_segment<NP, EXACT, RIGHT, 1, NP - 1, true, true>(R, S, K, lane);
+			else done = dp_segment<NP, EXACT, RIGHT, 0, NP - 1, true, true>(R, S, K, lane);
+		}
 		else if (NP > DP_MAX_TIGHT && jhi - jlo >= DP_MAX_TIGHT) done = dp_segment<NP, EXACT, RIGHT, 0, NP - 1, true, false>(R, S, K, lane);
 		else done = dp_dispatch<NP, EXACT, RIGHT, 0, 0, false>(jlo, jhi, R, S, K, lane);
 		if (done) break;
