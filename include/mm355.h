@@ -156,6 +156,11 @@ typedef struct {
 	int64_t n_ext_rounds;                        /* extension rounds of the last call (the reference has no bound on them) */
 	int64_t n_sort_fast_reads, n_sort_tie_reads; /* anchor sort: reads sorted by the segmented radix sort / of those, reads with equal keys
 	                                                whose equal-key runs went through the literal radix_sort_128x emulation */
+	/* mg_lchain_rmq on the device (row a9): kernel time, reads re-chained there, reads handed to the literal host implementation because the
+	 * device could not prove its range-minimum answer unique (or ran out of LDS capacity), window elements looked at */
+	double ms_rmq;
+	int64_t n_rmq_reads, n_rmq_host, rmq_scanned;
+	double host_cpu_ms;                          /* CPU time (not wall) the host tail of the last call spent, summed over the pool threads */
 } mm355_stats_t;
 
 /* sketch: minimizers of each read (mm_sketch). mz_off[n_reads+1] host array is filled; mz = (x,y) pairs */
@@ -173,6 +178,13 @@ int mm355_stage_chain(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_read
 int mm355_stage_chains(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
                        const int32_t *lens, int64_t *u_off, uint64_t *u, int64_t u_cap,
                        int64_t *a_off, uint64_t *a, int64_t a_cap);
+/* chains after the long-join re-chain (mg_lchain_rmq on the chained anchors when U:map.c::mm_map_frag's rescue test fires) or, for MM_F_RMQ
+ * presets, after mg_lchain_rmq as the primary chainer: u and the compacted anchors as mm355_stage_chains returns them, plus state[r]:
+ * 0 = not re-chained, 1 = re-chained on the device, 2 = left to the literal host implementation (equal range-minimum priorities): a[] then
+ * holds the read's anchors sorted by x and u_off[r+1] == u_off[r] */
+int mm355_stage_rmq(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
+                    const int32_t *lens, int64_t *u_off, uint64_t *u, int64_t u_cap,
+                    int64_t *a_off, uint64_t *a, int64_t a_cap, int32_t *state);
 /* one batch of banded extension problems (ksw_extd2_sse semantics); see mm355_dpjob_t */
 typedef struct {
 	int32_t qlen, tlen;

@@ -1,0 +1,160 @@
+// mm355_btcore.h -- U:lchain.c::mg_chain_backtrack + compact_a for one read by one wave; shared by k_backtrack (after mg_lchain_dp,
+// mm355_kernels.hip) and k_rmq_backtrack (after mg_lchain_rmq, mm355_rmq.hip).
+#pragma once
+#include "mm355_wave.h"
+#ifndef KPROF_BEGIN
+#define KPROF_BEGIN(bt) unsigned long long *kp_ = (bt).prof; unsigned long long kp_t_ = kp_? (unsigned long long)clock64() : 0
+#define KPROF(i) do { if (kp_ && (threadIdx.x & 63) == 0) { const unsigned long long t_ = (unsigned long long)clock64(); atomicAdd(&kp_[i], t_ - kp_t_); atomicMax(&kp_[32 + (i)], t_ - kp_t_); kp_t_ = t_; } } while (0)
+#endif
+// ------------------------------------------------------------------ a8: mg_chain_backtrack + compact_a
+#define Z_STAGE 2048      // 16 KB: with SortLds five blocks per CU (4096 entries: three)
+// One wave: backtrack + compact_a of read r over its first n anchors (f / p filled by a chaining kernel); max_drop = the band width
+// that chainer used (U:lchain.c: mg_lchain_dp passes bw, mg_lchain_rmq passes its own bw).  Leaves n_u[r], n_v[r], u[] and the compacted
+// anchors in place of a[].
+struct BtLds { SortLds L; uint64_t zstage[Z_STAGE]; int s_nu, s_nv; };
+__device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &bt, const DevAnchors &an, int *err, BtLds *S, const int r, const int n, const int max_drop)
+{
+	SortLds &L = S->L;
+	uint64_t *zstage = S->zstage;
+	int &s_nu = S->s_nu, &s_nv = S->s_nv;
+	const int lane = threadIdx.x;
+	const int64_t o = an.aoff[r];
+	if (lane == 0) { an.n_u[r] = 0; an.n_v[r] = 0; }
+	if (n == 0) return;
+	const mm128 *a = an.a + o;
+	const int32_t *f = an.f + o, *p = an.p + o;
+	uint64_t *z = an.z + o;
+	uint8_t *t8 = an.t8 + o;
+	int32_t *vi = an.vi + o;
+	mm128 *b = an.b + o;
+	uint64_t *u = an.u + o, *u2 = an.u2 + o;
+	mm128 *wk = an.wk + o;
+	const int min_sc = pr.min_chain_score, min_cnt = pr.min_cnt;
+	KPROF_BEGIN(bt);
+	// z[] = (f, i) for f >= min_sc, in anchor order
+	int n_z = 0;
+	for (int base = 0; base < n; base += WAVE) {
+		int i = base + lane;
+		int32_t fi = i < n? f[i] : INT32_MIN;
+		bool keep = i < n && fi >= min_sc;
+		unsigned long long mask = __ballot(keep);
+		if (keep) z[n_z + __popcll(mask & LANE_LT_MASK(lane))] = (uint64_t)(uint32_t)fi << 32 | (uint32_t)i;
+		n_z += __popcll(mask);
+	}
+	__syncthreads();
+	KPROF(0);
+	if (n_z == 0) return;
+	WalkScratch ws; ws.out = u2; ws.fpos = (uint32_t*)vi; ws.rank = (uint32_t*)(an.v + o); ws.flab = t8; ws.tcnt = 0;   // v[] is dead after the DP fill
+	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws);
+	if (lane == 0 && n_z > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
+	__syncthreads();
+	// The walk below is a pointer chase (one lane): every step used to be two dependent HBM/L2 round trips (p[i], then f and the mark of
+	// the node it points to).  All three now sit in ONE 8-byte word per anchor -- pf[i] = { (p + 1) | mark << 30, f } in the u2[] region,
+	// free between the two sorts -- so a step is one load; the nodes a probe visits are remembered in LDS (the sort stage, idle here), so
+	// the reset and collect passes of U:lchain.c::mg_chain_bk_end / mg_chain_backtrack store without chasing again; and the "already used"
+	// test of the n_z candidates is prefetched 64 at a time by the whole wave (a mark is final once it is 1, only zeros are re-read).
+	int2 *pf = (int2*)u2;
+	for (int i = lane; i < n; i += WAVE) pf[i] = make_int2(p[i] + 1, f[i]);
+	__syncthreads();
+	KPROF(1);
+	uint32_t *visited = (uint32_t*)zstage;                    // 2 * Z_STAGE entries
+	const int VCAP = 2 * Z_STAGE;
+	int n_v = 0, n_u = 0;
+#define PF_P(w) ((int)((uint32_t)(w).x & 0x3fffffffu) - 1)
+#define PF_MARK(w) ((uint32_t)(w).x >> 30)
+	for (int kb = n_z - 1; kb >= 0; kb -= WAVE) {
+		const int kk = kb - lane;
+		uint64_t zk = 0; bool cand = false;
+		if (kk >= 0) { zk = z[kk]; cand = PF_MARK(pf[(uint32_t)zk]) == 0; }
+		unsigned long long todo = __ballot(cand);
+		if (todo == 0) continue;                                  // wave-uniform
+		const uint32_t zlo = (uint32_t)zk, zhi = (uint32_t)(zk >> 32);
+		if (lane == 0) {
+			while (todo) {
+				const int l = __builtin_ctzll(todo); todo &= todo - 1;
+				const int zi = (int)(uint32_t)__builtin_amdgcn_readlane((int)zlo, l);
+				const int32_t zx = (int32_t)__builtin_amdgcn_readlane((int)zhi, l);
+				int2 w = pf[zi];
+				if (PF_MARK(w) != 0) continue;
+				// mg_chain_bk_end
+				int i = zi, end_i, max_i = zi, nvis = 0, q = 0;
+				int32_t max_s = 0;
+				bool over = false;
+				for (;;) {
+					pf[i].x = w.x | (int)(2u << 30);                      // t[i] = 2
+					if (nvis < VCAP) visited[nvis] = (uint32_t)i; else over = true;
+					++nvis;
+					end_i = i = PF_P(w);
+					int32_t sv = zx;
+					if (i >= 0) { w = pf[i]; sv = zx - w.y; }
+					if (sv > max_s) { max_s = sv; max_i = i; q = nvis; }
+					else if (max_s - sv > max_drop) break;
+					if (i < 0 || PF_MARK(w) != 0) break;
+				}
+				const int n_v0 = n_v;
+				if (!over) {   // marks: the first q visited nodes join the chain (1), the others are released (0)
+					for (int t = 0; t < nvis; ++t) {
+						const uint32_t vn = visited[t];
+						const uint32_t keep = t < q? 1u : 0u;
+						pf[vn].x = (int)(((uint32_t)pf[vn].x & 0x3fffffffu) | keep << 30);
+						if (keep) vi[n_v++] = (int)vn;
+					}
+				} else {       // a probe longer than the LDS list: the reference's two passes, chasing again
+					for (i = zi; i >= 0 && i != end_i; i = PF_P(pf[i])) pf[i].x = (int)((uint32_t)pf[i].x & 0x3fffffffu);
+					for (i = zi; i != max_i; i = PF_P(pf[i])) { vi[n_v++] = i; pf[i].x = (int)(((uint32_t)pf[i].x & 0x3fffffffu) | 1u << 30); }
+				}
+				const int32_t sc = q > 0? max_s : 0;
+				if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt)
+					u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)(n_v - n_v0);
+				else n_v = n_v0;
+			}
+			s_nu = n_u; s_nv = n_v;
+		}
+		__syncthreads();
+		n_u = s_nu; n_v = s_nv;
+	}
+#undef PF_P
+#undef PF_MARK
+	if (lane == 0) { s_nu = n_u; s_nv = n_v; }
+	__syncthreads();
+	n_u = s_nu; n_v = s_nv;
+	KPROF(2);
+	if (n_u == 0) return;
+	// compact_a: chains written forward; then chains re-ordered by the x of their first anchor
+	// (1) per-chain start offsets into wk[].y (k<<32|i), b[] filled in forward order
+	if (lane == 0) {
+		int k = 0;
+		for (int i = 0; i < n_u; ++i) { wk[i].y = (uint64_t)(uint32_t)k << 32 | (uint32_t)i; k += (int32_t)u[i]; }
+	}
+	__syncthreads();
+	for (int c = 0; c < n_u; ++c) {
+		const int k0 = (int)(wk[c].y >> 32), ni = (int32_t)u[c];
+		for (int j = lane; j < ni; j += WAVE) b[k0 + j] = a[vi[k0 + (ni - j - 1)]];
+	}
+	__syncthreads();
+	for (int c = lane; c < n_u; c += WAVE) wk[c].x = b[wk[c].y >> 32].x;
+	__syncthreads();
+	wave_radix_sort(wk, (uint32_t)n_u, mm_key_x(), &L, (mm128*)zstage, (uint32_t)(Z_STAGE / 2));
+	__syncthreads();
+	// (2) final order: anchors go back into a[] region as the compacted list (written to an.a, length n_v)
+	mm128 *aout = an.a + o;
+	if (lane == 0) {
+		int k = 0;
+		for (int i = 0; i < n_u; ++i) {
+			const int j = (int)(uint32_t)wk[i].y;
+			u2[i] = u[j];
+			wk[i].x = (uint64_t)(uint32_t)k;   // destination offset
+			k += (int32_t)u[j];
+		}
+	}
+	__syncthreads();
+	for (int c = 0; c < n_u; ++c) {
+		const int src = (int)(wk[c].y >> 32), dst = (int)wk[c].x, ni = (int32_t)u2[c];
+		for (int j = lane; j < ni; j += WAVE) aout[dst + j] = b[src + j];
+	}
+	__syncthreads();
+	for (int c = lane; c < n_u; c += WAVE) u[c] = u2[c];
+	if (lane == 0) { an.n_u[r] = n_u; an.n_v[r] = n_v; }
+	KPROF(3);
+}
+

@@ -66,7 +66,7 @@ __device__ inline int8_t SB(uint64_t w, int i) { return (int8_t)(w >> (8 * i)); 
 // otherwise be the tail of the whole launch.
 // per-launch-group cell counters are spread over DP_CTR_SPREAD words (slot = block & 15): every alignment adds once, and a single word
 // takes only ~88 atomics per microsecond -- 150 000 alignments of one launch on one word were 1.7 ms of atomics
-#define DP_CTR_SPREAD 16
+#define DP_CTR_SPREAD CTR_SPREAD
 template <int NT>
 __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
                                                     const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, int32_t *offbase,
@@ -587,17 +587,15 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4, *d_dense = c->counters.as<unsigned long long>() + 5;
 	double t_turn0 = 0;
 	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
-	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + 64;   // cells per group [24][DP_CTR_SPREAD]
+	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + CTR_GCELLS_OFF;   // cells per group [CTR_GROUPS][DP_CTR_SPREAD]
 	HIPCHK(hipMemsetAsync(d_cells, 0, 8, c->st));
-	HIPCHK(hipMemsetAsync(d_gcells, 0, 192 * DP_CTR_SPREAD, c->st));
+	HIPCHK(hipMemsetAsync(d_gcells, 0, CTR_GCELLS_WORDS * 8, c->st));
 	// every group gets its own HIP stream: the few long alignments of the big classes run concurrently with the thousands of
 	// short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
 	HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
 	if (c->dp_up_ev == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_up_ev, hipEventDisableTiming));
 	HIPCHK(hipEventRecord(c->dp_up_ev, c->st));   // the group streams start after the uploads
 	(void)hipFuncSetAttribute((const void*)k_ksw_extd2<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 12);
-	// groups share a few streams (launch order = big problems first): 0 the wide approx classes (targets <= 256), 1 every exact
-	// class <= 1024, 2 approx 512/1024, 3.. the eight-wave kernels (few long alignments each: they overlap one another).  MM355_DP_STREAMS=0: one stream per group.
 	// Streams (created back to back at context creation, so they sit on different hardware queues): 0 approx targets <= 256 (the wide
 	// grids), 1 every exact register class, 2 approx 1024, 3 approx 512, 4 the eight-wave kernel.  The long-target classes (4096 /
 	// 12288 LDS state, HBM state; approx and exact) are ONE launch: a few dozen latency-bound alignments that must not queue behind
@@ -725,10 +723,10 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
 	}
 	HIPCHK(hipGetLastError());
-	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 64 + 192 * DP_CTR_SPREAD)) return MM355_ENOMEM;
+	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 64 + CTR_GCELLS_WORDS * 8)) return MM355_ENOMEM;
 	unsigned long long *ctr = (unsigned long long*)((char*)c->h_res.p + n * sizeof(mm355_dpres_t));   // pinned landing zone of the counters
 	HIPCHK(hipMemcpyAsync(ctr, d_cells, 16, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, 192 * DP_CTR_SPREAD, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(ctr + 2, d_gcells, CTR_GCELLS_WORDS * 8, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(c->h_res.p, c->dp_res.p, n * sizeof(mm355_dpres_t), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
 	if (const char *dump = getenv("MM355_DP_DUMP_BT")) {   // diagnostics: the direction matrices of this launch group, raw
@@ -952,7 +950,7 @@ extern "C" int mm355_stage_dp(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t 
 	if (c == 0 || mo == 0) return MM355_EINVAL;
 	HIPCHK(hipSetDevice(c->dev));
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
-	HIPCHK(hipMemsetAsync(c->counters.p, 0, 256, c->st));
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, CTR_BYTES, c->st));
 	if (c->dp_q.ensure((size_t)n_q + 64) || c->dp_t.ensure((size_t)n_t + 64)) return MM355_ENOMEM;
 	if (n_q) HIPCHK(hipMemcpyAsync(c->dp_q.p, qcodes, n_q, hipMemcpyHostToDevice, c->st));
 	if (n_t) HIPCHK(hipMemcpyAsync(c->dp_t.p, tcodes, n_t, hipMemcpyHostToDevice, c->st));

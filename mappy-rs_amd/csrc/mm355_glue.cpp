@@ -809,7 +809,7 @@ void mm355_glue_chain_rmq(const mm355_index *mi, const mm355_mapopt_t *opt, Read
 }
 
 // ================================================================== stage 1: after the chain kernels
-void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs)
+void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs, int rmq_state)
 {
 	const int qlen = rs.qlen;
 	uint32_t hash = 0;   // qname is NULL through the reference (the L2 crate passes null)
@@ -818,7 +818,10 @@ void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, Read
 	const float pen_gap = (float)(opt->chain_gap_scale * 0.01 * mi->k), pen_skip = (float)(opt->chain_skip_scale * 0.01 * mi->k);
 	int n_regs0 = (int)rs.u.size();
 	{ ProfScope pf(PF_PRE_RMQ);
-	if (opt->bw_long > opt->bw && (opt->flag & (MMF_SPLICE | MMF_SR | MMF_NO_LJOIN)) == 0 && n_regs0 > 1) {
+	if (rmq_state == 2) {   // MM355_RMQ_HOST: the device sorted the chained anchors and left the chaining to the literal code
+		rechain_rmq(opt->max_gap, opt->rmq_inner_dist, opt->bw_long, opt->max_chain_skip, opt->rmq_size_cap, opt->min_cnt, opt->min_chain_score,
+		            pen_gap, pen_skip, rs.a, rs.u);
+	} else if (rmq_state < 0 && opt->bw_long > opt->bw && (opt->flag & (MMF_SPLICE | MMF_SR | MMF_NO_LJOIN)) == 0 && n_regs0 > 1) {
 		int32_t st = (int32_t)rs.a[0].y, en = (int32_t)rs.a[(int32_t)rs.u[0] - 1].y;
 		if (qlen - (en - st) > opt->rmq_rescue_size || en - st > qlen * opt->rmq_rescue_ratio) {
 			int64_t n_a = 0;

@@ -84,8 +84,11 @@ struct GlueStats { int64_t n_rmq = 0, n_rounds = 0, n_jobs = 0; };
 
 // stage 0, MM_F_RMQ only: rs.a = the read's sorted anchors -> chained anchors + rs.u (U:lchain.c::mg_lchain_rmq as primary chainer)
 void mm355_glue_chain_rmq(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs);
-// stage 1 (after the chain kernels): re-chain (if triggered), regions, pre-DP selection; leaves rs.regs ready for DP
-void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs);
+// stage 1 (after the chain kernels): re-chain (if triggered), regions, pre-DP selection; leaves rs.regs ready for DP.
+// rmq_state: what the device stage (mm355_run_rmq) did with this read's long-join re-chain -- MM355_RMQ_KEEP / _DONE: nothing left to do
+// here; MM355_RMQ_HOST: rs.a holds the chained anchors already sorted by x, mg_lchain_rmq runs here; -1: the stage did not run, the
+// rescue test, the sort and mg_lchain_rmq all run here (MM355_RMQ_ON_HOST=1)
+void mm355_glue_pre_align(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs, int rmq_state);
 // stage 2: advance the skeleton of one read as far as cached DP results allow; appends missing DP problems to `reqs`.
 // returns true when the read needs no more DP.
 bool mm355_glue_align_step(const mm355_index *mi, const mm355_mapopt_t *opt, int read_id, ReadState &rs, std::vector<DpReq> &reqs, int flags);

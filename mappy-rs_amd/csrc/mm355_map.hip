@@ -295,7 +295,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	c->n_arena = 0;
 	c->stats.n_reads = n_reads; c->stats.n_bases = c->hb.n_bases;
-	HIPCHK(hipMemsetAsync(c->counters.p, 0, 4096, c->st));
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, CTR_BYTES, c->st));
 	HIPCHK(hipMemsetAsync(c->err.p, 0, 16, c->st));
 	const std::vector<int32_t> &status = c->hb.status;
 	std::vector<int32_t> dl(c->hb.rlen);
@@ -313,11 +313,12 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		FRONT_STAGE("f:seeds", mm355_run_seeds(c, pr));
 		FRONT_STAGE("f:expand", mm355_run_expand(c, pr));
 		FRONT_STAGE("f:sort", mm355_run_sort(c));
-		if (rmq_chain) FRONT_STAGE("f:chain", mm355_run_chain_skip(c));   // asm presets: chained on the host from the sorted anchors
+		if (rmq_chain) FRONT_STAGE("f:chain", mm355_run_chain_skip(c));   // asm presets: mg_lchain_rmq is the primary chainer (next stage)
 		else {
 			FRONT_STAGE("f:chain", mm355_run_chain(c, pr));
 			FRONT_STAGE("f:backtrack", mm355_run_backtrack(c, pr));
 		}
+		FRONT_STAGE("f:rmq", mm355_run_rmq(c, mo, pr));                  // row a9: long-join re-chain / primary RMQ chainer on the device
 		FRONT_STAGE("f:codes", mm355_run_read_codes(c));
 #undef FRONT_STAGE
 	}
@@ -369,7 +370,13 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		r.u.assign(pu + uo[i], pu + uo[i + 1]);
 		r.a.assign(pa + vo[i], pa + vo[i + 1]);
 		r.mini_pos.assign(pm + mo_[i], pm + mo_[i + 1]); }
-		if (r.qlen > 0) { if (rmq_chain) mm355_glue_chain_rmq(mi, mo, r); mm355_glue_pre_align(mi, mo, r); } else r.aligned = true;
+		if (r.qlen > 0) {
+			const int rst = hb.rmq_state.empty()? -1 : (int)hb.rmq_state[i];
+			if (rmq_chain) {   // primary RMQ chainer: on the device unless it handed the read back (or the stage is switched off)
+				if (rst != 1) mm355_glue_chain_rmq(mi, mo, r);
+				mm355_glue_pre_align(mi, mo, r, 0);
+			} else mm355_glue_pre_align(mi, mo, r, rst);
+		} else r.aligned = true;
 	});
 	double ms_host = now_ms() - t_host0;
 	tv_pre = now_ms() - tv0; trace_add(c, "pre", tv0, now_ms());

@@ -35,6 +35,7 @@ struct HostBatch {            // packed reads of one sub-batch
 	int64_t n_reads = 0, n_bytes = 0, n_bases = 0;
 	std::vector<uint8_t> seq; std::vector<int64_t> roff; std::vector<int32_t> rlen, order;
 	std::vector<int32_t> n_mz, n_a, rep_len, n_mini, n_u, n_v, status;
+	std::vector<uint8_t> rmq_state;   // per read after mm355_run_rmq: MM355_RMQ_KEEP / _DONE / _HOST (empty: the stage did not run, the host decides)
 	std::vector<int64_t> aoff;
 	int64_t tot_a = 0;
 };
@@ -42,6 +43,24 @@ struct HostBatch {            // packed reads of one sub-batch
 // a batch of reads resident in HBM that is not the context's current one (mm355_batch_select): the packed reads, their tables and
 // the host copy; every working buffer stays with the context
 struct ResidentBatch { HostBatch hb; DBuf seq, roff, rlen, order, ck_read, ck_start, ck_r0; int64_t n_chunks = 0; };
+
+// Layout of mm355_ctx::counters (u64 words), one definition for every memset / kernel argument / read-back:
+//   [0..7]    seed stage (n_hit, n_a_multi, ...), the extension's total cells (4) and dense-arena pointer (5), k_chain_segments' two list lengths (6)
+//   CTR_GCELLS_OFF   cells per extension launch group, [CTR_GROUPS][CTR_SPREAD] (slot = block & (CTR_SPREAD - 1): one word takes ~88 atomics / us)
+//   CTR_PAIRS_OFF    chaining pair evaluations, CTR_PAIRS_WORDS slots (slot = block & 63)
+//   CTR_RMQ_OFF      window elements looked at by k_rmq_dp, CTR_RMQ_WORDS slots
+#define CTR_HEAD_WORDS   64
+#define CTR_SPREAD       16
+#define CTR_GROUPS       24
+#define CTR_GCELLS_OFF   CTR_HEAD_WORDS
+#define CTR_GCELLS_WORDS (CTR_GROUPS * CTR_SPREAD)
+#define CTR_PAIRS_OFF    (CTR_GCELLS_OFF + CTR_GCELLS_WORDS)
+#define CTR_PAIRS_WORDS  64
+#define CTR_RMQ_OFF      (CTR_PAIRS_OFF + CTR_PAIRS_WORDS)
+#define CTR_RMQ_WORDS    64
+#define CTR_WORDS        (CTR_RMQ_OFF + CTR_RMQ_WORDS)
+#define CTR_BYTES        (CTR_WORDS * 8)
+static_assert(CTR_GCELLS_OFF >= 8 && CTR_PAIRS_OFF == CTR_GCELLS_OFF + CTR_GCELLS_WORDS && CTR_RMQ_OFF == CTR_PAIRS_OFF + CTR_PAIRS_WORDS, "counter regions must be disjoint");
 
 struct mm355_ctx {
 	const mm355_index *mi = 0;
@@ -67,6 +86,7 @@ struct mm355_ctx {
 	hipEvent_t dp_up_ev = 0;      // dense CIGAR arenas of the launches of the current batch (results point into them)
 	DBuf kprof;    // MM355_KPROF phase counters (64 x u64)
 	DBuf rq;       // per-read query codes fwd|rev
+	DBuf rmq_list, rmq_flag; HBuf h_rmq;   // device mg_lchain_rmq: listed reads, per-read state
 	DBuf x_jobs, x_cig, x_cs, x_out, x_dense; HBuf h_xjobs, h_xcig, h_xout, h_xcs;   // k_extra (mm_update_extra's walk + cs on the device)
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
@@ -88,6 +108,7 @@ int mm355_run_sort(mm355_ctx *ctx);
 int mm355_run_chain(mm355_ctx *ctx, const DevParams &pr);
 int mm355_run_backtrack(mm355_ctx *ctx, const DevParams &pr);
 int mm355_run_chain_skip(mm355_ctx *c);
+int mm355_run_rmq(mm355_ctx *c, const mm355_mapopt_t *mo, const DevParams &pr);   // mg_lchain_rmq on the device: long-join re-chain, or the primary chainer of MM_F_RMQ presets
 
 // time one launch group on the context's stream with HIP events (the stream the kernels are launched on)
 // Stage timers.  EvTimer records a pair of events around the launches of a stage and does NOT synchronise: the pairs are turned into

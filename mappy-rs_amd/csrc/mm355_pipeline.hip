@@ -8,6 +8,7 @@
 #include <numeric>
 #include <mutex>
 #include "mm355_pipeline.h"
+#include "mm355_rmq.h"
 
 // ------------------------------------------------------------------ options -> kernel parameters
 int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi)
@@ -105,7 +106,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	c->dix.pos = (const uint64_t*)rp.pos; c->dix.S = (const uint32_t*)rp.S;
 	c->dix.seq_off = (const uint64_t*)rp.seq_off; c->dix.seq_len = (const uint32_t*)rp.seq_len;
 	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
-	if (c->counters.ensure(4096) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
+	if (c->counters.ensure(CTR_BYTES) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
 	if (getenv("MM355_KPROF")) { if (c->kprof.ensure(512)) { delete c; return MM355_ENOMEM; } HIPCHK(hipMemset(c->kprof.p, 0, 512)); }
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	*out = c;
@@ -199,10 +200,10 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 	DBuf *bufs[] = { &c->sort_tasks, &c->sort_tmp, &c->sort_flag, &c->tie_list, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
-		&c->kprof, &c->d_chunks, &c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack, &c->x_jobs, &c->x_cig, &c->x_cs, &c->x_out, &c->x_dense };
+		&c->kprof, &c->d_chunks, &c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack, &c->rmq_list, &c->rmq_flag, &c->x_jobs, &c->x_cig, &c->x_cs, &c->x_out, &c->x_dense };
 	for (DBuf *b : bufs) b->release();
 	for (ResidentBatch &r : c->slots) { r.seq.release(); r.roff.release(); r.rlen.release(); r.order.release(); r.ck_read.release(); r.ck_start.release(); r.ck_r0.release(); }
-	c->h_xjobs.release(); c->h_xcig.release(); c->h_xout.release(); c->h_xcs.release(); c->h_tasks.release(); c->h_chunks.release(); c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
+	c->h_rmq.release(); c->h_xjobs.release(); c->h_xcig.release(); c->h_xout.release(); c->h_xcs.release(); c->h_tasks.release(); c->h_chunks.release(); c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
 	for (int i = 0; i < 16; ++i) if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]);
 	for (int i = 0; i < 24; ++i) { if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); if (c->dp_ev0[i]) (void)hipEventDestroy(c->dp_ev0[i]); if (c->dp_ev1[i]) (void)hipEventDestroy(c->dp_ev1[i]); }
 	if (c->dp_up_ev) (void)hipEventDestroy(c->dp_up_ev);
@@ -270,7 +271,7 @@ int mm355_run_pack(mm355_ctx *c, int64_t n_reads, const char *const *seqs, const
 		HIPCHK(hipMemcpyAsync(c->rlen.p, hb.rlen.data(), n_reads * 4, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipMemcpyAsync(c->order.p, hb.order.data(), n_reads * 4, hipMemcpyHostToDevice, c->st));
 	}
-	HIPCHK(hipMemsetAsync(c->counters.p, 0, 4096, c->st));
+	HIPCHK(hipMemsetAsync(c->counters.p, 0, CTR_BYTES, c->st));
 	HIPCHK(hipMemsetAsync(c->err.p, 0, 16, c->st));
 	c->stats.n_reads = n_reads; c->stats.n_bases = bases;
 	{   // chunk table of the sketch kernel: longest reads first so that a wave holds chunks of similar cost
@@ -422,13 +423,13 @@ int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
 		if (n_chunks) HIPCHK(hipMemcpyAsync(c->d_chunks.p, hc, n_chunks * 8, hipMemcpyHostToDevice, c->st));
 	}
 	// segment lists live in scratch that is free at this point: z (8 B/anchor) and wk (16 B/anchor) hold >= tot_a/2 16-byte entries each
-	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + 448, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->d_chunks.p, (int)n_chunks, c->st)) return MM355_EHIP; }
+	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->d_chunks.p, (int)n_chunks, c->st)) return MM355_EHIP; }
 	HIPCHK(hipGetLastError());
-	unsigned long long pairs[64];   // spread over 64 words (slot = block & 63): one word takes ~88 atomics per microsecond
-	HIPCHK(hipMemcpyAsync(pairs, c->counters.as<unsigned long long>() + 448, 512, hipMemcpyDeviceToHost, c->st));
+	unsigned long long pairs[CTR_PAIRS_WORDS];   // spread over 64 words (slot = block & 63): one word takes ~88 atomics per microsecond
+	HIPCHK(hipMemcpyAsync(pairs, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, CTR_PAIRS_WORDS * 8, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
 	c->stats.chain_pairs = 0;
-	for (int k = 0; k < 64; ++k) c->stats.chain_pairs += (int64_t)pairs[k];
+	for (int k = 0; k < CTR_PAIRS_WORDS; ++k) c->stats.chain_pairs += (int64_t)pairs[k];
 	return 0;
 }
 
@@ -458,6 +459,52 @@ int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
 		HIPCHK(hipMemcpyAsync(hb.n_v.data(), c->n_v.p, n * 4, hipMemcpyDeviceToHost, c->st));
 	}
 	return check_err(c);
+}
+
+// mg_lchain_rmq on the device (mm355_rmq.hip).  Long-read presets: the long-join re-chain of every read with more than one chain whose
+// first chain passes the rescue test (the kernel evaluates the test).  MM_F_RMQ presets: the primary chainer over all sorted anchors.
+// Leaves hb.n_u / hb.n_v / hb.rmq_state up to date.  MM355_RMQ_ON_HOST=1: the stage does nothing and the host tail chains as in round 2.
+int mm355_run_rmq(mm355_ctx *c, const mm355_mapopt_t *mo, const DevParams &pr)
+{
+	HostBatch &hb = c->hb;
+	const int64_t n = hb.n_reads;
+	hb.rmq_state.clear();
+	const bool on_host = [] { const char *e = getenv("MM355_RMQ_ON_HOST"); return e && atoi(e) != 0; }();   // (read per call: the tests switch it)
+	const bool primary = (mo->flag & MMF_RMQ) != 0;
+	if (on_host || n == 0) return 0;
+	if (!primary && !(mo->bw_long > mo->bw && (mo->flag & (MMF_SPLICE | MMF_SR | MMF_NO_LJOIN)) == 0)) { hb.rmq_state.assign(n, MM355_RMQ_KEEP); return 0; }
+	RmqParams rp; memset(&rp, 0, sizeof(rp));
+	rp.max_dist = mo->max_gap; rp.max_dist_inner = mo->rmq_inner_dist; rp.bw = primary? mo->bw : mo->bw_long; rp.max_chn_skip = mo->max_chain_skip;
+	rp.cap = mo->rmq_size_cap; rp.pen_gap = pr.pen_gap; rp.pen_skip = pr.pen_skip; rp.rescue_size = mo->rmq_rescue_size; rp.rescue_ratio = mo->rmq_rescue_ratio;
+	rp.primary = primary? 1 : 0;
+	if (c->h_rmq.ensure((size_t)n * 4 + (size_t)n + 64) || c->rmq_list.ensure((size_t)n * 4 + 64) || c->rmq_flag.ensure((size_t)n + 64)) return MM355_ENOMEM;
+	int32_t *hl = (int32_t*)c->h_rmq.p; uint8_t *hf = (uint8_t*)c->h_rmq.p + (size_t)n * 4;
+	int nl = 0;
+	for (int64_t i = 0; i < n; ++i) if (primary? hb.n_a[i] > 0 : hb.n_u[i] > 1) hl[nl++] = (int32_t)i;
+	hb.rmq_state.assign(n, MM355_RMQ_KEEP);
+	if (nl == 0) return 0;
+	// the reads with the most anchors first: the longest dependence chain starts at t = 0
+	std::stable_sort(hl, hl + nl, [&](int32_t x, int32_t y) { return (primary? hb.n_a[x] > hb.n_a[y] : hb.n_v[x] > hb.n_v[y]); });
+	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
+	HIPCHK(hipMemcpyAsync(c->rmq_list.p, hl, (size_t)nl * 4, hipMemcpyHostToDevice, c->st));
+	HIPCHK(hipMemsetAsync(c->rmq_flag.p, primary? MM355_RMQ_DONE : MM355_RMQ_KEEP, (size_t)n, c->st));
+	unsigned long long *ctr = c->counters.as<unsigned long long>() + CTR_RMQ_OFF;
+	HIPCHK(hipMemsetAsync(ctr, 0, CTR_RMQ_WORDS * 8, c->st));
+	{ EvTimer t(c, &c->stats.ms_rmq);
+	  if (mm355_launch_rmq(rp, pr, b, a, c->rmq_list.as<int32_t>(), nl, c->rmq_flag.as<uint8_t>(), c->err.as<int>(), ctr, c->st)) return MM355_EHIP; }
+	unsigned long long hc[CTR_RMQ_WORDS];
+	HIPCHK(hipMemcpyAsync(hf, c->rmq_flag.p, (size_t)n, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(hb.n_u.data(), c->n_u.p, n * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(hb.n_v.data(), c->n_v.p, n * 4, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(hc, ctr, CTR_RMQ_WORDS * 8, hipMemcpyDeviceToHost, c->st));
+	int rc = check_err(c);   // (synchronises the stream)
+	if (rc) return rc;
+	for (int64_t i = 0; i < n; ++i) {
+		hb.rmq_state[i] = hf[i];
+		if (hf[i] == MM355_RMQ_DONE) ++c->stats.n_rmq_reads; else if (hf[i] == MM355_RMQ_HOST) ++c->stats.n_rmq_host;
+	}
+	for (int k = 0; k < CTR_RMQ_WORDS; ++k) c->stats.rmq_scanned += (int64_t)hc[k];
+	return 0;
 }
 
 // ------------------------------------------------------------------ per-stage C-ABI (tests + bench)
@@ -546,6 +593,38 @@ extern "C" int mm355_stage_chains(mm355_ctx_t *c, const mm355_mapopt_t *mo, int6
 	if (tu > u_cap || tv > a_cap) return MM355_ENOMEM;
 	for (int64_t i = 0; i < n_reads; ++i) {
 		if (hb.n_u[i]) HIPCHK(hipMemcpyAsync(u + u_off[i], c->u.as<uint64_t>() + hb.aoff[i], (size_t)hb.n_u[i] * 8, hipMemcpyDeviceToHost, c->st));
+		if (hb.n_v[i]) HIPCHK(hipMemcpyAsync(a + a_off[i] * 2, c->a.as<mm128>() + hb.aoff[i], (size_t)hb.n_v[i] * 16, hipMemcpyDeviceToHost, c->st));
+	}
+	HIPCHK(mm355_wait_stream(c->st));
+	return 0;
+}
+
+extern "C" int mm355_stage_rmq(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs, const int32_t *lens,
+                               int64_t *u_off, uint64_t *u, int64_t u_cap, int64_t *a_off, uint64_t *a, int64_t a_cap, int32_t *state)
+{
+	DevParams pr; int rc;
+	if ((rc = stage_prologue(c, mo, n_reads, seqs, lens, &pr))) return rc;
+	if ((rc = mm355_run_sketch(c))) return rc;
+	if ((rc = mm355_run_seeds(c, pr))) return rc;
+	if ((rc = mm355_run_expand(c, pr))) return rc;
+	if ((rc = mm355_run_sort(c))) return rc;
+	if (mo->flag & MMF_RMQ) { if ((rc = mm355_run_chain_skip(c))) return rc; }
+	else {
+		if ((rc = mm355_run_chain(c, pr))) return rc;
+		if ((rc = mm355_run_backtrack(c, pr))) return rc;
+	}
+	if ((rc = mm355_run_rmq(c, mo, pr))) return rc;
+	HostBatch &hb = c->hb;
+	int64_t tu = 0, tv = 0;
+	for (int64_t i = 0; i < n_reads; ++i) {
+		const int st = hb.rmq_state.empty()? MM355_RMQ_HOST : hb.rmq_state[i];
+		state[i] = st;
+		u_off[i] = tu; a_off[i] = tv; tu += st == MM355_RMQ_HOST? 0 : hb.n_u[i]; tv += hb.n_v[i];
+	}
+	u_off[n_reads] = tu; a_off[n_reads] = tv;
+	if (tu > u_cap || tv > a_cap) return MM355_ENOMEM;
+	for (int64_t i = 0; i < n_reads; ++i) {
+		if (u_off[i + 1] > u_off[i]) HIPCHK(hipMemcpyAsync(u + u_off[i], c->u.as<uint64_t>() + hb.aoff[i], (size_t)(u_off[i + 1] - u_off[i]) * 8, hipMemcpyDeviceToHost, c->st));
 		if (hb.n_v[i]) HIPCHK(hipMemcpyAsync(a + a_off[i] * 2, c->a.as<mm128>() + hb.aoff[i], (size_t)hb.n_v[i] * 16, hipMemcpyDeviceToHost, c->st));
 	}
 	HIPCHK(mm355_wait_stream(c->st));

@@ -65,7 +65,9 @@ class Stats(C.Structure):
                 ("ms_backtrack", C.c_double), ("ms_dp", C.c_double), ("ms_host", C.c_double), ("ms_total", C.c_double),
                 ("ms_seed_lookup", C.c_double), ("ms_seed_expand", C.c_double), ("n_launch_seed", C.c_int64), ("n_launch_dp", C.c_int64),
                 ("ms_dp_group", C.c_double * 24), ("dp_cells_group", C.c_int64 * 24), ("n_launch_group", C.c_int64 * 24),
-                ("n_ext_rounds", C.c_int64), ("n_sort_fast_reads", C.c_int64), ("n_sort_tie_reads", C.c_int64)]
+                ("n_ext_rounds", C.c_int64), ("n_sort_fast_reads", C.c_int64), ("n_sort_tie_reads", C.c_int64),
+                ("ms_rmq", C.c_double), ("n_rmq_reads", C.c_int64), ("n_rmq_host", C.c_int64), ("rmq_scanned", C.c_int64),
+                ("host_cpu_ms", C.c_double)]
 
 
 class DpJob(C.Structure):
@@ -91,7 +93,7 @@ EXPORTS = [
     "mm355_set_opt", "mm355_mapopt_update", "mm355_index_load", "mm355_index_build", "mm355_index_build_device", "mm355_index_free",
     "mm355_index_info", "mm355_index_seq_name", "mm355_index_seq_len", "mm355_index_name2id", "mm355_index_getseq",
     "mm355_index_get", "mm355_index_stat", "mm355_upload", "mm355_ctx_create", "mm355_ctx_destroy", "mm355_map_batch",
-    "mm355_free_hits", "mm355_batch_upload", "mm355_batch_select", "mm355_map_resident", "mm355_stage_sketch", "mm355_stage_anchors", "mm355_stage_chain", "mm355_stage_chains",
+    "mm355_free_hits", "mm355_batch_upload", "mm355_batch_select", "mm355_map_resident", "mm355_stage_sketch", "mm355_stage_anchors", "mm355_stage_chain", "mm355_stage_chains", "mm355_stage_rmq",
     "mm355_stage_dp", "mm355_stage_extra", "mm355_get_stats", "mm355_device_count", "mm355_device_synchronize", "mm355_strerror", "mm355_version",
 ]
 
@@ -137,6 +139,7 @@ def lib():
     L.mm355_stage_chain.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, C.POINTER(C.c_char_p), i32p, vp, vp, vp, vp, vp, C.c_int64]
     L.mm355_stage_chains.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, C.POINTER(C.c_char_p), i32p, vp, vp, C.c_int64, vp, vp, C.c_int64]
     L.mm355_stage_dp.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64]
+    L.mm355_stage_rmq.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, C.POINTER(C.c_char_p), i32p, vp, vp, C.c_int64, vp, vp, C.c_int64, vp]
     L.mm355_stage_extra.argtypes = [vp, C.POINTER(MapOpt), C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int, vp, vp, C.c_int64]
     L.mm355_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.mm355_strerror.restype = C.c_char_p
@@ -232,3 +235,15 @@ class StageRunner:
         check(self.L.mm355_stage_chains(self.ctx, C.byref(self.mo), n, arr, lens, uoff.ctypes.data, u.ctypes.data, cap,
                                         aoff.ctypes.data, a.ctypes.data, cap))
         return [(u[uoff[i]:uoff[i + 1]].copy(), a[aoff[i]:aoff[i + 1]].copy()) for i in range(n)]
+
+    def rmq(self, seqs, cap=None):
+        """chains after mg_lchain_rmq (long-join re-chain, or the primary chainer of MM_F_RMQ presets): [(u, anchors, state)] per read"""
+        arr, lens, keep = pack_reads(seqs)
+        n = len(seqs)
+        cap = cap or (64 * sum(len(b) for b in keep) + 1024)
+        uoff = np.zeros(n + 1, np.int64); aoff = np.zeros(n + 1, np.int64)
+        u = np.zeros(cap, np.uint64); a = np.zeros((cap, 2), np.uint64)
+        state = np.zeros(n, np.int32)
+        check(self.L.mm355_stage_rmq(self.ctx, C.byref(self.mo), n, arr, lens, uoff.ctypes.data, u.ctypes.data, cap,
+                                     aoff.ctypes.data, a.ctypes.data, cap, state.ctypes.data))
+        return [(u[uoff[i]:uoff[i + 1]].copy(), a[aoff[i]:aoff[i + 1]].copy(), int(state[i])) for i in range(n)]

@@ -140,6 +140,9 @@ def lib():
         L.mmo_lchain_dp.restype = C.c_void_p
         L.mmo_lchain_dp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_int, C.c_int, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.mmo_lchain_rmq.restype = C.c_void_p
+        L.mmo_lchain_rmq.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                     C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
         _LIB = L
     return _LIB
 
@@ -281,6 +284,46 @@ class OracleAligner:
         aa = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint64)), shape=(nv, 2)).copy()
         L.free(u); L.free(b)
         return ua, aa
+
+    def _lchain_rmq(self, sorted_anchors, bw):
+        """mg_lchain_rmq on anchors sorted by x: (u, compacted anchors)"""
+        L = lib()
+        n = sorted_anchors.shape[0]
+        if n == 0:
+            return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+        buf = L.malloc(n * 16)
+        C.memmove(buf, np.ascontiguousarray(sorted_anchors, dtype=np.uint64).ctypes.data, n * 16)
+        mo = self.mo
+        pen_gap = np.float32(np.float64(mo.chain_gap_scale) * 0.01 * self.k)
+        pen_skip = np.float32(np.float64(mo.chain_skip_scale) * 0.01 * self.k)
+        n_u, u = C.c_int(), C.c_void_p()
+        b = L.mmo_lchain_rmq(mo.max_gap, mo.rmq_inner_dist, bw, mo.max_chain_skip, mo.rmq_size_cap, mo.min_cnt, mo.min_chain_score,
+                             pen_gap, pen_skip, n, buf, C.byref(n_u), C.byref(u))
+        if n_u.value == 0:
+            return np.zeros(0, np.uint64), np.zeros((0, 2), np.uint64)
+        ua = np.ctypeslib.as_array(C.cast(u, C.POINTER(C.c_uint64)), shape=(n_u.value,)).copy()
+        nv = int((ua & np.uint64(0xffffffff)).sum())
+        aa = np.ctypeslib.as_array(C.cast(b, C.POINTER(C.c_uint64)), shape=(nv, 2)).copy()
+        L.free(u); L.free(b)
+        return ua, aa
+
+    def chains_final(self, anchors, qlen):
+        """what mm_map_frag (mmo_map.c) holds before mm_gen_regs: (u, anchors, did_rmq).  MM_F_RMQ presets: mg_lchain_rmq is the primary
+        chainer; otherwise mg_lchain_dp and, when the rescue test fires, the long-join re-chain (radix_sort_128x + mg_lchain_rmq, bw_long)"""
+        L = lib()
+        mo = self.mo
+        if mo.flag & 0x80000000:
+            u, a = self._lchain_rmq(anchors, mo.bw)
+            return u, a, 1
+        u, a = self.chains(anchors, qlen)
+        if mo.bw_long > mo.bw and (mo.flag & (0x080 | 0x1000 | 0x400)) == 0 and len(u) > 1:
+            st = int(np.int32(a[0, 1] & np.uint64(0xffffffff))); en = int(np.int32(a[int(u[0] & np.uint64(0xffffffff)) - 1, 1] & np.uint64(0xffffffff)))
+            if qlen - (en - st) > mo.rmq_rescue_size or np.float32(en - st) > np.float32(qlen) * np.float32(mo.rmq_rescue_ratio):
+                srt = np.ascontiguousarray(a, dtype=np.uint64).copy()
+                L.mmo_radix_sort_128x(srt.ctypes.data, srt.ctypes.data + srt.shape[0] * 16)
+                u, a = self._lchain_rmq(srt, mo.bw_long)
+                return u, a, 1
+        return u, a, 0
 
     def map(self, seq, cs=False, MD=False):
         L = lib()

@@ -91,6 +91,75 @@ def test_chains_parity(world):
     assert n_multi > 0
 
 
+def _sv_reads(g, rng, n_each=10):
+    """reads whose chains mg_lchain_dp (bw 500) cannot join: a 1.5 - 6 kb deletion, an inserted block, a chimera of two loci"""
+    comp = lambda c: np.where(c < 4, 3 - c, 4).astype(np.uint8)[::-1]
+    out = []
+    for _ in range(n_each):
+        a0 = int(rng.integers(0, 330000)); gap = int(rng.integers(1500, 6000))
+        out.append(S.codes_to_str(S.mutate(np.concatenate([g[0][a0:a0 + 3000], g[0][a0 + 3000 + gap:a0 + 8000 + gap]]), rng, 0.02, 0.01, 0.01)))
+        out.append(S.codes_to_str(S.mutate(np.concatenate([g[0][a0:a0 + 2500], S.random_codes(rng, int(rng.integers(700, 3000))), g[0][a0 + 2500:a0 + 6000]]), rng, 0.02, 0.01, 0.01)))
+        b0 = int(rng.integers(0, 200000))
+        out.append(S.codes_to_str(S.mutate(np.concatenate([g[0][a0:a0 + 3000], comp(g[1][b0:b0 + 2500])]), rng, 0.02, 0.01, 0.01)))
+    return out
+
+
+def _check_rmq(sr, orc, reads, must_rechain):
+    got = sr.rmq(reads)
+    n_dev = n_host = n_keep = 0
+    for i, rd in enumerate(reads):
+        u, a, state = got[i]
+        ea, _, _, _ = orc.anchors(rd, sorted_=True)
+        eu, eb, did = orc.chains_final(ea, len(rd))
+        if state == 2:      # handed to the literal host code: the device leaves the chained anchors sorted by x (checked end to end by the mapping tests)
+            n_host += 1
+            assert did == 1, i
+            assert len(u) == 0 and np.all(a[1:, 0] >= a[:-1, 0]), i
+            continue
+        assert (state == 1) == (did == 1), (i, state, did)
+        assert np.array_equal(u, eu), (i, state)
+        assert np.array_equal(a, eb), (i, state)
+        n_dev += state == 1; n_keep += state == 0
+    assert n_dev >= must_rechain, (n_dev, n_host, n_keep)
+    assert n_host <= max(2, len(reads) // 10), (n_dev, n_host)      # the fallback is the exception
+    return n_dev, n_host, n_keep
+
+
+def test_rmq_rechain_parity(world):
+    """row a9 on the device: long-join re-chain (rescue test, radix_sort_128x of the chained anchors, mg_lchain_rmq with bw_long,
+    backtrack, compact_a) against the oracle's mg_lchain_rmq, read by read"""
+    reads = world["reads"] + _sv_reads(world["genome"], np.random.default_rng(91))
+    n_dev, n_host, n_keep = _check_rmq(world["sr"], world["orc"], reads, must_rechain=25)
+    assert n_keep > 0
+
+
+def test_rmq_stage_off_leaves_the_host_in_charge(world, monkeypatch):
+    monkeypatch.setenv("MM355_RMQ_ON_HOST", "1")
+    got = world["sr"].rmq(world["reads"][:8])
+    assert all(st == 2 for _, _, st in got)
+
+
+@pytest.mark.parametrize("preset", ["asm5", "asm20"])
+def test_rmq_primary_chainer_parity(built, tmp_path, preset):
+    """MM_F_RMQ presets: mg_lchain_rmq over all sorted anchors of a read on the device (bw 1000, inner distance 1000, cap 100000)"""
+    import mappy_rs
+    g = S.make_genome(81, [350000, 150000], repeats=((4000, 4, 0.01), (900, 12, 0.02)), n_runs=2)
+    fa = str(tmp_path / "p.fa")
+    S.write_fasta(fa, g, ["ctgA", "ctgB"])
+    div = {"asm5": 0.002, "asm20": 0.02}[preset]
+    reads, _ = S.make_reads(82, g, 40, n50=15000, lo=1500, sub=div, ins=div / 4, dele=div / 4)
+    rng = np.random.default_rng(83)
+    for _ in range(6):
+        a0 = int(rng.integers(0, 300000))
+        reads.append(S.codes_to_str(S.mutate(np.concatenate([g[0][a0:a0 + 9000], g[0][a0 + 9000 + 2500:a0 + 20000]]), rng, div, div / 4, div / 4)))
+    reads += ["ACGT", S.codes_to_str(g[1][5000:5400])]
+    al = mappy_rs.Aligner(fa, preset=preset)
+    orc = O.OracleAligner(fa, preset=preset)
+    sr = al._stage_runner()
+    _check_rmq(sr, orc, reads, must_rechain=40)
+    sr.close()
+
+
 def test_empty_and_ragged_batches(world):
     sr = world["sr"]
     assert sr.sketch([]) == []
