@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- aligned Mbases/s of the MI355X mapping path (BASELINE.json metric: ONT reads vs GRCh38, map-ont).
 
-A "step" is one pass of the hot path (sketch -> seed lookup -> chain -> extension -> hits) over one batch of synthetic ONT reads.
-Default workload = BASELINE.json configs[2]: synthetic GRCh38-scale genome (3.09 Gbp, index built on the device), map-ont, reads
-N50 ~10 kb.  `value` is the PCIe-inclusive rate (H2D of the reads and D2H of the results inside the timed region, index
-upload outside); the rate with the reads already resident in HBM is reported beside it (`resident_mbases_per_s`).
+A "step" is one pass of the hot path (sketch -> seed lookup -> chain -> extension -> hits) over one block of synthetic ONT reads.
+Default workload = BASELINE.json configs[2]: synthetic GRCh38-scale genome (3.09 Gbp, index built on the device), map-ont, 1 M reads
+N50 ~10 kb: the read set is cut into steps + warmup DISTINCT blocks of 73 728 reads (14 + 1 by default: 1 032 192 reads in the timed
+region, no read mapped twice in it; the warm-up block is a block of its own).  `value` is the rate with the reads already resident in
+HBM when the timed region starts (every block is uploaded before it); the PCIe-inclusive rate (host buffers in, hit records out:
+mm355_map_batch, the drop-in call) is timed afterwards on a few of the same blocks and reported beside it (`pcie_inclusive_mbases_per_s`).
 
 Multi-GPU (--gpus N): ONE read set of N x --reads reads is cut into N contiguous shards balanced by cumulative bases;
 rank r maps shard r against its own replica of the index; no data-path collective.  The driver launches the ranks with
@@ -33,7 +35,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 def _parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=14)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="human")
     ap.add_argument("--reads", type=int, default=0, help="reads per step per GPU (0 = workload default)")
@@ -42,7 +44,8 @@ def _parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="genome scale of the human workloads")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-resident", action="store_true", help="skip the second timed region (reads already resident in HBM)")
+    ap.add_argument("--no-pcie", "--no-resident", dest="no_pcie", action="store_true", help="skip the second timed region (PCIe-inclusive: mm355_map_batch on host buffers)")
+    ap.add_argument("--pcie-steps", type=int, default=3, help="blocks of the second (PCIe-inclusive) timed region")
     return ap.parse_args()
 
 
@@ -153,17 +156,40 @@ def make_genome(kind, scale):
                      "index built on the device" % (tot / 1e9, scale), True
 
 
-def shard_reads(wl, g, n_per_gpu, rank, world):
-    """rank's shard of the ONE read set of world * n_per_gpu reads: contiguous, balanced by cumulative bases"""
+_SYNTH = {}
+
+
+def _synth_block(b):
+    import synthdata as S
+    rd, _ = S.make_read_block(_SYNTH["seed"], b, _SYNTH["g"], **_SYNTH["kw"])
+    return rd
+
+
+def shard_reads(wl, g, n_per_gpu, rank, world, procs):
+    """rank's shard of the ONE read set of world * n_per_gpu reads: contiguous, balanced by cumulative bases.  The blocks of
+    the read set (synthdata.READ_BLOCK reads each, one PRNG stream per block) are synthesised by forked worker processes -- this runs
+    before anything in the process has touched the GPU."""
+    import multiprocessing as mp
     import synthdata as S
     from mappy_rs import shard_by_bases
     t0 = time.time()
     total = n_per_gpu * world
     lens = S.read_set_lengths(wl["seed"], total, **{k: v for k, v in wl["reads"].items() if k in ("n50", "sigma", "lo", "hi")})
     b = shard_by_bases(lens, world)
-    reads = S.read_set_slice(wl["seed"], b[rank], b[rank + 1], g, **wl["reads"])
-    log("[bench] read set: %d reads, rank %d maps reads [%d, %d) (%.1f Mbases) -- synthesised in %.1fs"
-        % (total, rank, b[rank], b[rank + 1], sum(len(r) for r in reads) / 1e6, time.time() - t0))
+    lo, hi = b[rank], b[rank + 1]
+    blocks = list(range(lo // S.READ_BLOCK, (hi + S.READ_BLOCK - 1) // S.READ_BLOCK))
+    _SYNTH.update(seed=wl["seed"], g=g, kw=wl["reads"])
+    if procs > 1 and len(blocks) > 1:
+        with mp.get_context("fork").Pool(min(procs, len(blocks))) as pool:
+            parts = pool.map(_synth_block, blocks, chunksize=1)
+    else:
+        parts = [_synth_block(bk) for bk in blocks]
+    reads = []
+    for bk, rd in zip(blocks, parts):
+        b0 = bk * S.READ_BLOCK
+        reads.extend(rd[max(lo, b0) - b0:min(hi, b0 + S.READ_BLOCK) - b0])
+    log("[bench] read set: %d reads, rank %d maps reads [%d, %d) (%.1f Mbases) -- synthesised in %.1fs on %d processes"
+        % (total, rank, lo, hi, sum(len(r) for r in reads) / 1e6, time.time() - t0, min(procs, max(1, len(blocks)))))
     return reads
 
 
@@ -222,38 +248,58 @@ def cpu_baseline(g, names, preset, reads, budget_s, threads, gpu_sigs=None):
                        "(not timed)" % (done["n"], done["bases"] / 1e6, dt, threads, t_build))
 
 
+# VALU issue peak of the chip: 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz lane-operations per second
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9
+# Arithmetic a unit of work needs at least (DESIGN.md section 4 spells the counts out):
+#   one cell of the two-piece affine recurrence with its direction byte: 34 integer operations (4 adds for the four gap candidates, 4 max
+#   + 8 compare/select for z and its source, 2 subtractions for u' / v', 4 x 4 for the four gap states' open-or-extend updates and flag
+#   bits), two int16 cells per lane-operation (v_pk_*) -> 17 lane-operations per cell;
+#   one predecessor evaluation of the chaining recurrence (comput_sc + window test + running max): 30 operations, no packing.
+DP_LANE_OPS_PER_CELL = 17.0
+CHAIN_LANE_OPS_PER_PAIR = 30.0
+
+
 def main():
     args = _ARGS
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    import __graft_entry__ as ge
+    import synthdata as S
+    if args.workload not in WORKLOADS:
+        raise SystemExit("unknown workload " + args.workload)
+    wl = WORKLOADS[args.workload]
+    n_per_step = args.reads or wl["n_reads"]          # reads per step per GPU
+    n_thr = max(1, args.streams or wl["streams"])
+    depth = max(1, args.depth or wl["depth"])
+    K, W = max(1, args.steps), max(0, args.warmup)
+    # every step maps a block of its own; the library keeps at most 64 resident batches per context (depth of them per block)
+    max_blocks = 64 // depth
+    n_blocks = min(K + W, max_blocks)
+    n_timed_blocks = min(K, n_blocks - min(W, 1)) if n_blocks > 1 else 1
+
+    # ---- host-side synthesis first: nothing below this block may have touched the GPU (worker processes are forked)
+    g, names, gdesc, device_index = make_genome(wl["genome"], args.scale)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    procs = max(1, min(16, int((os.cpu_count() or 2) // max(1, local_world)) - 1))
+    reads = shard_reads(wl, g, n_per_step * n_blocks, rank, world, procs)
+
     dist = None
-    if world > 1:
+    if os.environ.get("WORLD_SIZE") is not None:   # launched by torch.distributed.run (or by _spawn_ranks): also with a single rank
         import torch
         import torch.distributed as dist_
         dist = dist_
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
-
-    import __graft_entry__ as ge
     if rank == 0:
         ge.build()
     if dist is not None:
         dist.barrier()
     from mappy_rs import _ffi
-    import synthdata as S
     L = _ffi.lib()
     if L.mm355_device_count() <= local_rank:
         raise SystemExit("bench.py needs an MI355X: libmm355 has no CPU fallback (devices visible: %d)" % L.mm355_device_count())
-    if args.workload not in WORKLOADS:
-        raise SystemExit("unknown workload " + args.workload)
-    wl = WORKLOADS[args.workload]
-    n_per_gpu = args.reads or wl["n_reads"]
-    n_thr = max(1, args.streams or wl["streams"])
-    depth = max(1, args.depth or wl["depth"])
 
-    g, names, gdesc, device_index = make_genome(wl["genome"], args.scale)
-    reads = shard_reads(wl, g, n_per_gpu, rank, world)
     # index (replicated on every GPU; built on the device for the GRCh38-scale genome)
     t0 = time.time()
     io, mo = _ffi.IdxOpt(), _ffi.MapOpt()
@@ -271,56 +317,73 @@ def main():
         arr = (C.c_char_p * len(seqs))(*seqs)
         _ffi.check(L.mm355_index_build(C.byref(io), len(seqs), arr, lens, nm, min(16, os.cpu_count() or 1), C.byref(idx)))
     L.mm355_mapopt_update(C.byref(mo), idx)
-    # one context (own HIP streams + working buffers) per host thread; every context holds `depth` sub-batches (mm355_batch_select)
-    # and maps them one after the other within a step, so that the host tail of one sub-batch overlaps kernels of another.
-    n_str = n_thr * depth                 # sub-batches per step
-    ctxs, parts = [], []
+    log("[bench] index built + uploaded in %.1fs (mid_occ=%d)" % (time.time() - t0, mo.mid_occ))
+
+    # one context (own HIP streams + working buffers) per host thread.  Block b of the read set (one step) is cut into n_str = streams x
+    # depth sub-batches; sub-batch si of block b lives in context si % n_thr as resident batch b * depth + si // n_thr.  A host thread
+    # maps its sub-batches of a step one after the other, so that the host tail of one overlaps kernels of another.
+    n_str = n_thr * depth
+    ctxs = []
     for ti in range(n_thr):
         ctx = C.c_void_p()
         _ffi.check(L.mm355_ctx_create(idx, local_rank, C.byref(ctx)))
         ctxs.append(ctx)
-    for si in range(n_str):
-        parts.append(reads[si::n_str])
-    log("[bench] index built + uploaded in %.1fs (mid_occ=%d)" % (time.time() - t0, mo.mid_occ))
+    per_block = len(reads) // n_blocks
+    t0 = time.time()
+    packed, rlens_np, block_bases = {}, {}, []
+    pcie_blocks = 0 if args.no_pcie else min(args.pcie_steps, n_timed_blocks)
+    for b in range(n_blocks):
+        blk = reads[b * per_block:(b + 1) * per_block]
+        block_bases.append(sum(len(r) for r in blk))
+        for si in range(n_str):
+            pk = _ffi.pack_reads(blk[si::n_str])
+            rlens_np[(b, si)] = np.asarray(pk[1], dtype=np.int64)
+            _ffi.check(L.mm355_batch_select(ctxs[si % n_thr], b * depth + si // n_thr))
+            _ffi.check(L.mm355_batch_upload(ctxs[si % n_thr], len(pk[2]), pk[0], pk[1]))
+            if b < pcie_blocks:
+                packed[(b, si)] = pk          # host buffers of the blocks the PCIe-inclusive region maps again
+    cpu_sample = reads[:min(len(reads), per_block)]   # the CPU leg samples the first block
+    n_reads_rank = len(reads)
+    del reads
+    log("[bench] %d blocks of %d reads uploaded (%d resident sub-batches of ~%d reads) in %.1fs" %
+        (n_blocks, per_block, n_blocks * n_str, per_block // n_str, time.time() - t0))
 
-    packed = [_ffi.pack_reads(p) for p in parts]
-    n_bases = sum(len(b) for pk in packed for b in pk[2])
-    rlens_np = [np.asarray(pk[1], dtype=np.int64) for pk in packed]
-
-    def step_one(si, resident):
-        ctx, (rarr, rlens, keep) = ctxs[si % n_thr], packed[si]       # sub-batch si lives in context si % n_thr, slot si // n_thr
-        _ffi.check(L.mm355_batch_select(ctx, si // n_thr))
+    def step_one(b, si, resident):
+        ctx = ctxs[si % n_thr]
+        _ffi.check(L.mm355_batch_select(ctx, b * depth + si // n_thr))
         hp = C.POINTER(_ffi.Hits)()
-        if resident:
+        if resident:   # the timed call of `value`: inputs already in HBM
             _ffi.check(L.mm355_map_resident(ctx, C.byref(mo), _ffi.OUT_CS, C.byref(hp)))
-        else:   # the drop-in call: host buffers in (H2D), hit records out (D2H)
-            _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(keep), rarr, rlens, _ffi.OUT_CS, C.byref(hp)))
+        else:          # the drop-in call: host buffers in (H2D), hit records out (D2H)
+            rarr, rl, keep = packed[(b, si)]
+            _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(keep), rarr, rl, _ffi.OUT_CS, C.byref(hp)))
         h = hp.contents
-        off = np.ctypeslib.as_array(h.hit_off, shape=(len(keep) + 1,))
+        nr = len(rlens_np[(b, si)])
+        off = np.ctypeslib.as_array(h.hit_off, shape=(nr + 1,))
         mapped = np.diff(off) > 0
-        aligned = int(rlens_np[si][mapped].sum())
+        aligned = int(rlens_np[(b, si)][mapped].sum())
         n_hits = int(h.n_hits)
         L.mm355_free_hits(hp)
         st = _ffi.Stats()
         L.mm355_get_stats(ctx, C.byref(st))
-        return aligned, n_hits, st
+        return aligned, n_hits, st, nr
 
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(n_thr)
 
-    def run_steps(resident, steps):
-        """`steps` passes over the batch: every host thread maps its own sub-batches `steps` times, one after the other, without waiting
-        for the other threads between passes (the passes of different threads overlap; the barriers bracket the whole region, not a pass)"""
+    def run_blocks(resident, blocks):
+        """one pass over every listed block: every host thread maps its own sub-batches of block after block without waiting for the other
+        threads between blocks (the barriers bracket the whole region, not a step)"""
         def thread(ti):
-            return [step_one(si, resident) for _ in range(steps) for si in range(ti, n_str, n_thr)]
+            return [step_one(b, si, resident) for b in blocks for si in range(ti, n_str, n_thr)]
         res = [r for part in pool.map(thread, range(n_thr)) for r in part]
         agg_st = {}
-        for _a, _h, st in res:
+        for _a, _h, st, _n in res:
             for k, _t in _ffi.Stats._fields_:
                 v = getattr(st, k)
                 v = np.array(list(v), dtype=np.float64) if hasattr(v, "__len__") else v
                 agg_st[k] = agg_st.get(k, 0) + v
-        return sum(r[0] for r in res), sum(r[1] for r in res), agg_st
+        return sum(r[0] for r in res), sum(r[1] for r in res), agg_st, sum(r[3] for r in res)
 
     def barrier():
         # both sides of the timed region: every stream of this rank's GPU drained (the library runs on its own HIP streams, which
@@ -332,98 +395,132 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed(resident, steps):
+    def timed(resident, blocks):
         barrier()
         t0 = time.perf_counter()
-        aligned_tot, n_hits, agg = run_steps(resident, steps)
+        aligned_tot, n_hits, agg, n_mapped = run_blocks(resident, blocks)
         barrier()
         dt = time.perf_counter() - t0
-        dt, aligned_all, bases_all = aggregate(dist, dt, aligned_tot, n_bases * steps)
-        return dt, aligned_all, bases_all, agg
+        dt, aligned_all, bases_all = aggregate(dist, dt, aligned_tot, sum(block_bases[b] for b in blocks))
+        return dt, aligned_all, bases_all, agg, n_mapped
 
-    if args.warmup:
-        run_steps(False, args.warmup)
-    K = args.steps
-    dt, aligned_all, bases_all, agg = timed(False, K)           # `value`: H2D + map + D2H
-    if args.no_resident:
-        dt_res, aligned_res = None, None
+    # blocks: the timed region maps blocks 0..; the warm-up maps the blocks behind them (its own reads), wrapping only when the 64-slot
+    # limit of a context leaves no block for it
+    timed_blocks = [k % n_timed_blocks for k in range(K)]
+    warm_blocks = [(n_timed_blocks + k) % n_blocks for k in range(W)]
+    if warm_blocks:
+        run_blocks(True, warm_blocks)
+    dt, aligned_all, bases_all, agg, n_mapped = timed(True, timed_blocks)             # `value`: reads resident in HBM
+    if pcie_blocks:
+        dt_p, aligned_p, _b, _agg, _n = timed(False, list(range(pcie_blocks)))      # host buffers in, records out (same reads again)
     else:
-        dt_res, aligned_res, _b, _agg = timed(True, K)          # reads already resident in HBM (uploaded by the steps above)
+        dt_p, aligned_p = None, None
 
     if rank == 0:
         kern_ms = {"sketch": agg["ms_sketch"] / K, "seed_lookup": agg["ms_seed_lookup"] / K, "seed_expand": agg["ms_seed_expand"] / K,
                    "seed_select+mzflt": agg["ms_seed"] / K, "sort": agg["ms_sort"] / K, "chain": agg["ms_chain"] / K,
-                   "backtrack": agg["ms_backtrack"] / K, "dp": agg["ms_dp"] / K, "host_glue": agg["ms_host"] / K}
+                   "backtrack": agg["ms_backtrack"] / K, "rmq": agg["ms_rmq"] / K, "dp": agg["ms_dp"] / K, "host_glue": agg["ms_host"] / K}
         n_mz, n_hit, n_a, n_am = agg["n_mz"] / K, agg["n_hit"] / K, agg["n_a"] / K, agg["n_a_multi"] / K
         cells, pairs = agg["dp_cells"] / K, agg["chain_pairs"] / K
         # algorithmic bytes per launch
         lookup_bytes = 16 * n_mz + 16 * n_hit
         expand_bytes = 8 * n_am + 16 * n_a
         n_ldp = max(1.0, agg["n_launch_dp"] / K)          # extension launch groups per step (one per sub-batch and round)
-        # the extension kernel that takes the most time, timed alone with HIP events on its own stream (group = 2 * size class + exact)
+        # the extension kernels, each timed alone with HIP events on its own stream (group = 2 * size class + exact)
         # (the long-target classes are two launches, approx and exact alignments together: targets <= 4096 timed as group 8, longer ones as 10)
         gnames = ["k_ksw_reg<%d, %s>" % (np_, ex) for np_ in (1, 2, 4, 8) for ex in ("false", "true")] + \
                  ["k_ksw_extd2<512> (targets 1025..4096)", "-", "k_ksw_extd2<512> (targets > 4096)", "-", "-", "-", "k_ksw_row<2>", "k_ksw_row<4>", "k_ksw_row<8>", "k_ksw_rowl (targets 1025..8192)", "k_ksw_regw (exact, band <= 832, targets > 1024)"]
         cells_g = np.array(agg["dp_cells_group"], dtype=np.float64); cells_g[8] = cells_g[8:10].sum(); cells_g[10] = cells_g[10:14].sum(); cells_g[9] = 0; cells_g[11:14] = 0
         nl_g = np.array(agg["n_launch_group"], dtype=np.float64); nl_g[8] = nl_g[8:10].max(); nl_g[10] = nl_g[10:14].max(); nl_g[9] = 0; nl_g[11:14] = 0
-        gi = int(np.argmax(agg["ms_dp_group"]))
-        g_ms, g_cells, g_nl = agg["ms_dp_group"][gi] / K, cells_g[gi] / K, max(1.0, nl_g[gi] / K)
         n_lfront = float(n_str)                            # one launch of every front kernel per sub-batch
-        cand = {   # name: (algorithmic bytes per step, summed kernel ms per step, launches per step, formula)
-            gnames[gi]: (g_cells, g_ms, g_nl, "1 B/cell direction matrix written to HBM, %.4g cells per launch (HIP events on the kernel's own stream)" % (g_cells / g_nl)),
-        }
-        for i in range(19):   # every extension kernel that ran, each timed alone on its own stream (the dominant one is also `roofline`)
-            if i != gi and nl_g[i] > 0 and agg["ms_dp_group"][i] > 0:
-                cand[gnames[i]] = (cells_g[i] / K, agg["ms_dp_group"][i] / K, max(1.0, nl_g[i] / K),
-                                   "1 B/cell direction matrix written to HBM, %.4g cells per launch (HIP events on the kernel's own stream)" % (cells_g[i] / max(1.0, nl_g[i])))
-        cand.update({
-            "extension launch group": (cells, kern_ms["dp"], n_ldp, "1 B/cell x %.4g cells per group = all k_ksw_reg<NP,exact> / k_ksw_extd2 size classes "
-                                       "on their streams + k_ksw_backtrack; one HIP-event pair around the group" % (cells / n_ldp)),
-            "k_seed_lookup": (lookup_bytes, kern_ms["seed_lookup"], n_lfront, "16*n_mz + 16*n_hit (minimizer read + one table slot)"),
-            "k_seed_expand": (expand_bytes, kern_ms["seed_expand"], n_lfront, "8*n_a_multi + 16*n_a (pos[] entry read + anchor written)"),
-            "anchor sort": (32 * n_a, kern_ms["sort"], n_lfront, "2*16*n_a (one read + one write of every anchor; the radix passes actually needed are not counted)"),
-            "k_chain": (36 * n_a, kern_ms["chain"], n_lfront, "16*n_a read + 20*n_a written"),
-        })
+        reads_per_sub = per_block // n_str
+        roof = {}
+
+        def add_hbm(name, b, ms, nl, how):
+            ach = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0     # bytes per launch / average launch duration (ratio of the per-step sums)
+            roof[name] = dict(bound="hbm", achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                              frac_of_measured_copy=round(ach / HBM_COPY_GBS, 5), traffic=pmc_traffic(args.workload, reads_per_sub, name), kernel=name,
+                              launches_per_step=round(nl, 2), ms_per_launch=round(ms / nl, 4), algorithmic_bytes=int(b / nl), formula=how)
+
+        def add_valu(name, units, ms, nl, ops_per_unit, unit, how, bytes_per_unit):
+            ach = units / (ms * 1e-3) / 1e9 if ms > 0 else 0.0   # G units per second
+            peak = VALU_LANE_OPS / ops_per_unit / 1e9
+            roof[name] = dict(bound="valu", achieved=round(ach, 3), peak=round(peak, 1), unit=unit, frac=round(ach / peak, 5),
+                              traffic=pmc_traffic(args.workload, reads_per_sub, name), kernel=name, launches_per_step=round(nl, 2),
+                              ms_per_launch=round(ms / nl, 4), units_per_launch=int(units / nl), lane_ops_per_unit=ops_per_unit,
+                              hbm_gbs=round(units * bytes_per_unit / (ms * 1e-3) / 1e9, 3) if ms > 0 else 0.0,
+                              hbm_frac=round(units * bytes_per_unit / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else 0.0, formula=how)
+
+        for i in range(19):   # every extension kernel that ran, each timed alone on its own stream
+            if nl_g[i] > 0 and agg["ms_dp_group"][i] > 0:
+                add_valu(gnames[i], cells_g[i] / K, agg["ms_dp_group"][i] / K, max(1.0, nl_g[i] / K), DP_LANE_OPS_PER_CELL, "Gcells/s",
+                         "cell updates of the two-piece affine recurrence per second against the VALU issue peak (%.3g lane-ops/s / %g lane-ops per cell, "
+                         "packed int16); hbm_*: the 1 B/cell direction matrix against 8 TB/s; HIP events on the kernel's own stream" % (VALU_LANE_OPS, DP_LANE_OPS_PER_CELL), 1.0)
+        add_valu("extension launch group", cells, kern_ms["dp"], n_ldp, DP_LANE_OPS_PER_CELL, "Gcells/s",
+                 "all extension kernels of a round on their streams + k_ksw_backtrack; one HIP-event pair around the group", 1.0)
+        add_valu("k_chain", pairs, kern_ms["chain"], n_lfront, CHAIN_LANE_OPS_PER_PAIR, "Gpairs/s",
+                 "predecessor evaluations of mg_lchain_dp per second against the VALU issue peak (%g lane-ops per pair); hbm_*: 16*n_a read + 20*n_a written" % CHAIN_LANE_OPS_PER_PAIR,
+                 36.0 * n_a / max(1.0, pairs))
+        add_hbm("k_seed_lookup", lookup_bytes, kern_ms["seed_lookup"], n_lfront, "16*n_mz + 16*n_hit (minimizer read + one table slot)")
+        add_hbm("k_seed_expand", expand_bytes, kern_ms["seed_expand"], n_lfront, "8*n_a_multi + 16*n_a (pos[] entry read + anchor written)")
+        add_hbm("anchor sort", 32 * n_a, kern_ms["sort"], n_lfront, "2*16*n_a (one read + one write of every anchor; the radix passes actually needed are not counted)")
         # dominant kernel = the extension kernel with the largest summed duration (each is timed alone with HIP events on the stream it is launched
         # on; the rocprofv3 kernel statistics of the same command, profiles/, name the same kernel at the top).  The front stages are timed as
         # event spans on the context's main stream, where kernels of other contexts interleave: they stay in roofline_all.
+        gi = int(np.argmax(agg["ms_dp_group"]))
         dom = gnames[gi]
-        reads_per_sub = len(reads) // n_str
-        roof = {}
-        for k, (b, ms, nl, how) in cand.items():
-            ach = b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0     # bytes per launch / average launch duration (ratio of the per-step sums)
-            roof[k] = dict(bound="hbm", achieved=round(ach, 3), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
-                           frac_of_measured_copy=round(ach / HBM_COPY_GBS, 5), traffic=pmc_traffic(args.workload, reads_per_sub, k), kernel=k,
-                           launches_per_step=round(nl, 2), ms_per_launch=round(ms / nl, 4), algorithmic_bytes=int(b / nl), formula=how)
+        # the kernel the north star names: seed lookup against the HBM roof, and against what the memory system delivers for uniformly random
+        # 128-byte lines of a table this size (profiles/r03_random_line_roof.json, measured by tools/linebench on the same chip)
+        rl = dict(roof["k_seed_lookup"])
+        try:
+            rr = json.load(open(os.path.join(ROOT, "profiles", "r03_random_line_roof.json")))
+            rl["random_line_roof_gbs"] = rr["random_128B_lines_GBs"]
+            if rl["traffic"]:
+                rl["traffic_gbs"] = round(rl["traffic"] / (rl["ms_per_launch"] * 1e-3) / 1e9, 1)
+                rl["traffic_frac_of_random_line_roof"] = round(rl["traffic_gbs"] / rr["random_128B_lines_GBs"], 4)
+        except (OSError, ValueError, KeyError):
+            pass
+        pool_threads = int(os.environ.get("MM355_HOST_THREADS", "14"))
         out = {
             "metric": METRIC,
-            "value": round(aligned_all / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "value": round(aligned_all / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/int32 (+f32 chaining gap cost)", "data": "synthetic",
+            "dtype": "u8/int32 (+f32 chaining gap cost, f64 RMQ priority)", "data": "synthetic",
             "config": dict(workload="%s: %s, %s %s, %s" % (wl["cfg"], gdesc, wl["preset"], "k%d w%d" % (io.k, io.w), wl["what"]),
-                           reads_per_step_per_gpu=len(reads), read_set="%d reads, %d contiguous shard(s) balanced by cumulative bases" % (n_per_gpu * world, world),
-                           streams_per_gpu=n_thr, sub_batches_per_stream=depth, mbases_per_step_per_gpu=round(n_bases / 1e6, 3),
+                           reads_total=int(per_block * n_timed_blocks * world), reads_mapped_in_timed_region=int(n_mapped * world) if dist is None else None,
+                           distinct_blocks_in_timed_region=n_timed_blocks, reads_per_step_per_gpu=per_block,
+                           read_set="%d reads, %d contiguous shard(s) balanced by cumulative bases, %d distinct blocks per shard (%d timed + %d warm-up)"
+                                    % (n_per_step * n_blocks * world, world, n_blocks, n_timed_blocks, n_blocks - n_timed_blocks),
+                           streams_per_gpu=n_thr, sub_batches_per_stream=depth, mbases_per_step_per_gpu=round(sum(block_bases[b] for b in timed_blocks) / K / 1e6, 3),
                            preset=wl["preset"], parallelism="reads sharded over %d GPU(s), index replicated, no collective" % world),
-            "value_basis": "PCIe-inclusive (SURVEY 8d): reads handed over as host buffers (H2D), hit records returned to the host (D2H), index resident",
+            "value_basis": "reads resident in HBM when the timed region starts (every block uploaded beforehand), hit records returned to the host; "
+                           "the PCIe-inclusive rate of the drop-in call (host buffers in) is pcie_inclusive_mbases_per_s",
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
-            "resident_mbases_per_s": None if dt_res is None else round(aligned_res / dt_res / 1e6, 3),
-            "roofline": roof[dom], "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
+            "pcie_inclusive_mbases_per_s": None if dt_p is None else round(aligned_p / dt_p / 1e6, 3),
+            "roofline": roof[dom], "roofline_seed_lookup": rl, "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
             "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(19) if nl_g[i] > 0},
             "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(19) if nl_g[i] > 0},
             "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
-                                      n_dp_jobs=int(agg["n_dp_jobs"] / K)),
+                                      n_dp_jobs=int(agg["n_dp_jobs"] / K), n_sort_tie_reads=int(agg["n_sort_tie_reads"] / K),
+                                      n_rmq_reads=int(agg["n_rmq_reads"] / K), n_rmq_host_fallback=int(agg["n_rmq_host"] / K),
+                                      rmq_window_elements=int(agg["rmq_scanned"] / K)),
+            "host": dict(cpu_us_per_read=round(agg["host_cpu_ms"] * 1e3 / max(1, n_mapped), 2), pool_threads=pool_threads, context_threads=n_thr,
+                         busy_frac_of_pool=round(agg["host_cpu_ms"] * 1e-3 / (dt * (pool_threads + n_thr)), 4),
+                         note="CPU time (thread clocks) of the context threads and the shared pool inside mm355_map_resident, rank 0; "
+                              "busy_frac = that / (wall x (pool + context threads))"),
         }
     barrier()
     gpu_sigs = None
     if rank == 0 and not args.no_cpu and world == 1:   # (outside the timed region) the records of the reads the CPU sample will cover
         import mappy_rs
         gpu_sigs = []
-        n_chk = len(reads) if args.cpu_seconds >= 60 else min(len(reads), 4 * 6144)   # a long CPU leg compares the whole read set
+        n_chk = len(cpu_sample) if args.cpu_seconds >= 60 else min(len(cpu_sample), 4 * 6144)   # a long CPU leg compares the whole block
+        _ffi.check(L.mm355_batch_select(ctxs[0], 63))   # a slot of its own: the resident blocks stay as they are
         for lo in range(0, n_chk, 6144):
-            sub = reads[lo:min(n_chk, lo + 6144)]
-            rarr, rlens, keep = _ffi.pack_reads(sub)
+            sub = cpu_sample[lo:min(n_chk, lo + 6144)]
+            rarr, rl_, keep = _ffi.pack_reads(sub)
             hp = C.POINTER(_ffi.Hits)()
-            _ffi.check(L.mm355_map_batch(ctxs[0], C.byref(mo), len(sub), rarr, rlens, _ffi.OUT_CS, C.byref(hp)))
+            _ffi.check(L.mm355_map_batch(ctxs[0], C.byref(mo), len(sub), rarr, rl_, _ffi.OUT_CS, C.byref(hp)))
             for ms in mappy_rs._batch_to_mappings(hp, len(sub), names):
                 gpu_sigs.append(None if isinstance(ms, Exception) else hash(tuple(tuple(getattr(m, k) for k in SIG_FIELDS) for m in ms)))
             L.mm355_free_hits(hp)
@@ -432,7 +529,7 @@ def main():
     L.mm355_index_free(idx)
     if rank == 0:
         if not args.no_cpu and world == 1:   # after the GPU side has released its memory; rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(g, names, wl["preset"], reads, args.cpu_seconds, min(16, os.cpu_count() or 1), gpu_sigs)
+            out["cpu_baseline"] = cpu_baseline(g, names, wl["preset"], cpu_sample, args.cpu_seconds, min(16, os.cpu_count() or 1), gpu_sigs)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -180,8 +180,9 @@ int mm355_stage_chains(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_rea
                        int64_t *a_off, uint64_t *a, int64_t a_cap);
 /* chains after the long-join re-chain (mg_lchain_rmq on the chained anchors when U:map.c::mm_map_frag's rescue test fires) or, for MM_F_RMQ
  * presets, after mg_lchain_rmq as the primary chainer: u and the compacted anchors as mm355_stage_chains returns them, plus state[r]:
- * 0 = not re-chained, 1 = re-chained on the device, 2 = left to the literal host implementation (equal range-minimum priorities): a[] then
- * holds the read's anchors sorted by x and u_off[r+1] == u_off[r] */
+ * 0 = not re-chained, 1 = re-chained on the device, 2 = the long-join re-chain is left to the literal host implementation (equal range-minimum
+ * priorities): a[] then holds the read's chained anchors sorted by x and u_off[r+1] == u_off[r]; 3 = every mg_lchain_rmq call of the read is
+ * left to the host (MM_F_RMQ presets whose primary pass was handed back, or MM355_RMQ_ON_HOST=1): a[] = the read's sorted anchors */
 int mm355_stage_rmq(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
                     const int32_t *lens, int64_t *u_off, uint64_t *u, int64_t u_cap,
                     int64_t *a_off, uint64_t *a, int64_t a_cap, int32_t *state);

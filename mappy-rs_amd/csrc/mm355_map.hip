@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <sched.h>
+#include <time.h>
 #include <string.h>
 #include <thread>
 #include <atomic>
@@ -39,16 +40,19 @@ __global__ __launch_bounds__(256) void k_pack_chains(int n_reads, const int64_t 
 #include <functional>
 #include <memory>
 struct PJob { std::atomic<int64_t> next{0}; int64_t n = 0; std::function<void(int64_t, int)> f; std::atomic<int> pending{0}; std::atomic<int> tid{1};
+              std::atomic<int64_t> helper_cpu_ns{0};         // CPU time the helper threads spent inside this job (the caller's own share is in its thread clock)
               std::mutex dm; std::condition_variable dcv; };   // the caller sleeps on dcv until the helpers that started have finished
+static inline int64_t thread_cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (int64_t)ts.tv_sec * 1000000000LL + ts.tv_nsec; }
 class HostPool {
 public:
 	// intentionally leaked: destroying a condition variable with parked workers at process exit would block in pthread_cond_destroy
 	static HostPool &get() { static HostPool *p = new HostPool(); return *p; }
 	int size() const { return (int)th.size() + 1; }
-	void run(int64_t n, int want_threads, std::function<void(int64_t, int)> f) {
-		if (n <= 0) return;
+	// returns the CPU nanoseconds the helper threads spent in the job
+	int64_t run(int64_t n, int want_threads, std::function<void(int64_t, int)> f) {
+		if (n <= 0) return 0;
 		int helpers = std::min<int64_t>((int64_t)std::min(want_threads, size()) - 1, n - 1);
-		if (helpers <= 0) { for (int64_t i = 0; i < n; ++i) f(i, 0); return; }
+		if (helpers <= 0) { for (int64_t i = 0; i < n; ++i) f(i, 0); return 0; }
 		auto j = std::make_shared<PJob>();
 		j->n = n; j->f = std::move(f); j->pending = helpers;
 		{ std::lock_guard<std::mutex> lk(m); for (int h = 0; h < helpers; ++h) q.push_back(j); }
@@ -63,6 +67,7 @@ public:
 			std::unique_lock<std::mutex> lk(j->dm);
 			j->dcv.wait(lk, [&]() { return j->pending.load(std::memory_order_acquire) <= 0; });
 		}
+		return j->helper_cpu_ns.load();
 	}
 private:
 	HostPool() {
@@ -95,17 +100,20 @@ private:
 			std::shared_ptr<PJob> j;
 			{ std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&]() { return !q.empty(); }); j = q.front(); q.pop_front(); }
 			const int tid = j->tid.fetch_add(1);
+			const int64_t c0 = thread_cpu_ns();
 			for (;;) { int64_t i = j->next.fetch_add(1); if (i >= j->n) break; j->f(i, tid); }
+			j->helper_cpu_ns.fetch_add(thread_cpu_ns() - c0);
 			if (j->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(j->dm); j->dcv.notify_all(); }
 		}
 	}
 	std::vector<std::thread> th; std::mutex m; std::condition_variable cv; std::deque<std::shared_ptr<PJob>> q;
 };
 
+static thread_local int64_t tl_helper_cpu_ns = 0;   // helper CPU time of the jobs this (context) thread has issued
 template <typename F>
 static void parallel_for(int64_t n, int n_threads, F f)
 {
-	HostPool::get().run(n, n_threads, std::function<void(int64_t, int)>(f));
+	tl_helper_cpu_ns += HostPool::get().run(n, n_threads, std::function<void(int64_t, int)>(f));
 }
 
 // MM355_TRACE=<file>: host-side phase timeline (context, phase, start ms, end ms), written at process exit
@@ -289,6 +297,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(c->dev));
 	const double t_start = now_ms();
+	const int64_t cpu_start = thread_cpu_ns(); tl_helper_cpu_ns = 0;
 	const mm355_index *mi = c->mi;
 	DevParams pr = mm355_make_params(mo, mi);
 	const int64_t n_reads = c->hb.n_reads;
@@ -371,11 +380,9 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		r.a.assign(pa + vo[i], pa + vo[i + 1]);
 		r.mini_pos.assign(pm + mo_[i], pm + mo_[i + 1]); }
 		if (r.qlen > 0) {
-			const int rst = hb.rmq_state.empty()? -1 : (int)hb.rmq_state[i];
-			if (rmq_chain) {   // primary RMQ chainer: on the device unless it handed the read back (or the stage is switched off)
-				if (rst != 1) mm355_glue_chain_rmq(mi, mo, r);
-				mm355_glue_pre_align(mi, mo, r, 0);
-			} else mm355_glue_pre_align(mi, mo, r, rst);
+			int rst = hb.rmq_state.empty()? 3 : (int)hb.rmq_state[i];   // 3 = MM355_RMQ_HOST_ALL
+			if (rst == 3) { if (rmq_chain) mm355_glue_chain_rmq(mi, mo, r); rst = -1; }   // every mg_lchain_rmq call of this read on the host
+			mm355_glue_pre_align(mi, mo, r, rst);
 		} else r.aligned = true;
 	});
 	double ms_host = now_ms() - t_host0;
@@ -469,6 +476,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	                     tv_front, tv_pack, tv_pre, tv_steps, n_rounds, tv_dp, c->stats.ms_dp, tv_extra, tv_fin, tv_asm, now_ms() - t_start);
 	c->stats.ms_host = ms_host; c->stats.n_ext_rounds = n_rounds;
 	c->stats.ms_total = now_ms() - t_start;
+	c->stats.host_cpu_ms = (double)(thread_cpu_ns() - cpu_start + tl_helper_cpu_ns) * 1e-6;   // this thread (driver calls, waits, serial parts, its share of the jobs) + the pool's helpers
 	if (verbose) mm355_prof_dump(n_reads);
 	if (verbose) mm355_kprof_dump(c);
 	*out = H;

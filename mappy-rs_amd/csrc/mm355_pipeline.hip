@@ -461,33 +461,23 @@ int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
 	return check_err(c);
 }
 
-// mg_lchain_rmq on the device (mm355_rmq.hip).  Long-read presets: the long-join re-chain of every read with more than one chain whose
-// first chain passes the rescue test (the kernel evaluates the test).  MM_F_RMQ presets: the primary chainer over all sorted anchors.
+// mg_lchain_rmq on the device (mm355_rmq.hip), as U:map.c::mm_map_frag calls it:
+//   pass A (MM_F_RMQ presets only): the primary chainer over all sorted anchors of every read (band width bw);
+//   pass B (bw_long > bw, no MM_F_NO_LJOIN): the long-join re-chain of every read that has more than one chain and passes the rescue test
+//           (the kernel evaluates the test), band width bw_long.
 // Leaves hb.n_u / hb.n_v / hb.rmq_state up to date.  MM355_RMQ_ON_HOST=1: the stage does nothing and the host tail chains as in round 2.
-int mm355_run_rmq(mm355_ctx *c, const mm355_mapopt_t *mo, const DevParams &pr)
+static int rmq_pass(mm355_ctx *c, const RmqParams &rp, const DevParams &pr, int nl, std::vector<uint8_t> &state)
 {
 	HostBatch &hb = c->hb;
 	const int64_t n = hb.n_reads;
-	hb.rmq_state.clear();
-	const bool on_host = [] { const char *e = getenv("MM355_RMQ_ON_HOST"); return e && atoi(e) != 0; }();   // (read per call: the tests switch it)
-	const bool primary = (mo->flag & MMF_RMQ) != 0;
-	if (on_host || n == 0) return 0;
-	if (!primary && !(mo->bw_long > mo->bw && (mo->flag & (MMF_SPLICE | MMF_SR | MMF_NO_LJOIN)) == 0)) { hb.rmq_state.assign(n, MM355_RMQ_KEEP); return 0; }
-	RmqParams rp; memset(&rp, 0, sizeof(rp));
-	rp.max_dist = mo->max_gap; rp.max_dist_inner = mo->rmq_inner_dist; rp.bw = primary? mo->bw : mo->bw_long; rp.max_chn_skip = mo->max_chain_skip;
-	rp.cap = mo->rmq_size_cap; rp.pen_gap = pr.pen_gap; rp.pen_skip = pr.pen_skip; rp.rescue_size = mo->rmq_rescue_size; rp.rescue_ratio = mo->rmq_rescue_ratio;
-	rp.primary = primary? 1 : 0;
-	if (c->h_rmq.ensure((size_t)n * 4 + (size_t)n + 64) || c->rmq_list.ensure((size_t)n * 4 + 64) || c->rmq_flag.ensure((size_t)n + 64)) return MM355_ENOMEM;
 	int32_t *hl = (int32_t*)c->h_rmq.p; uint8_t *hf = (uint8_t*)c->h_rmq.p + (size_t)n * 4;
-	int nl = 0;
-	for (int64_t i = 0; i < n; ++i) if (primary? hb.n_a[i] > 0 : hb.n_u[i] > 1) hl[nl++] = (int32_t)i;
-	hb.rmq_state.assign(n, MM355_RMQ_KEEP);
+	state.assign(n, MM355_RMQ_KEEP);
 	if (nl == 0) return 0;
 	// the reads with the most anchors first: the longest dependence chain starts at t = 0
-	std::stable_sort(hl, hl + nl, [&](int32_t x, int32_t y) { return (primary? hb.n_a[x] > hb.n_a[y] : hb.n_v[x] > hb.n_v[y]); });
+	std::stable_sort(hl, hl + nl, [&](int32_t x, int32_t y) { return (rp.primary? hb.n_a[x] > hb.n_a[y] : hb.n_v[x] > hb.n_v[y]); });
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
 	HIPCHK(hipMemcpyAsync(c->rmq_list.p, hl, (size_t)nl * 4, hipMemcpyHostToDevice, c->st));
-	HIPCHK(hipMemsetAsync(c->rmq_flag.p, primary? MM355_RMQ_DONE : MM355_RMQ_KEEP, (size_t)n, c->st));
+	HIPCHK(hipMemsetAsync(c->rmq_flag.p, rp.primary? MM355_RMQ_DONE : MM355_RMQ_KEEP, (size_t)n, c->st));
 	unsigned long long *ctr = c->counters.as<unsigned long long>() + CTR_RMQ_OFF;
 	HIPCHK(hipMemsetAsync(ctr, 0, CTR_RMQ_WORDS * 8, c->st));
 	{ EvTimer t(c, &c->stats.ms_rmq);
@@ -500,10 +490,45 @@ int mm355_run_rmq(mm355_ctx *c, const mm355_mapopt_t *mo, const DevParams &pr)
 	int rc = check_err(c);   // (synchronises the stream)
 	if (rc) return rc;
 	for (int64_t i = 0; i < n; ++i) {
-		hb.rmq_state[i] = hf[i];
+		state[i] = hf[i];
 		if (hf[i] == MM355_RMQ_DONE) ++c->stats.n_rmq_reads; else if (hf[i] == MM355_RMQ_HOST) ++c->stats.n_rmq_host;
 	}
 	for (int k = 0; k < CTR_RMQ_WORDS; ++k) c->stats.rmq_scanned += (int64_t)hc[k];
+	return 0;
+}
+
+int mm355_run_rmq(mm355_ctx *c, const mm355_mapopt_t *mo, const DevParams &pr)
+{
+	HostBatch &hb = c->hb;
+	const int64_t n = hb.n_reads;
+	hb.rmq_state.clear();
+	const bool on_host = [] { const char *e = getenv("MM355_RMQ_ON_HOST"); return e && atoi(e) != 0; }();   // (read per call: the tests switch it)
+	const bool primary = (mo->flag & MMF_RMQ) != 0;
+	const bool ljoin = mo->bw_long > mo->bw && (mo->flag & (MMF_SPLICE | MMF_SR | MMF_NO_LJOIN)) == 0;
+	if (on_host || n == 0) return 0;
+	if (!primary && !ljoin) { hb.rmq_state.assign(n, MM355_RMQ_KEEP); return 0; }
+	RmqParams rp; memset(&rp, 0, sizeof(rp));
+	rp.max_dist = mo->max_gap; rp.max_dist_inner = mo->rmq_inner_dist; rp.max_chn_skip = mo->max_chain_skip;
+	rp.cap = mo->rmq_size_cap; rp.pen_gap = pr.pen_gap; rp.pen_skip = pr.pen_skip; rp.rescue_size = mo->rmq_rescue_size; rp.rescue_ratio = mo->rmq_rescue_ratio;
+	if (c->h_rmq.ensure((size_t)n * 4 + (size_t)n + 64) || c->rmq_list.ensure((size_t)n * 4 + 64) || c->rmq_flag.ensure((size_t)n + 64)) return MM355_ENOMEM;
+	int32_t *hl = (int32_t*)c->h_rmq.p;
+	std::vector<uint8_t> st_a, st_b;
+	int rc;
+	if (primary) {
+		int nl = 0;
+		for (int64_t i = 0; i < n; ++i) if (hb.n_a[i] > 0) hl[nl++] = (int32_t)i;
+		rp.primary = 1; rp.bw = mo->bw;
+		if ((rc = rmq_pass(c, rp, pr, nl, st_a))) return rc;
+	}
+	if (ljoin) {
+		int nl = 0;
+		for (int64_t i = 0; i < n; ++i) if (hb.n_u[i] > 1 && (!primary || st_a[i] == MM355_RMQ_DONE)) hl[nl++] = (int32_t)i;
+		rp.primary = 0; rp.bw = mo->bw_long;
+		if ((rc = rmq_pass(c, rp, pr, nl, st_b))) return rc;
+	} else st_b.assign(n, MM355_RMQ_KEEP);
+	hb.rmq_state.resize(n);
+	for (int64_t i = 0; i < n; ++i)
+		hb.rmq_state[i] = primary && st_a[i] == MM355_RMQ_HOST? MM355_RMQ_HOST_ALL : primary && st_a[i] == MM355_RMQ_KEEP && hb.n_a[i] > 0? MM355_RMQ_HOST_ALL : st_b[i];
 	return 0;
 }
 
@@ -617,9 +642,9 @@ extern "C" int mm355_stage_rmq(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t
 	HostBatch &hb = c->hb;
 	int64_t tu = 0, tv = 0;
 	for (int64_t i = 0; i < n_reads; ++i) {
-		const int st = hb.rmq_state.empty()? MM355_RMQ_HOST : hb.rmq_state[i];
+		const int st = hb.rmq_state.empty()? MM355_RMQ_HOST_ALL : hb.rmq_state[i];
 		state[i] = st;
-		u_off[i] = tu; a_off[i] = tv; tu += st == MM355_RMQ_HOST? 0 : hb.n_u[i]; tv += hb.n_v[i];
+		u_off[i] = tu; a_off[i] = tv; tu += st >= MM355_RMQ_HOST? 0 : hb.n_u[i]; tv += hb.n_v[i];
 	}
 	u_off[n_reads] = tu; a_off[n_reads] = tv;
 	if (tu > u_cap || tv > a_cap) return MM355_ENOMEM;

@@ -15,6 +15,8 @@ struct RmqParams {            // arguments of U:lchain.c::mg_lchain_rmq + the re
 #define MM355_RMQ_KEEP 0
 #define MM355_RMQ_DONE 1
 #define MM355_RMQ_HOST 2
+#define MM355_RMQ_HOST_ALL 3    // host-side summary only (hb.rmq_state): nothing of this read was chained by mg_lchain_rmq on the device -- MM_F_RMQ
+                                // presets whose primary pass handed the read back, or the stage switched off: the host runs every mg_lchain_rmq call
 #ifdef __HIPCC__
 int mm355_launch_rmq(const RmqParams &rp, const DevParams &pr, const DevBatch &bt, DevAnchors &an, const int32_t *d_list, int n_list, uint8_t *d_flag,
                      int *err, unsigned long long *ctr, hipStream_t st);

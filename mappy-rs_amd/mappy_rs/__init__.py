@@ -17,6 +17,7 @@ import os
 import queue
 import threading
 import time
+import weakref
 
 # ROCclr multiplexes all HIP streams over GPU_MAX_HW_QUEUES hardware queues (default 4); the pipelined map_batch keeps several contexts in
 # flight and measures best with 8 (bench.py sets the same).  Only effective if the HIP runtime has not been started yet.
@@ -36,36 +37,85 @@ WORK_QUEUE_CAP = 50000
 RESULT_CHANNEL_CAP = 20000
 
 
-class Mapping:
-    """Result record; fields and aliases of mappy_rs::Mapping (lib.rs:109-154, 196-284)."""
+_HIT_FIELDS = [k for k, _t in _ffi.Hit._fields_]
+_F = {k: i for i, k in enumerate(_HIT_FIELDS)}
+_HIT_DTYPE = np.dtype([(k, np.dtype(t)) for k, t in _ffi.Hit._fields_], align=True)
+(_QS, _QE, _ST, _RID, _TL, _TS, _TE, _ML, _BL, _MQ, _PR, _NM, _NC, _CO, _CSO, _CSL, _MDO, _MDL) = (_F[k] for k in (
+    "query_start", "query_end", "strand", "rid", "target_len", "target_start", "target_end", "match_len", "block_len", "mapq",
+    "is_primary", "NM", "n_cigar", "cigar_off", "cs_off", "cs_len", "md_off", "md_len"))
 
-    __slots__ = ("query_start", "query_end", "_strand", "target_name", "target_len", "target_start", "target_end",
-                 "match_len", "block_len", "mapq", "is_primary", "_cig", "NM", "MD", "cs")
+
+class _HitBatch:
+    """what the Mapping records of one mm355_hits_t share: the packed CIGAR words, the string arena, the contig names"""
+    __slots__ = ("cig", "sbuf", "names")
+
+    def __init__(self, cig, sbuf, names):
+        self.cig, self.sbuf, self.names = cig, sbuf, names
+
+
+class Mapping:
+    """Result record; fields and aliases of mappy_rs::Mapping (lib.rs:109-154, 196-284).
+
+    A record that comes out of the mapping path is a view: `_r` is the row of the C-ABI hit array (a tuple, converted in bulk), `_b`
+    the arenas it points into; fields are read on access (the reference converts its Vec / Strings on access as well, lib.rs:196-284).
+    Creating a record is two slot stores -- the per-hit cost under the GIL that used to cap `map_batch` below the C-ABI rate."""
+
+    __slots__ = ("_b", "_r", "_cig", "_own")
+    FIELDS = ("query_start", "query_end", "strand", "target_name", "target_len", "target_start", "target_end",
+              "match_len", "block_len", "mapq", "is_primary", "cigar", "NM", "MD", "cs")
 
     def __init__(self, query_start, query_end, strand, target_name, target_len, target_start, target_end, match_len,
                  block_len, mapq, is_primary, cigar, NM, MD, cs):
-        self.query_start = query_start
-        self.query_end = query_end
-        self._strand = strand
-        self.target_name = target_name
-        self.target_len = target_len
-        self.target_start = target_start
-        self.target_end = target_end
-        self.match_len = match_len
-        self.block_len = block_len
-        self.mapq = mapq
-        self.is_primary = is_primary
-        self._cig = cigar          # list of (length, op) or the packed uint32 words (length << 4 | op) until first read
-        self.NM = NM
-        self.MD = MD
-        self.cs = cs
+        self._b = None
+        self._r = None
+        self._cig = list(cigar)
+        self._own = (query_start, query_end, strand, target_name, target_len, target_start, target_end, match_len, block_len, mapq,
+                     bool(is_primary), NM, MD, cs)
+
+    @classmethod
+    def _view(cls, batch, row):
+        m = object.__new__(cls)
+        m._b = batch
+        m._r = row
+        m._cig = None
+        m._own = None
+        return m
+
+    query_start = property(lambda s: s._r[_QS] if s._own is None else s._own[0])
+    query_end = property(lambda s: s._r[_QE] if s._own is None else s._own[1])
+    strand = property(lambda s: s._r[_ST] if s._own is None else s._own[2])          # +1 / -1 (lib.rs:231-237)
+    target_name = property(lambda s: s._b.names[s._r[_RID]] if s._own is None else s._own[3])
+    target_len = property(lambda s: s._r[_TL] if s._own is None else s._own[4])
+    target_start = property(lambda s: s._r[_TS] if s._own is None else s._own[5])
+    target_end = property(lambda s: s._r[_TE] if s._own is None else s._own[6])
+    match_len = property(lambda s: s._r[_ML] if s._own is None else s._own[7])
+    block_len = property(lambda s: s._r[_BL] if s._own is None else s._own[8])
+    mapq = property(lambda s: s._r[_MQ] if s._own is None else s._own[9])
+    is_primary = property(lambda s: bool(s._r[_PR]) if s._own is None else s._own[10])
+    NM = property(lambda s: s._r[_NM] if s._own is None else s._own[11])
+
+    @property
+    def MD(self):
+        if self._own is not None:
+            return self._own[12]
+        r = self._r
+        return self._b.sbuf[r[_MDO]:r[_MDO] + r[_MDL]].decode() if r[_MDL] >= 0 else None
+
+    @property
+    def cs(self):
+        if self._own is not None:
+            return self._own[13]
+        r = self._r
+        return self._b.sbuf[r[_CSO]:r[_CSO] + r[_CSL]].decode() if r[_CSL] >= 0 else None
 
     @property
     def cigar(self):
-        """list of (length, op) tuples, as mappy-rs; unpacked on first access (the reference converts its Vec on access as well)"""
+        """list of (length, op) tuples, as mappy-rs; unpacked from the packed uint32 words (length << 4 | op) on first access"""
         c = self._cig
-        if not isinstance(c, list):
-            c = list(zip((c >> 4).tolist(), (c & 0xf).tolist()))
+        if c is None:
+            r = self._r
+            w = self._b.cig[r[_CO]:r[_CO] + r[_NC]]
+            c = list(zip((w >> 4).tolist(), (w & 0xf).tolist()))
             self._cig = c
         return c
 
@@ -76,7 +126,6 @@ class Mapping:
     r_en = property(lambda s: s.target_end)
     q_st = property(lambda s: s.query_start)
     q_en = property(lambda s: s.query_end)
-    strand = property(lambda s: s._strand)          # +1 / -1 (lib.rs:231-237)
     blen = property(lambda s: s.block_len)
     mlen = property(lambda s: s.match_len)
 
@@ -91,50 +140,40 @@ class Mapping:
 
     def __str__(self):  # PAF-like, lib.rs:159-180
         tp = "tp:A:P" if self.is_primary else "tp:A:S"
-        return "\t".join(str(x) for x in (self.query_start, self.query_end, "+" if self._strand > 0 else "-",
+        return "\t".join(str(x) for x in (self.query_start, self.query_end, "+" if self.strand > 0 else "-",
                                           self.target_name, self.target_len, self.target_start, self.target_end,
                                           self.match_len, self.block_len, self.mapq, tp, "cg:Z:" + self.cigar_str))
 
     def __repr__(self):
-        return "Mapping(%s)" % ", ".join("%s=%r" % (k.lstrip("_"), getattr(self, "cigar" if k == "_cig" else k)) for k in self.__slots__)
+        return "Mapping(%s)" % ", ".join("%s=%r" % (k, getattr(self, k)) for k in Mapping.FIELDS)
 
     def __eq__(self, o):
-        return isinstance(o, Mapping) and all(getattr(self, "cigar" if k == "_cig" else k) == getattr(o, "cigar" if k == "_cig" else k)
-                                              for k in self.__slots__)
+        return isinstance(o, Mapping) and all(getattr(self, k) == getattr(o, k) for k in Mapping.FIELDS)
 
-
-_HIT_DTYPE = np.dtype([(k, np.dtype(t)) for k, t in _ffi.Hit._fields_], align=True)
+    __hash__ = None
 
 
 def _batch_to_mappings(hp, n_reads, names):
-    """all hits of one mm355_hits_t -> list (per read) of list[Mapping] or RuntimeError.  One bulk copy per array; CIGARs stay packed
-    (unpacked when .cigar is first read), strings are sliced from one bytes object."""
+    """all hits of one mm355_hits_t -> list (per read) of list[Mapping] or RuntimeError.  One bulk copy per array (hit rows, CIGAR words,
+    string arena); every Mapping is a view of its row (fields, cs / MD strings and the CIGAR list are produced on access)."""
     h = hp.contents
     nh = int(h.n_hits)
     off = np.ctypeslib.as_array(h.hit_off, shape=(n_reads + 1,)).tolist()
-    status = np.ctypeslib.as_array(h.status, shape=(max(n_reads, 1),)).tolist()
+    status = np.ctypeslib.as_array(h.status, shape=(max(n_reads, 1),))
+    empty = np.flatnonzero(status[:n_reads] == _ffi.MM355_EEMPTY).tolist() if n_reads else []
     if nh:
         assert _HIT_DTYPE.itemsize == C.sizeof(_ffi.Hit)
         rows = np.frombuffer(C.string_at(h.hits, nh * C.sizeof(_ffi.Hit)), dtype=_HIT_DTYPE).tolist()
         cig = np.ctypeslib.as_array(h.cigar, shape=(max(int(h.n_cigar), 1),)).copy()
         sbuf = C.string_at(h.str, int(h.n_str)) if h.n_str else b""
-    F = {k: i for i, (k, _t) in enumerate(_ffi.Hit._fields_)}
-    qs, qe, st, rid, tl, ts, te, ml, bl, mq, pr, nm, nc, co, cso, csl, mdo, mdl = (F[k] for k in (
-        "query_start", "query_end", "strand", "rid", "target_len", "target_start", "target_end", "match_len", "block_len", "mapq",
-        "is_primary", "NM", "n_cigar", "cigar_off", "cs_off", "cs_len", "md_off", "md_len"))
-    out = []
-    for i in range(n_reads):
-        if status[i] == _ffi.MM355_EEMPTY:
-            out.append(RuntimeError("Sequence is empty"))
-            continue
-        ms = []
-        for k in range(off[i], off[i + 1]):
-            x = rows[k]
-            cs = sbuf[x[cso]:x[cso] + x[csl]].decode() if x[csl] >= 0 else None
-            md = sbuf[x[mdo]:x[mdo] + x[mdl]].decode() if x[mdl] >= 0 else None
-            ms.append(Mapping(x[qs], x[qe], x[st], names[x[rid]], x[tl], x[ts], x[te], x[ml], x[bl], x[mq], bool(x[pr]),
-                              cig[x[co]:x[co] + x[nc]], x[nm], md, cs))
-        out.append(ms)
+        B = _HitBatch(cig, sbuf, names)
+        view = Mapping._view
+        ms = [view(B, r) for r in rows]
+        out = [ms[off[i]:off[i + 1]] for i in range(n_reads)]
+    else:
+        out = [[] for _ in range(n_reads)]
+    for i in empty:
+        out[i] = RuntimeError("Sequence is empty")
     return out
 
 
@@ -191,6 +230,26 @@ class _Channel:
         return len(self.d)
 
 
+class _BatchState:
+    """Everything the worker threads and the collector of one map_batch call share.  The threads hold THIS object, never the iterator
+    the caller gets: when the caller drops the iterator (or calls close()) a weakref finalizer sets `cancel` / `abandoned` here, the
+    workers blocked on the full result channel give up, return their GPU contexts to the Aligner's pool and exit -- the reference's
+    workers stop the same way when their `tx.send` fails because the receiver is gone."""
+
+    def __init__(self):
+        self.ch = _Channel(RESULT_CHANNEL_CAP)
+        self.cancel = threading.Event()      # workers stop taking sub-batches (worker error, validation error, abandoned iterator)
+        self.abandoned = threading.Event()   # nobody will ever read the channel again
+        self.errors = []
+        self.n_sub_batches = 0
+        self.t_sub_done = []      # wall-clock time each sub-batch left the GPU pipeline (tests / latency diagnostics)
+        self.threads = []         # workers + collector (tests: they must all exit once the iterator is gone)
+
+    def close(self):
+        self.cancel.set()
+        self.abandoned.set()
+
+
 class AlignmentBatchResultIter:
     """Iterator returned by map_batch (lib.rs:923-991): yields (list[Mapping], dict) in COMPLETION order.
 
@@ -200,15 +259,14 @@ class AlignmentBatchResultIter:
 
     _FINISHED = object()
 
-    def __init__(self):
-        self._ch = _Channel(RESULT_CHANNEL_CAP)
+    def __init__(self, state=None):
+        self._st = state if state is not None else _BatchState()
         self._done = False
-        self._cancel = threading.Event()      # workers stop taking sub-batches (worker error, validation error, abandoned iterator)
-        self._abandoned = threading.Event()   # nobody will ever read the channel again
-        self._errors = []
-        self.n_sub_batches = 0
-        self.t_sub_done = []      # wall-clock time each sub-batch left the GPU pipeline (tests / latency diagnostics)
         self.t_first_yield = None
+        self._fin = weakref.finalize(self, _BatchState.close, self._st)   # the state, not the iterator, is what the threads keep alive
+
+    n_sub_batches = property(lambda s: s._st.n_sub_batches)
+    t_sub_done = property(lambda s: s._st.t_sub_done)
 
     def __iter__(self):
         return self
@@ -216,11 +274,11 @@ class AlignmentBatchResultIter:
     def __next__(self):
         if self._done:
             raise StopIteration("Finished")
-        r = self._ch.get()
+        r = self._st.ch.get()
         if r is AlignmentBatchResultIter._FINISHED:
             self._done = True
-            if self._errors:
-                raise self._errors[0]
+            if self._st.errors:
+                raise self._st.errors[0]
             raise StopIteration("Finished")
         if self.t_first_yield is None:
             self.t_first_yield = time.perf_counter()
@@ -228,11 +286,7 @@ class AlignmentBatchResultIter:
 
     def close(self):
         """stop mapping what has not been started yet; results already produced are dropped"""
-        self._cancel.set()
-        self._abandoned.set()
-
-    def __del__(self):
-        self.close()
+        self._st.close()
 
 
 class Aligner:
@@ -432,7 +486,7 @@ class Aligner:
         if isinstance(seqs, (dict, str, bytes)) or not (isinstance(seqs, (list, tuple, collections.abc.Sequence)) or
                                                         isinstance(seqs, collections.abc.Iterator)):
             raise TypeError("Unsupported batch type, pass a list, iter, generator or tuple")
-        res = AlignmentBatchResultIter()
+        st = _BatchState()
         max_workers = max(1, min(self._n_threads, 8)) * len(self._devices)
         try:
             n_known = len(seqs)
@@ -447,37 +501,48 @@ class Aligner:
 
         work = collections.deque()          # sub-batches (reads, items) waiting for a worker
         cv = threading.Condition()
-        state = {"closed": False, "n_sub": 0}
-        workers = []
+        state = {"closed": False, "n_sub": 0, "pending": 0}     # pending: reads in `work`, not yet taken by a worker
+        workers = st.threads
         self._names()                       # fill the name cache before the workers read it
+        map_many, acquire, release = self._map_many, self._ctx_acquire, self._ctx_release
 
+        # (the closures below capture `st`, never the iterator handed to the caller)
         def worker(slot):
             ctx = None
             try:
-                ctx = self._ctx_acquire(slot)
+                ctx = acquire(slot)
                 while True:
                     with cv:
-                        while not work and not state["closed"] and not res._cancel.is_set():
+                        while not work and not state["closed"] and not st.cancel.is_set():
                             cv.wait(0.2)
-                        if res._cancel.is_set() or not work:
+                        if st.cancel.is_set() or not work:
                             return
                         reads, items = work.popleft()
-                    maps = self._map_many(reads, _ffi.OUT_CS, ctx[1])         # cs=true, MD=false: lib.rs:589-590
-                    res.t_sub_done.append(time.perf_counter())
+                        state["pending"] -= len(reads)
+                        cv.notify_all()                                   # the producer may be waiting for room (back-off)
+                    maps = map_many(reads, _ffi.OUT_CS, ctx[1])           # cs=true, MD=false: lib.rs:589-590
+                    st.t_sub_done.append(time.perf_counter())
                     # a worker error on one read => no result for that id (lib.rs:621-623)
                     out = [(m, it) for m, it in zip(maps, items) if not isinstance(m, Exception)]
-                    if not res._ch.put_many(out, res._cancel):
+                    if not st.ch.put_many(out, st.cancel):
                         return
             except Exception as e:   # surfaced by the iterator when it finishes, like a worker panic in the reference
-                res._errors.append(e)
-                res._cancel.set()
+                st.errors.append(e)
+                st.cancel.set()
             finally:
                 if ctx is not None:
-                    self._ctx_release(ctx)
+                    release(ctx)
 
         def dispatch(reads, items):
             with cv:
+                # the reference's work queue holds 50 000 reads (lib.rs:429): with back-off the producer sleeps until the workers have
+                # made room (lib.rs:870-888), so a huge iterable never sits in memory as pending sub-batches
+                # (not while the result channel is full: nobody reads it before map_batch has returned, so the workers cannot make room)
+                while (back_off and state["pending"] > 0 and state["pending"] + len(reads) > WORK_QUEUE_CAP and not st.cancel.is_set()
+                       and len(st.ch) < RESULT_CHANNEL_CAP):
+                    cv.wait(0.05)
                 work.append((reads, items))
+                state["pending"] += len(reads)
                 state["n_sub"] += 1
                 cv.notify()
             if len(workers) < max_workers and len(workers) < state["n_sub"]:
@@ -489,7 +554,7 @@ class Aligner:
             with cv:
                 state["closed"] = True
                 cv.notify_all()
-            for t in workers:
+            for t in list(workers):
                 t.join()
 
         cur_reads, cur_items, cur_bases = [], [], 0
@@ -498,7 +563,7 @@ class Aligner:
                 if not isinstance(item, dict):
                     raise TypeError("Element in iterable is not a dictionary")
                 if "seq" not in item:
-                    raise KeyError("AHHH Key \U0001F5DD️  not found in iterated dictionary")
+                    raise KeyError("AHHH Key \U0001F5DD\uFE0F  not found in iterated dictionary")
                 s = item["seq"]
                 if not isinstance(s, str):
                     raise ValueError("`seq` must be a string")
@@ -515,19 +580,21 @@ class Aligner:
             if cur_reads:
                 dispatch(cur_reads, cur_items)
         except BaseException:
-            res.close()                           # nothing is yielded: the workers stop after their current sub-batch
+            st.close()                            # nothing is yielded: the workers stop after their current sub-batch
             close_and_join()
             raise
-        res.n_sub_batches = state["n_sub"]
+        st.n_sub_batches = state["n_sub"]
 
         def finalize():                           # the reference's collector thread: `Finished` once every worker is done (lib.rs:804-815)
             close_and_join()
-            while not res._ch.put_many([AlignmentBatchResultIter._FINISHED], res._abandoned):
-                if res._abandoned.is_set():
+            while not st.ch.put_many([AlignmentBatchResultIter._FINISHED], st.abandoned):
+                if st.abandoned.is_set():
                     return
 
-        threading.Thread(target=finalize, daemon=True).start()
-        return res
+        tf = threading.Thread(target=finalize, daemon=True)
+        tf.start()
+        st.threads = list(workers) + [tf]
+        return AlignmentBatchResultIter(st)
 
     def _stage_runner(self):
         """per-stage access to the same kernels (parity tests, kernel bench)"""

@@ -308,22 +308,24 @@ class OracleAligner:
         return ua, aa
 
     def chains_final(self, anchors, qlen):
-        """what mm_map_frag (mmo_map.c) holds before mm_gen_regs: (u, anchors, did_rmq).  MM_F_RMQ presets: mg_lchain_rmq is the primary
+        """what mm_map_frag (mmo_map.c) holds before mm_gen_regs: (u, anchors, did) with did bit 0 = primary RMQ chainer ran, bit 1 = long-join re-chain ran.  MM_F_RMQ presets: mg_lchain_rmq is the primary
         chainer; otherwise mg_lchain_dp and, when the rescue test fires, the long-join re-chain (radix_sort_128x + mg_lchain_rmq, bw_long)"""
         L = lib()
         mo = self.mo
+        did = 0
         if mo.flag & 0x80000000:
             u, a = self._lchain_rmq(anchors, mo.bw)
-            return u, a, 1
-        u, a = self.chains(anchors, qlen)
+            did = 1
+        else:
+            u, a = self.chains(anchors, qlen)
         if mo.bw_long > mo.bw and (mo.flag & (0x080 | 0x1000 | 0x400)) == 0 and len(u) > 1:
             st = int(np.int32(a[0, 1] & np.uint64(0xffffffff))); en = int(np.int32(a[int(u[0] & np.uint64(0xffffffff)) - 1, 1] & np.uint64(0xffffffff)))
             if qlen - (en - st) > mo.rmq_rescue_size or np.float32(en - st) > np.float32(qlen) * np.float32(mo.rmq_rescue_ratio):
                 srt = np.ascontiguousarray(a, dtype=np.uint64).copy()
                 L.mmo_radix_sort_128x(srt.ctypes.data, srt.ctypes.data + srt.shape[0] * 16)
                 u, a = self._lchain_rmq(srt, mo.bw_long)
-                return u, a, 1
-        return u, a, 0
+                return u, a, did + 2
+        return u, a, did
 
     def map(self, seq, cs=False, MD=False):
         L = lib()

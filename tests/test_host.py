@@ -208,3 +208,83 @@ def test_index_build_with_repeats_matches_oracle(ffi, tmp_path):
     assert L.mm355_index_getseq(h, 1, 500, 1500, out) == 1000
     assert bytes(out) == bytes(int(c) for c in g[1][500:1500])
     L.mm355_index_free(h)
+
+
+# ---- map_batch plumbing with the GPU call mocked out (host logic only: channel, back-pressure, worker lifetime)
+def _mocked_aligner(golden_dir, monkeypatch, delay=0.0):
+    import time
+    import mappy_rs
+    al = mappy_rs.Aligner(os.path.join(golden_dir, "test.mmi"))
+    taken, given = [], []
+    monkeypatch.setattr(al, "_ctx_acquire", lambda slot: (taken.append(slot), (0, slot))[1])
+    monkeypatch.setattr(al, "_ctx_release", lambda dc: given.append(dc[1]))
+
+    def fake_map_many(seqs, flags, ctx=None):
+        if delay:
+            time.sleep(delay)
+        return [[] for _ in seqs]
+    monkeypatch.setattr(al, "_map_many", fake_map_many)
+    al.enable_threading(4)
+    return al, taken, given
+
+
+def test_abandoned_map_batch_iterator_releases_workers_and_contexts(ffi, golden_dir, monkeypatch):
+    """more results than the channel holds, the iterator dropped after one item: workers blocked on the full channel must give up,
+    hand their contexts back and exit (they used to poll for the life of the process)"""
+    import gc
+    import time
+    import mappy_rs
+    monkeypatch.setattr(mappy_rs, "RESULT_CHANNEL_CAP", 500)
+    al, taken, given = _mocked_aligner(golden_dir, monkeypatch)
+    it = al.map_batch([{"seq": "ACGT", "i": i} for i in range(9000)])
+    st = it._st
+    next(it)
+    threads = list(st.threads)
+    assert len(threads) >= 3 and any(t.is_alive() for t in threads)      # blocked: 9000 results do not fit 500 slots
+    del it
+    gc.collect()
+    deadline = time.time() + 10
+    while any(t.is_alive() for t in threads) and time.time() < deadline:
+        time.sleep(0.05)
+    assert not any(t.is_alive() for t in threads)
+    assert sorted(given) == sorted(taken) and len(taken) >= 2               # every context went back to the pool
+
+
+def test_map_batch_back_off_bounds_pending_work(ffi, golden_dir, monkeypatch):
+    """with back_off the producer waits once 50 000 reads are pending (lib.rs:867-888); all results still arrive, in any order"""
+    import mappy_rs
+    monkeypatch.setattr(mappy_rs, "WORK_QUEUE_CAP", 3000)
+    al, taken, given = _mocked_aligner(golden_dir, monkeypatch, delay=0.002)
+    ids = set()
+    for m, d in al.map_batch(({"seq": "ACGT", "i": i} for i in range(20000))):
+        ids.add(d["i"])
+    assert len(ids) == 20000
+    with pytest.raises(RuntimeError, match="without backoff"):
+        monkeypatch.setattr(mappy_rs, "WORK_QUEUE_CAP", 50000)
+        al.map_batch([{"seq": "ACGT"}] * 50001, back_off=False)
+
+
+def test_mapping_views_read_the_hit_rows(ffi):
+    """_batch_to_mappings: Mapping records are views of the C-ABI arrays; every field, cs / MD and the CIGAR come out on access"""
+    import mappy_rs
+    from mappy_rs import _ffi
+    hits = (_ffi.Hit * 2)()
+    hits[0].query_start, hits[0].query_end, hits[0].strand, hits[0].rid, hits[0].target_len = 3, 40, -1, 1, 999
+    hits[0].target_start, hits[0].target_end, hits[0].match_len, hits[0].block_len, hits[0].mapq, hits[0].is_primary, hits[0].NM = 10, 47, 30, 37, 60, 1, 7
+    hits[0].n_cigar, hits[0].cigar_off, hits[0].cs_off, hits[0].cs_len, hits[0].md_off, hits[0].md_len = 2, 1, 0, 3, 4, 2
+    hits[1].rid, hits[1].strand, hits[1].n_cigar, hits[1].cigar_off, hits[1].cs_len, hits[1].md_len = 0, 1, 1, 0, -1, -1
+    cig = (C.c_uint32 * 3)(5 << 4, (30 << 4) | 0, (7 << 4) | 2)
+    sbuf = C.create_string_buffer(b":30\x0012\x00")
+    off = (C.c_int64 * 4)(0, 1, 1, 2)
+    status = (C.c_int32 * 3)(0, _ffi.MM355_EEMPTY, 0)
+    H = _ffi.Hits()
+    H.n_reads, H.hit_off, H.status, H.hits = 3, off, status, hits
+    H.cigar, H.str, H.n_hits, H.n_cigar, H.n_str = cig, C.cast(sbuf, type(H.str)), 2, 3, 7
+    out = mappy_rs._batch_to_mappings(C.pointer(H), 3, ["chrA", "chrB"])
+    assert isinstance(out[1], RuntimeError) and str(out[1]) == "Sequence is empty"
+    m = out[0][0]
+    assert (m.q_st, m.q_en, m.strand, m.ctg, m.ctg_len, m.r_st, m.r_en, m.mlen, m.blen, m.mapq, m.is_primary, m.NM) == (3, 40, -1, "chrB", 999, 10, 47, 30, 37, 60, True, 7)
+    assert m.cigar == [(30, 0), (7, 2)] and m.cigar_str == "30M7D" and m.cs == ":30" and m.MD == "12"
+    m2 = out[2][0]
+    assert m2.ctg == "chrA" and m2.cs is None and m2.MD is None and m2.cigar == [(5, 0)] and not m2.is_primary
+    assert m == m and m != m2 and "cg:Z:30M7D" in str(m)
