@@ -165,7 +165,7 @@ def _synth_block(b):
     return rd
 
 
-def shard_reads(wl, g, n_per_gpu, rank, world, procs):
+def shard_reads(wl, g, n_per_gpu, rank, world, procs=1):
     """rank's shard of the ONE read set of world * n_per_gpu reads: contiguous, balanced by cumulative bases.  The blocks of
     the read set (synthdata.READ_BLOCK reads each, one PRNG stream per block) are synthesised by forked worker processes -- this runs
     before anything in the process has touched the GPU."""
