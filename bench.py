@@ -366,7 +366,7 @@ def main():
         L.mm355_free_hits(hp)
         st = _ffi.Stats()
         L.mm355_get_stats(ctx, C.byref(st))
-        return aligned, n_hits, st, nr
+        return aligned, n_hits, st, nr, time.perf_counter()
 
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(n_thr)
@@ -375,8 +375,13 @@ def main():
         """one pass over every listed block: every host thread maps its own sub-batches of block after block without waiting for the other
         threads between blocks (the barriers bracket the whole region, not a step)"""
         def thread(ti):
-            return [step_one(b, si, resident) for b in blocks for si in range(ti, n_str, n_thr)]
+            return [(k,) + step_one(b, si, resident) for k, b in enumerate(blocks) for si in range(ti, n_str, n_thr)]
         res = [r for part in pool.map(thread, range(n_thr)) for r in part]
+        done = [0.0] * len(blocks)                 # when the last sub-batch of every step finished
+        for r in res:
+            done[r[0]] = max(done[r[0]], r[5])
+        res = [r[1:5] for r in res]
+        run_blocks.step_done = done
         agg_st = {}
         for _a, _h, st, _n in res:
             for k, _t in _ffi.Stats._fields_:
@@ -401,6 +406,7 @@ def main():
         aligned_tot, n_hits, agg, n_mapped = run_blocks(resident, blocks)
         barrier()
         dt = time.perf_counter() - t0
+        timed.step_ms = [round((b - a) * 1e3, 1) for a, b in zip([t0] + run_blocks.step_done[:-1], run_blocks.step_done)]
         dt, aligned_all, bases_all = aggregate(dist, dt, aligned_tot, sum(block_bases[b] for b in blocks))
         return dt, aligned_all, bases_all, agg, n_mapped
 
@@ -411,6 +417,7 @@ def main():
     if warm_blocks:
         run_blocks(True, warm_blocks)
     dt, aligned_all, bases_all, agg, n_mapped = timed(True, timed_blocks)             # `value`: reads resident in HBM
+    step_ms = timed.step_ms
     if pcie_blocks:
         dt_p, aligned_p, _b, _agg, _n = timed(False, list(range(pcie_blocks)))      # host buffers in, records out (same reads again)
     else:
@@ -496,6 +503,8 @@ def main():
             "value_basis": "reads resident in HBM when the timed region starts (every block uploaded beforehand), hit records returned to the host; "
                            "the PCIe-inclusive rate of the drop-in call (host buffers in) is pcie_inclusive_mbases_per_s",
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
+            "step_ms": dict(median=float(np.median(step_ms)), min=min(step_ms), max=max(step_ms), all=step_ms,
+                            note="completion of the last sub-batch of every step, rank 0 (the threads do not wait for one another between steps)"),
             "pcie_inclusive_mbases_per_s": None if dt_p is None else round(aligned_p / dt_p / 1e6, 3),
             "roofline": roof[dom], "roofline_seed_lookup": rl, "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
             "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(19) if nl_g[i] > 0},

@@ -12,7 +12,7 @@
 // that chainer used (U:lchain.c: mg_lchain_dp passes bw, mg_lchain_rmq passes its own bw).  Leaves n_u[r], n_v[r], u[] and the compacted
 // anchors in place of a[].
 struct BtLds { SortLds L; uint64_t zstage[Z_STAGE]; int s_nu, s_nv; };
-__device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &bt, const DevAnchors &an, int *err, BtLds *S, const int r, const int n, const int max_drop)
+__device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &bt, const DevAnchors &an, int *err, BtLds *S, const int r, const int n, const int max_drop, const int kp_base = 0)
 {
 	SortLds &L = S->L;
 	uint64_t *zstage = S->zstage;
@@ -42,7 +42,7 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 		n_z += __popcll(mask);
 	}
 	__syncthreads();
-	KPROF(0);
+	KPROF(kp_base + 0);
 	if (n_z == 0) return;
 	WalkScratch ws; ws.out = u2; ws.fpos = (uint32_t*)vi; ws.rank = (uint32_t*)(an.v + o); ws.flab = t8; ws.tcnt = 0;   // v[] is dead after the DP fill
 	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws);
@@ -56,7 +56,7 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	int2 *pf = (int2*)u2;
 	for (int i = lane; i < n; i += WAVE) pf[i] = make_int2(p[i] + 1, f[i]);
 	__syncthreads();
-	KPROF(1);
+	KPROF(kp_base + 1);
 	uint32_t *visited = (uint32_t*)zstage;                    // 2 * Z_STAGE entries
 	const int VCAP = 2 * Z_STAGE;
 	int n_v = 0, n_u = 0;
@@ -118,7 +118,7 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	if (lane == 0) { s_nu = n_u; s_nv = n_v; }
 	__syncthreads();
 	n_u = s_nu; n_v = s_nv;
-	KPROF(2);
+	KPROF(kp_base + 2);
 	if (n_u == 0) return;
 	// compact_a: chains written forward; then chains re-ordered by the x of their first anchor
 	// (1) per-chain start offsets into wk[].y (k<<32|i), b[] filled in forward order
@@ -155,6 +155,6 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	__syncthreads();
 	for (int c = lane; c < n_u; c += WAVE) u[c] = u2[c];
 	if (lane == 0) { an.n_u[r] = n_u; an.n_v[r] = n_v; }
-	KPROF(3);
+	KPROF(kp_base + 3);
 }
 

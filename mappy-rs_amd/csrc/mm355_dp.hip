@@ -563,7 +563,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// t = 0 and the short ones fill in behind them instead of the launch ending on a late-started long one
 		for (size_t k = 0; k < n; ++k) { const int32_t i = h_ord[k]; h_ids[cur[grp[i]]++] = i; }
 	}
-	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64) ||
+	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64, 4) ||
 	    c->dp_work.ensure((off_tot + 16) * 4 + (2 * n + 32) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_dense.ensure((cig_tot + 16) * 4) ||
 	    c->dp_H.ensure((st_tot + 16) * 12)) return MM355_ENOMEM;
 	// One extension round saturates the GPU.  Rounds of different contexts take turns (per device): run side by side they would all

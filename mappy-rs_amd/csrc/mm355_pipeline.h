@@ -7,11 +7,14 @@
 
 struct DBuf {
 	void *p = 0; size_t cap = 0;
-	int ensure(size_t bytes) {
+	int ensure(size_t bytes, int slack_div = 2) {
 		if (bytes <= cap) return 0;
 		if (p) (void)hipFree(p);
-		const size_t slack = bytes / 4 < ((size_t)256 << 20)? bytes / 4 : ((size_t)256 << 20);   // grow-only with headroom, but no more than 256 MB of it:
-		size_t want = bytes + slack + 256;                                                       // several contexts hold multi-GB buffers side by side
+		// grow-only with 50 % headroom: a re-allocation is a hipFree + hipMalloc (both synchronise the device and stall every other context), and
+		// the sub-batches of a read stream differ by tens of per cent in anchors and extension cells; a context's buffers are ~10 GB of 288 GB
+		// (the direction matrices of the extension rounds -- the one buffer of ten and more GB -- take 25 %)
+		const size_t slack = bytes / (size_t)slack_div;
+		size_t want = bytes + slack + 256;
 		if (hipMalloc(&p, want) != hipSuccess) { p = 0; cap = 0; return -1; }
 		cap = want; return 0;
 	}
@@ -24,7 +27,7 @@ struct HBuf {                 // pinned host staging buffer (grow-only)
 	int ensure(size_t bytes) {
 		if (bytes <= cap) return 0;
 		if (p) (void)hipHostFree(p);
-		size_t want = bytes + bytes / 4 + 4096;
+		size_t want = bytes + bytes / 2 + 4096;
 		if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = 0; cap = 0; return -1; }
 		cap = want; return 0;
 	}

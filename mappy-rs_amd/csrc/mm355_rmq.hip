@@ -25,10 +25,12 @@
 #include "mm355_rmq.h"
 
 #define MM355_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(3)
-#define RQ_RING 1024
+#define RQ_RING 512                 // x, y, f, p of the last anchors: covers the inner set (checked) and, usually, the range-minimum winner
 #define RQ_RMASK (RQ_RING - 1)
-#define RQ_INN 1024                 // capacity of the inner set
-#define RQ_TW 2048                  // mark window (> RQ_RING + one wave)
+#define RQ_WRING 2048               // (y, pri) of the last anchors: the range-minimum window (20 kb of reference at ~0.07 chained anchors per base)
+#define RQ_WMASK (RQ_WRING - 1)
+#define RQ_NB (RQ_WRING / 64)       // block summaries of the (y, pri) ring
+#define RQ_TW 1024                  // mark window (> RQ_RING + one wave)
 #define RQ_TWMASK (RQ_TW - 1)
 #define RQ_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 #define A_STAGE 2048
@@ -66,54 +68,6 @@ __device__ inline double rq_ldf64(const double *p)
 	return __longlong_as_double(v);
 }
 
-// ---- sorted key array in LDS (the reference's root_inner): keys (int64)y << 32 | j, ascending
-__device__ inline int rq_count(const long long *inn, int n, long long key, bool or_equal)   // #entries < key (<= key)
-{
-	const int lane = threadIdx.x & 63;
-	int pos = 0;
-	for (int base = 0; base < n; base += WAVE) {
-		const int k = base + lane;
-		const bool c = k < n && (or_equal? inn[k] <= key : inn[k] < key);
-		const unsigned long long m = __ballot(c);
-		pos += __popcll(m);
-		if (m != ~0ULL) break;
-	}
-	return pos;
-}
-__device__ inline void rq_insert(long long *inn, int &n, long long key)
-{
-	const int lane = threadIdx.x & 63;
-	const int pos = rq_count(inn, n, key, false);
-	if (n > pos) {
-		for (int b = pos + ((n - 1 - pos) / WAVE) * WAVE; b >= pos; b -= WAVE) {   // top chunk first: its first slot is free when the chunk below writes into it
-			const int k = b + lane;
-			long long v = 0;
-			if (k < n) v = inn[k];
-			RQ_SYNC();
-			if (k < n) inn[k + 1] = v;
-			RQ_SYNC();
-		}
-	}
-	if (lane == 0) inn[pos] = key;
-	RQ_SYNC();
-	++n;
-}
-__device__ inline void rq_erase(long long *inn, int &n, long long key)
-{
-	const int lane = threadIdx.x & 63;
-	const int pos = rq_count(inn, n, key, false);
-	if (pos >= n || inn[pos] != key) return;   // (U: krmq_find misses -> nothing erased; cannot happen for members)
-	for (int b = pos + 1; b < n; b += WAVE) {
-		const int k = b + lane;
-		long long v = 0;
-		if (k < n) v = inn[k];
-		RQ_SYNC();
-		if (k < n) inn[k - 1] = v;
-		RQ_SYNC();
-	}
-	--n;
-}
-
 // ---- stage 1 (long-join re-chain only): the rescue test of U:map.c::mm_map_frag and radix_sort_128x of the chained anchors
 __global__ __launch_bounds__(WAVE) void k_rmq_sort(RmqParams rp, DevBatch bt, DevAnchors an, const int32_t *list, uint8_t *flag, int *err)
 {
@@ -138,13 +92,66 @@ __global__ __launch_bounds__(WAVE) void k_rmq_sort(RmqParams rp, DevBatch bt, De
 }
 
 // ---- stage 2: the chaining recurrence
+// Nothing on the loop-carried path of an anchor waits for HBM: the window starts st / st_inner are monotone functions of the sorted x and are
+// computed for all anchors up front (binary searches, 64 anchors at a time); x, y, f, p of the last RQ_RING anchors and (y, pri) of the last
+// RQ_WRING anchors live in LDS rings.  Only a range-minimum window longer than RQ_WRING anchors (or a winner further back than RQ_RING) reads HBM.
+//
+// Range minimum: the window [st, i0) is cut at multiples of 64.  Every complete block of 64 anchors has a summary (min y, max y, minimal pri, its
+// index, "attained twice"); a block whose y range lies inside the query's is answered by its summary, one lane per block; only the two ragged
+// ends of the window and the blocks that straddle a y bound are looked at element by element -- a 20 kb window of a long read is ~4 steps, not ~30.
+//
+// Inner walk: the reference walks the members of [st_inner, i0) with y in [y_i - max_dist_inner, y_i - 1] in descending (y, j) order.  Among
+// anchors of one chain y grows with j, so descending j IS that order unless chains of different diagonals interleave; the walk runs over j,
+// checks on the way that y never increases, and only when it does sorts the candidates of this anchor (rank by counting, in LDS).
+struct RqWalk { int32_t max_f, max_j, n_skip; };
+// one step of the inner walk: 64 candidates in walk order (lane 0 first), `valid` lanes take part.  Returns true when the walk stops here.
+__device__ inline bool rq_walk_step(RqWalk &w, uint32_t *tw, uint32_t mark, int jj, bool valid, int32_t sc2, int32_t pj, int st_in, int32_t max_skip)
+{
+	const int lane = threadIdx.x & 63;
+	if (valid && pj >= st_in) tw[pj & RQ_TWMASK] = mark;   // t[p[j]] = i; marks below st_inner are never tested
+	RQ_SYNC();
+	const bool marked = valid && tw[jj & RQ_TWMASK] == mark;
+	const int32_t scv = valid? sc2 : INT32_MIN;
+	int32_t pm = wave_excl_prefix_max(scv, lane);
+	pm = pm > w.max_f? pm : w.max_f;
+	const bool improved = valid && sc2 > pm;
+	// n_skip along the walk (see k_chain_big): +1 on a marked lane, -1 (not below 0) on an improving one; stop at the first marked lane above max_skip
+	const int32_t dstep = improved? -1 : marked? 1 : 0;
+	const int32_t S = w.n_skip + wave_incl_scan_add(dstep);
+	const int32_t m0 = wave_incl_scan_min(S);
+	const int32_t ck = S - (m0 < 0? m0 : 0);
+	const unsigned long long bmask = __ballot(dstep == 1 && ck > max_skip);
+	int brk = -1;
+	if (bmask) brk = __builtin_ctzll(bmask);
+	else w.n_skip = __builtin_amdgcn_readlane(ck, 63);
+	const bool considered = brk < 0 || lane <= brk;
+	const int32_t cv = (valid && considered)? sc2 : INT32_MIN;
+	const int32_t cmax = wave_reduce_max(cv);
+	if (cmax > w.max_f) {
+		const unsigned long long m = __ballot(cv == cmax);
+		w.max_f = cmax; w.max_j = __builtin_amdgcn_readlane(jj, __builtin_ctzll(m));   // lowest lane = first met by the sequential walk
+	}
+	RQ_SYNC();
+	return brk >= 0;
+}
+
+struct RqBest { double best; int bj; bool tie; };
+__device__ inline void rq_offer(RqBest &b, double pj, int j, bool tie_in)
+{
+	if (b.bj < 0 || pj < b.best) { b.best = pj; b.bj = j; b.tie = tie_in; } else if (pj == b.best) b.tie = true;
+}
+
 __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevAnchors an, const int32_t *list, uint8_t *flag, unsigned long long *ctr)
 {
 	MM355_LATENCY_KERNEL();
-	__shared__ long long inn[RQ_INN];
+	__shared__ long long cand[RQ_RING], sorted[RQ_RING];   // slow path of the inner walk
 	__shared__ uint32_t tw[RQ_TW];
-	__shared__ double rpri[RQ_RING];
-	__shared__ int32_t ry[RQ_RING], rf[RQ_RING], rpp[RQ_RING];
+	__shared__ uint64_t rx[RQ_RING], ryy[RQ_RING];
+	__shared__ int32_t rf[RQ_RING], rpp[RQ_RING];
+	__shared__ double wpri[RQ_WRING];
+	__shared__ int32_t wy[RQ_WRING];
+	__shared__ double bpri[RQ_NB];
+	__shared__ int32_t bmin[RQ_NB], bmax[RQ_NB], bjj[RQ_NB], btie[RQ_NB];
 	const int r = list[blockIdx.x], lane = threadIdx.x;
 	if (flag[r] != MM355_RMQ_DONE) return;
 	const int64_t o = an.aoff[r];
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 	if (n <= 0) return;
 	const mm128 *a = an.a + o;
 	int32_t *f = an.f + o, *p = an.p + o, *yy = an.vi + o;
+	int32_t *lb_out = an.v + o, *lbi_out = (int32_t*)(an.u2 + o);   // window starts of every anchor (v[] and u2[] are free until the backtrack)
 	double *pri = (double*)(an.z + o);
 	int32_t max_dist = rp.max_dist, max_dist_inner = rp.max_dist_inner;
 	const int32_t bw = rp.bw, max_skip = rp.max_chn_skip, cap = rp.cap;
@@ -161,154 +169,214 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 	if (cap < 0) { if (lane == 0) flag[r] = MM355_RMQ_HOST; return; }   // (a negative cap empties the trees before anything is inserted: left to the literal code)
 	const float pen_gap = rp.pen_gap, pen_skip = rp.pen_skip;
 	const double half_gap = 0.5 * (double)pen_gap;
+	KPROF_BEGIN(bt);
+	// ---- window starts: lb(i) = first idx <= i of i's strand / contig with x_idx + dist >= x_i.  The reference's `while (st < i && ...) ++st`
+	// stops exactly there (its condition is true on a prefix of [0, i) and false behind it, and the prefix only grows with i).
+	{
+		int lo_all = 0, lo_all_in = 0;
+		for (int base = 0; base < n; base += WAVE) {
+			const int i = base + lane;
+			int lo = lo_all, hi = i < n? i : n - 1, lo2 = lo_all_in, hi2 = hi;
+			const uint64_t xi = a[i < n? i : n - 1].x;
+			while (__any(lo < hi || lo2 < hi2)) {
+				const int mid = (lo + hi) >> 1, mid2 = (lo2 + hi2) >> 1;
+				const uint64_t xs = a[mid].x, xs2 = a[mid2].x;
+				if (lo < hi) { if ((xi >> 32 != xs >> 32) || xi > xs + (uint64_t)(int64_t)max_dist) lo = mid + 1; else hi = mid; }
+				if (lo2 < hi2) { if ((xi >> 32 != xs2 >> 32) || xi > xs2 + (uint64_t)(int64_t)max_dist_inner) lo2 = mid2 + 1; else hi2 = mid2; }
+			}
+			if (i < n) { lb_out[i] = lo; lbi_out[i] = lo2; }
+			lo_all = __builtin_amdgcn_readlane(lo, 0); lo_all_in = __builtin_amdgcn_readlane(lo2, 0);   // lb is monotone: the next 64 anchors start from this chunk's first
+		}
+	}
 	for (int k = lane; k < RQ_TW; k += WAVE) tw[k] = 0;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	RQ_SYNC();
-	int i0 = 0, st = 0, st_in = 0, inn_n = 0;
+	KPROF(17);
+	int i0 = 0, st = 0, st_in = 0;
 	uint64_t x_i0 = 0, cx = 0, cy = 0;
+	int32_t clb = 0, clbi = 0;
 	unsigned long long n_scan = 0;
 	bool bail = false;
 	for (int i = 0; i < n; ++i) {
-		if ((i & (WAVE - 1)) == 0) { cx = cy = 0; if (i + lane < n) { const mm128 t = a[i + lane]; cx = t.x; cy = t.y; } }
+		if ((i & (WAVE - 1)) == 0) {
+			// chunk boundary: this chunk's anchors enter the x / y rings (nothing older than i - RQ_RING + 64 may be read from them) ...
+			cx = cy = 0; clb = clbi = 0;
+			if (i + lane < n) {
+				const mm128 t = a[i + lane]; cx = t.x; cy = t.y;
+				clb = rq_ld32(lb_out + i + lane); clbi = rq_ld32(lbi_out + i + lane);
+				rx[(i + lane) & RQ_RMASK] = cx; ryy[(i + lane) & RQ_RMASK] = cy;
+			}
+			if (i > 0) {   // ... and the block of 64 anchors that has just been finished gets its summary
+				const int jb = i - WAVE + lane;
+				const int32_t yj = wy[jb & RQ_WMASK];
+				const double pj = wpri[jb & RQ_WMASK];
+				long long sk = __double_as_longlong(pj);
+				sk = sk >= 0? sk : (sk ^ 0x7fffffffffffffffLL);
+				const long long mx = wave_reduce_max64(~sk);
+				const unsigned long long who = __ballot(~sk == mx);
+				const int32_t ymx = wave_reduce_max(yj), ymn = -wave_reduce_max(-yj);
+				if (lane == 0) {
+					const int sl = ((i >> 6) - 1) & (RQ_NB - 1);
+					const int wl = __builtin_ctzll(who);
+					bmin[sl] = ymn; bmax[sl] = ymx; bjj[sl] = i - WAVE + wl; btie[sl] = __popcll(who) > 1;
+				}
+				const double pmin = wpri[(i - WAVE + __builtin_ctzll(who)) & RQ_WMASK];
+				if (lane == 0) bpri[((i >> 6) - 1) & (RQ_NB - 1)] = pmin;
+			}
+			RQ_SYNC();
+		}
 		const uint64_t xi = rq_bcast64(cx, i & (WAVE - 1)), yi = rq_bcast64(cy, i & (WAVE - 1));
 		const int32_t yi32 = (int32_t)yi;
 		// the anchors of the previous run of equal x become visible
 		if (i == 0) x_i0 = xi;
-		if (i0 < i && x_i0 != xi) {
-			if (max_dist_inner > 0) {
-				for (int j = i0; j < i; ++j) {
-					if (inn_n >= RQ_INN) { bail = true; break; }
-					rq_insert(inn, inn_n, (long long)(((uint64_t)(int64_t)ry[j & RQ_RMASK]) << 32 | (uint32_t)j));   // i - j <= run length: still in the ring (checked below)
-				}
-				if (bail) break;
-			}
-			i0 = i; x_i0 = xi;
-		}
+		if (i0 < i && x_i0 != xi) { i0 = i; x_i0 = xi; }
 		// st: first anchor of the same strand / contig within max_dist; at most cap elements stay
-		for (;;) {
-			const int idx = st + lane;
-			bool c = false;
-			if (idx < i) { const uint64_t xs = a[idx].x; c = (xi >> 32 != xs >> 32) || xi > xs + (uint64_t)(int64_t)max_dist; }
-			const unsigned long long m = __ballot(c);
-			if (m == ~0ULL) { st += WAVE; continue; }
-			st += __builtin_ctzll(~m);
-			break;
+		{
+			const int lbv = __builtin_amdgcn_readlane(clb, i & (WAVE - 1));
+			if (lbv > st) st = lbv;
+			if (st < i0 && i0 - st > cap) st = i0 - cap;
 		}
-		if (st < i0 && i0 - st > cap) st = i0 - cap;
 		if (max_dist_inner > 0) {
-			int s2 = st_in;
-			for (;;) {
-				const int idx = s2 + lane;
-				bool c = false;
-				if (idx < i) { const uint64_t xs = a[idx].x; c = (xi >> 32 != xs >> 32) || xi > xs + (uint64_t)(int64_t)max_dist_inner; }
-				const unsigned long long m = __ballot(c);
-				if (m == ~0ULL) { s2 += WAVE; continue; }
-				s2 += __builtin_ctzll(~m);
-				break;
-			}
-			if (s2 < i0 && i0 - s2 > cap) s2 = i0 - cap;
-			if (s2 >= i0) inn_n = 0;                       // every member left
-			else if (s2 > st_in) {
-				if (i - st_in > RQ_RING) { bail = true; break; }   // (members older than the ring: not reachable with the capacity checks below)
-				for (int j = st_in; j < s2; ++j) rq_erase(inn, inn_n, (long long)(((uint64_t)(int64_t)ry[j & RQ_RMASK]) << 32 | (uint32_t)j));
-			}
-			st_in = s2;
-			if (i - st_in > RQ_RING - WAVE) { bail = true; break; }   // the rings (and the mark window) must cover the inner set and the current run
+			const int lbv = __builtin_amdgcn_readlane(clbi, i & (WAVE - 1));
+			if (lbv > st_in) st_in = lbv;
+			if (st_in < i0 && i0 - st_in > cap) st_in = i0 - cap;
+			if (st_in < i0 && i - st_in > RQ_RING - 2 * WAVE) { bail = true; break; }   // the rings (and the mark window) must cover the inner set and the current run
 		}
-		// range-minimum query over the outer set, 64 elements per step
+		// ---- range-minimum query over the outer set [st, i0)
 		const int32_t lo_y = yi32 - max_dist;
-		double best = 0.0; int bj = -1; bool tie = false;
-		const int near0 = i - RQ_RING > st? i - RQ_RING : st;   // [near0, i0) is served by the rings
+		RqBest B; B.best = 0.0; B.bj = -1; B.tie = false;
+		const int near0 = i - RQ_WRING + WAVE > st? i - RQ_WRING + WAVE : st;   // [near0, i0) is served by the (y, pri) ring and the block summaries
 		for (int j = st + lane; j < near0; j += WAVE) {
 			const int32_t yj = rq_ld32(yy + j);
-			if ((yj > lo_y && yj < yi32) || (yj == yi32 && j == 0)) {
-				const double pj = rq_ldf64(pri + j);
-				if (bj < 0 || pj < best) { best = pj; bj = j; tie = false; } else if (pj == best) tie = true;
-			}
+			const double pj = rq_ldf64(pri + j);
+			if ((yj > lo_y && yj < yi32) || (yj == yi32 && j == 0)) rq_offer(B, pj, j, false);
 		}
-		for (int j = near0 + lane; j < i0; j += WAVE) {
-			const int32_t yj = ry[j & RQ_RMASK];
-			if ((yj > lo_y && yj < yi32) || (yj == yi32 && j == 0)) {
-				const double pj = rpri[j & RQ_RMASK];
-				if (bj < 0 || pj < best) { best = pj; bj = j; tie = false; } else if (pj == best) tie = true;
+		if (near0 < i0) {
+			const int fb0 = (near0 + WAVE - 1) >> 6, fb1 = i0 >> 6;     // complete blocks: fb0 .. fb1 - 1
+			int e0 = near0, e1 = i0;                                    // element-wise: [near0, 64 fb0) and [64 fb1, i0), or everything
+			unsigned long long straddle = 0;
+			if (fb0 < fb1) {
+				e1 = fb0 << 6;
+				const int bb = fb0 + lane;
+				bool strad = false;
+				if (bb < fb1) {
+					const int sl = bb & (RQ_NB - 1);
+					const int32_t ymn = bmin[sl], ymx = bmax[sl];
+					if (ymn > lo_y && ymx < yi32) rq_offer(B, bpri[sl], bjj[sl], btie[sl] != 0);        // every member inside the query's y range
+					else if (!(ymx <= lo_y || ymn > yi32 || (ymn == yi32 && bb != 0))) strad = true;       // some member may be inside
+				}
+				straddle = __ballot(strad);
+			}
+			for (int j = e0 + lane; j < e1; j += WAVE) {     // leading ragged end (or the whole window when it holds no complete block)
+				const int32_t yj = wy[j & RQ_WMASK];
+				const double pj = wpri[j & RQ_WMASK];
+				if ((yj > lo_y && yj < yi32) || (yj == yi32 && j == 0)) rq_offer(B, pj, j, false);
+			}
+			if (fb0 < fb1) {
+				for (int j = (fb1 << 6) + lane; j < i0; j += WAVE) {   // trailing ragged end
+					const int32_t yj = wy[j & RQ_WMASK];
+					const double pj = wpri[j & RQ_WMASK];
+					if ((yj > lo_y && yj < yi32) || (yj == yi32 && j == 0)) rq_offer(B, pj, j, false);
+				}
+				while (straddle) {                                       // blocks cut by a y bound
+					const int j = ((fb0 + __builtin_ctzll(straddle)) << 6) + lane; straddle &= straddle - 1;
+					const int32_t yj = wy[j & RQ_WMASK];
+					const double pj = wpri[j & RQ_WMASK];
+					if ((yj > lo_y && yj < yi32) || (yj == yi32 && j == 0)) rq_offer(B, pj, j, false);
+				}
 			}
 		}
 		n_scan += (unsigned long long)(i0 - st);
-		int32_t max_f = (int32_t)(yi >> 32 & 0xff), max_j = -1;
+		RqWalk w; w.max_f = (int32_t)(yi >> 32 & 0xff); w.max_j = -1; w.n_skip = 0;
 		{   // wave minimum of an order-preserving integer image of the double; the minimum must be attained exactly once
-			long long sk = __double_as_longlong(best);
+			long long sk = __double_as_longlong(B.best);
 			sk = sk >= 0? sk : (sk ^ 0x7fffffffffffffffLL);
-			const long long mine = bj >= 0? ~sk : (long long)0x8000000000000000ULL;
+			const long long mine = B.bj >= 0? ~sk : (long long)0x8000000000000000ULL;
 			const long long mx = wave_reduce_max64(mine);
-			const unsigned long long who = __ballot(bj >= 0 && mine == mx);
+			const unsigned long long who = __ballot(B.bj >= 0 && mine == mx);
 			if (who) {
-				if (__popcll(who) > 1 || __ballot(tie && mine == mx)) { bail = true; break; }
+				if (__popcll(who) > 1 || __ballot(B.tie && mine == mx)) { bail = true; break; }
 				const int wl = __builtin_ctzll(who);
-				const int j = __builtin_amdgcn_readlane(bj, wl);
-				const mm128 aj = a[j];
-				const int32_t fj = i - j <= RQ_RING? rf[j & RQ_RMASK] : rq_ld32(f + j);
+				const int j = __builtin_amdgcn_readlane(B.bj, wl);
+				uint64_t ajx, ajy; int32_t fj;
+				if (i - j <= RQ_RING - WAVE) { ajx = rx[j & RQ_RMASK]; ajy = ryy[j & RQ_RMASK]; fj = rf[j & RQ_RMASK]; }
+				else { const mm128 aj = a[j]; ajx = aj.x; ajy = aj.y; fj = rq_ld32(f + j); }
 				bool exact; int32_t width;
-				const int32_t sc = fj + rq_comput_sc(xi, yi, aj.x, aj.y, pen_gap, pen_skip, &exact, &width);
-				if (width <= bw && sc > max_f) { max_f = sc; max_j = j; }
-				if (!exact && inn_n > 0 && yi32 > 0) {
-					// largest key <= (y_i - 1, n), then downwards while y >= y_i - max_dist_inner
-					const int top = rq_count(inn, inn_n, (long long)(((uint64_t)(int64_t)(yi32 - 1)) << 32 | (uint32_t)n), true);
-					int32_t n_skip = 0;
+				const int32_t sc = fj + rq_comput_sc(xi, yi, ajx, ajy, pen_gap, pen_skip, &exact, &width);
+				if (width <= bw && sc > w.max_f) { w.max_f = sc; w.max_j = j; }
+				if (!exact && max_dist_inner > 0 && st_in < i0 && yi32 > 0) {
 					const uint32_t mark = (uint32_t)i + 1u;
-					for (int kb = top - 1; kb >= 0; kb -= WAVE) {
-						const int k = kb - lane;
-						bool active = k >= 0;
-						long long key = 0;
-						if (active) key = inn[k];
-						const int32_t y2 = (int32_t)(key >> 32);
-						const unsigned long long mstop = __ballot(active && y2 < yi32 - max_dist_inner);
-						if (mstop) active = active && lane < __builtin_ctzll(mstop);
-						const int jj = (int)(uint32_t)key;
-						int32_t sc2 = 0, pj = -1, width2 = 0;
-						bool valid = false;
-						if (active) {
-							const mm128 aj2 = a[jj];
-							bool ex2;
-							sc2 = rf[jj & RQ_RMASK] + rq_comput_sc(xi, yi, aj2.x, aj2.y, pen_gap, pen_skip, &ex2, &width2);
+					const int32_t y_lo = yi32 - max_dist_inner;
+					// walk in descending j; on the way check that this IS descending (y, j): y must never increase along the walk
+					const RqWalk w_saved = w;
+					int32_t carry = INT32_MAX; bool sortit = false;
+					for (int jb = i0 - 1; jb >= st_in; jb -= WAVE) {
+						const int jj = jb - lane;
+						bool in = false, valid = false; int32_t sc2 = 0, pj = -1, y2 = 0;
+						uint64_t yj = 0;
+						if (jj >= st_in) { yj = ryy[jj & RQ_RMASK]; y2 = (int32_t)yj; in = y2 >= y_lo && y2 < yi32; }
+						const int32_t neg = in? -y2 : INT32_MIN;                      // prefix minimum of y = - prefix maximum of -y
+						int32_t pmn = wave_excl_prefix_max(neg, lane);
+						pmn = pmn == INT32_MIN? INT32_MAX : -pmn;
+						pmn = pmn < carry? pmn : carry;
+						if (__ballot(in && y2 > pmn)) { sortit = true; break; }
+						const int32_t cm = wave_reduce_max(neg);
+						if (cm != INT32_MIN && -cm < carry) carry = -cm;
+						if (in) {
+							bool ex2; int32_t width2;
+							sc2 = rf[jj & RQ_RMASK] + rq_comput_sc(xi, yi, rx[jj & RQ_RMASK], yj, pen_gap, pen_skip, &ex2, &width2);
 							valid = width2 <= bw;
 							if (valid) pj = rpp[jj & RQ_RMASK];
 						}
-						if (valid && pj >= st_in) tw[pj & RQ_TWMASK] = mark;   // t[p[j]] = i; marks below st_inner are never tested
-						RQ_SYNC();
-						const bool marked = valid && tw[jj & RQ_TWMASK] == mark;
-						const int32_t scv = valid? sc2 : INT32_MIN;
-						int32_t pm = wave_excl_prefix_max(scv, lane);
-						pm = pm > max_f? pm : max_f;
-						const bool improved = valid && sc2 > pm;
-						// n_skip along the scan order (see k_chain_big): +1 on a marked lane, -1 (not below 0) on an improving one
-						const int32_t dstep = improved? -1 : marked? 1 : 0;
-						const int32_t S = n_skip + wave_incl_scan_add(dstep);
-						const int32_t m0 = wave_incl_scan_min(S);
-						const int32_t ck = S - (m0 < 0? m0 : 0);
-						const unsigned long long bmask = __ballot(dstep == 1 && ck > max_skip);
-						int brk = -1;
-						if (bmask) brk = __builtin_ctzll(bmask);
-						else n_skip = __builtin_amdgcn_readlane(ck, 63);
-						const bool considered = brk < 0 || lane <= brk;
-						const int32_t cv = (valid && considered)? sc2 : INT32_MIN;
-						const int32_t cmax = wave_reduce_max(cv);
-						if (cmax > max_f) {
-							const unsigned long long w = __ballot(cv == cmax);
-							max_f = cmax; max_j = __builtin_amdgcn_readlane(jj, __builtin_ctzll(w));   // lowest lane = first met by the sequential walk
+						if (rq_walk_step(w, tw, mark, jj, valid, sc2, pj, st_in, max_skip)) break;
+					}
+					if (sortit) {
+						w = w_saved;                                                   // (the marks of the abandoned attempt carry `mark`; the redo uses another value)
+						const uint32_t mark2 = mark | 0x80000000u;
+						// chains of different diagonals interleave here: order the candidates of this anchor by (y, j), descending
+						int m = 0;
+						for (int jb = i0 - 1; jb >= st_in; jb -= WAVE) {
+							const int jj = jb - lane;
+							bool in = false; int32_t y2 = 0;
+							if (jj >= st_in) { y2 = (int32_t)ryy[jj & RQ_RMASK]; in = y2 >= y_lo && y2 < yi32; }
+							const unsigned long long mk = __ballot(in);
+							if (in) cand[m + __popcll(mk & LANE_LT_MASK(lane))] = (long long)(((uint64_t)(int64_t)y2) << 32 | (uint32_t)jj);
+							m += __popcll(mk);
 						}
 						RQ_SYNC();
-						if (brk >= 0 || mstop) break;
+						for (int c = lane; c < m; c += WAVE) {
+							const long long kc = cand[c];
+							int rank = 0;
+							for (int t = 0; t < m; ++t) rank += cand[t] > kc;
+							sorted[rank] = kc;          // keys are unique (j is part of them)
+						}
+						RQ_SYNC();
+						for (int kb = 0; kb < m; kb += WAVE) {
+							const int k = kb + lane;
+							bool valid = false; int32_t sc2 = 0, pj = -1; int jj = 0;
+							if (k < m) {
+								jj = (int)(uint32_t)sorted[k];
+								bool ex2; int32_t width2;
+								sc2 = rf[jj & RQ_RMASK] + rq_comput_sc(xi, yi, rx[jj & RQ_RMASK], ryy[jj & RQ_RMASK], pen_gap, pen_skip, &ex2, &width2);
+								valid = width2 <= bw;
+								if (valid) pj = rpp[jj & RQ_RMASK];
+							}
+							if (rq_walk_step(w, tw, mark2, jj, valid, sc2, pj, st_in, max_skip)) break;
+						}
 					}
 				}
 			}
 		}
+		const int32_t max_f = w.max_f, max_j = w.max_j;
 		const double pv = -((double)max_f + half_gap * (double)((int32_t)xi + yi32));
 		RQ_SYNC();   // every lane has finished reading the ring slots this anchor overwrites
 		if (lane == 0) {
 			f[i] = max_f; p[i] = max_j; yy[i] = yi32; pri[i] = pv;
-			rf[i & RQ_RMASK] = max_f; rpp[i & RQ_RMASK] = max_j; ry[i & RQ_RMASK] = yi32; rpri[i & RQ_RMASK] = pv;
+			rf[i & RQ_RMASK] = max_f; rpp[i & RQ_RMASK] = max_j; wy[i & RQ_WMASK] = yi32; wpri[i & RQ_WMASK] = pv;
 		}
 		RQ_SYNC();
 	}
+	KPROF(18);
 	if (bail) { if (lane == 0) flag[r] = MM355_RMQ_HOST; return; }
 	if (lane == 0 && ctr) atomicAdd(ctr + (blockIdx.x & 63), n_scan);
 }
@@ -321,7 +389,7 @@ __global__ __launch_bounds__(WAVE) void k_rmq_backtrack(RmqParams rp, DevParams 
 	const int r = list[blockIdx.x];
 	if (flag[r] != MM355_RMQ_DONE) return;
 	const int n = rp.primary? (int)(an.aoff[r + 1] - an.aoff[r]) : an.n_v[r];
-	wave_backtrack_read(pr, bt, an, err, &S, r, n, rp.bw);
+	wave_backtrack_read(pr, bt, an, err, &S, r, n, rp.bw, 20);
 }
 
 int mm355_launch_rmq(const RmqParams &rp, const DevParams &pr, const DevBatch &bt, DevAnchors &an, const int32_t *d_list, int n_list, uint8_t *d_flag,
