@@ -161,57 +161,73 @@ __global__ __launch_bounds__(WAVE) void k_mzflt(DevParams pr, DevBatch bt, DevSe
 // form a prefix of a line (the builders fill the first empty slot and never delete), so: a match anywhere in the line = hit, else an
 // empty slot = absent, else (line full, ~1 line in 12 at load 0.55) the next line.  A wave keeps LK_UNROLL x 8 independent line fetches
 // in flight per iteration; nothing in the loop depends on an earlier fetch.
-#define LK_UNROLL 4
-__global__ __launch_bounds__(256) void k_seed_lookup(DevIndex ix, DevBatch bt, DevSeeds sd)
+// Grid: the chunk table of the sketch (one block per SK_CHUNK bases of a read; a read's minimizers sit packed at the front of its slot range,
+// so block (read, start) owns the minimizer slots [start, start + SK_CHUNK) below n_mz[read] and most blocks of a read leave at once).  Work
+// is flat over the minimizers of the batch -- a 100 kb read is 260 blocks, not one block that loops 140 times -- and every 8-lane group
+// has all its LK_PER_GROUP line fetches in flight before it looks at the first.  The roof of this access pattern, measured on the same chip
+// (tools/ubench/linebench.hip, profiles/r03_random_line_roof.json): 5.9 TB/s of uniformly random 128-byte lines out of 16 GB = 46 G lookups/s;
+// 64-byte buckets are served at the same request rate (3.1 TB/s), so a narrower bucket would not buy lookups.
+#define LK_PER_GROUP (SK_CHUNK / 32)
+#define LK_TILES 4
+__global__ __launch_bounds__(256) void k_seed_lookup(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, unsigned long long *hit_ctr)
 {
-	const int r = blockIdx.x;
-	const int n = sd.n_mz[r];
-	const int64_t off = bt.roff[r];
-	const mm128 *mz = sd.mz + off;
 	const int grp = threadIdx.x >> 3, sl = threadIdx.x & 7;          // 32 groups of 8 lanes per block; lane sl owns slot sl of the line
 	const int gsh = (threadIdx.x & 63) & ~7;                          // bit position of this group's 8 lanes in a wave ballot
 	unsigned int hits = 0;
-	for (int j0 = 0; j0 < n; j0 += 32 * LK_UNROLL) {
-		uint64_t minier[LK_UNROLL], line[LK_UNROLL]; uint4 raw[LK_UNROLL]; bool live[LK_UNROLL];
+	// LK_TILES table entries per block: four fifths of the entries are empty (a read has ~0.19 minimizers per base), and an empty block still
+	// costs its dispatch
+	for (int e = 0; e < LK_TILES; ++e) {
+	const int ck = (int)blockIdx.x * LK_TILES + e;
+	if (ck >= n_chunks) break;
+	const int r = chunk_read[ck], s0 = chunk_start[ck];
+	const int n = sd.n_mz[r];
+	if (s0 >= n) continue;
+	const int64_t off = bt.roff[r];
+	const mm128 *mz = sd.mz + off;
+	uint64_t minier[LK_PER_GROUP], line[LK_PER_GROUP]; uint4 raw[LK_PER_GROUP]; bool live[LK_PER_GROUP];
 #pragma unroll
-		for (int u = 0; u < LK_UNROLL; ++u) {
-			const int j = j0 + u * 32 + grp;
-			live[u] = j < n;
-			minier[u] = live[u]? mz[j].x >> 8 : 0;
-			line[u] = mm_table_hash(minier[u]) & ix.line_mask;
-		}
+	for (int u = 0; u < LK_PER_GROUP; ++u) {
+		const int j = s0 + u * 32 + grp;
+		live[u] = j < n && u * 32 + grp < SK_CHUNK;
+		minier[u] = live[u]? mz[j].x >> 8 : 0;
+		line[u] = mm_table_hash(minier[u]) & ix.line_mask;
+	}
 #pragma unroll
-		for (int u = 0; u < LK_UNROLL; ++u)                           // LK_UNROLL line fetches issued back to back
-			raw[u] = live[u]? *(const uint4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl) : make_uint4(~0u, ~0u, 0, 0);
+	for (int u = 0; u < LK_PER_GROUP; ++u)                            // every line fetch of the group issued back to back
+		raw[u] = live[u]? *(const uint4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl) : make_uint4(~0u, ~0u, 0, 0);
 #pragma unroll
-		for (int u = 0; u < LK_UNROLL; ++u) {
-			const int j = j0 + u * 32 + grp;
-			for (;;) {                                                 // uniform per group; groups of a wave only diverge on a full line
-				const uint64_t key = (uint64_t)raw[u].y << 32 | raw[u].x, v = (uint64_t)raw[u].w << 32 | raw[u].z;
-				const bool match = live[u] && (key >> 1) == minier[u] && key != UINT64_MAX;
-				const bool empty = key == UINT64_MAX;
-				const unsigned int mm = (unsigned int)(__ballot(match) >> gsh) & 0xffu, em = (unsigned int)(__ballot(empty) >> gsh) & 0xffu;
-				if (mm) {
-					if (match) {
-						uint32_t cnt; uint64_t val;
-						if (key & 1) cnt = 1, val = v;
-						else cnt = (uint32_t)v, val = v >> 32;
-						sd.sn[off + j] = cnt; sd.sv[off + j] = val;
-						++hits;
-					}
-					break;
+	for (int u = 0; u < LK_PER_GROUP; ++u) {
+		const int j = s0 + u * 32 + grp;
+		for (;;) {                                                    // uniform per group; groups of a wave only diverge on a full line
+			const uint64_t key = (uint64_t)raw[u].y << 32 | raw[u].x, v = (uint64_t)raw[u].w << 32 | raw[u].z;
+			const bool match = live[u] && (key >> 1) == minier[u] && key != UINT64_MAX;
+			const bool empty = key == UINT64_MAX;
+			const unsigned int mm = (unsigned int)(__ballot(match) >> gsh) & 0xffu, em = (unsigned int)(__ballot(empty) >> gsh) & 0xffu;
+			if (mm) {
+				if (match) {
+					uint32_t cnt; uint64_t val;
+					if (key & 1) cnt = 1, val = v;
+					else cnt = (uint32_t)v, val = v >> 32;
+					sd.sn[off + j] = cnt; sd.sv[off + j] = val;
+					++hits;
 				}
-				if (em || !live[u]) {
-					if (live[u] && sl == 0) { sd.sn[off + j] = 0; sd.sv[off + j] = 0; }
-					break;
-				}
-				line[u] = (line[u] + 1) & ix.line_mask;                // full line without the key: probe the next one
-				raw[u] = *(const uint4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl);
+				break;
 			}
+			if (em || !live[u]) {
+				if (live[u] && sl == 0) { sd.sn[off + j] = 0; sd.sv[off + j] = 0; }
+				break;
+			}
+			line[u] = (line[u] + 1) & ix.line_mask;                   // full line without the key: probe the next one
+			raw[u] = *(const uint4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl);
 		}
 	}
+	}
+	// one atomic per block, spread over 64 words (one word takes ~88 atomics per microsecond)
+	__shared__ unsigned int s_hits[4];
 	for (int o = 32; o > 0; o >>= 1) hits += __shfl_down(hits, o);
-	if ((threadIdx.x & 63) == 0 && hits) atomicAdd(&sd.counters[0], (unsigned long long)hits);
+	if ((threadIdx.x & 63) == 0) s_hits[threadIdx.x >> 6] = hits;
+	__syncthreads();
+	if (threadIdx.x == 0) { const unsigned int h = s_hits[0] + s_hits[1] + s_hits[2] + s_hits[3]; if (h) atomicAdd(hit_ctr + (blockIdx.x & 63), (unsigned long long)h); }
 }
 
 // ------------------------------------------------------------------ a4: mm_seed_select + mm_collect_matches
@@ -1046,10 +1062,11 @@ void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, h
 	if (bt.n_reads == 0) return;
 	hipLaunchKernelGGL(k_mzflt, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, sd);
 }
-void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
+void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
+                              unsigned long long *hit_ctr, hipStream_t st)
 {
-	if (bt.n_reads == 0) return;
-	hipLaunchKernelGGL(k_seed_lookup, dim3(bt.n_reads), dim3(256), 0, st, ix, bt, sd);
+	if (bt.n_reads == 0 || n_chunks == 0) return;
+	hipLaunchKernelGGL(k_seed_lookup, dim3((n_chunks + LK_TILES - 1) / LK_TILES), dim3(256), 0, st, ix, bt, sd, chunk_read, chunk_start, n_chunks, hit_ctr);
 }
 void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
 {

@@ -52,6 +52,7 @@ struct ResidentBatch { HostBatch hb; DBuf seq, roff, rlen, order, ck_read, ck_st
 //   CTR_GCELLS_OFF   cells per extension launch group, [CTR_GROUPS][CTR_SPREAD] (slot = block & (CTR_SPREAD - 1): one word takes ~88 atomics / us)
 //   CTR_PAIRS_OFF    chaining pair evaluations, CTR_PAIRS_WORDS slots (slot = block & 63)
 //   CTR_RMQ_OFF      window elements looked at by k_rmq_dp, CTR_RMQ_WORDS slots
+//   CTR_HITS_OFF     minimizers k_seed_lookup found in the index, CTR_HITS_WORDS slots
 #define CTR_HEAD_WORDS   64
 #define CTR_SPREAD       16
 #define CTR_GROUPS       24
@@ -61,7 +62,9 @@ struct ResidentBatch { HostBatch hb; DBuf seq, roff, rlen, order, ck_read, ck_st
 #define CTR_PAIRS_WORDS  64
 #define CTR_RMQ_OFF      (CTR_PAIRS_OFF + CTR_PAIRS_WORDS)
 #define CTR_RMQ_WORDS    64
-#define CTR_WORDS        (CTR_RMQ_OFF + CTR_RMQ_WORDS)
+#define CTR_HITS_OFF     (CTR_RMQ_OFF + CTR_RMQ_WORDS)     // minimizers found in the index (k_seed_lookup), CTR_HITS_WORDS slots
+#define CTR_HITS_WORDS   64
+#define CTR_WORDS        (CTR_HITS_OFF + CTR_HITS_WORDS)
 #define CTR_BYTES        (CTR_WORDS * 8)
 static_assert(CTR_GCELLS_OFF >= 8 && CTR_PAIRS_OFF == CTR_GCELLS_OFF + CTR_GCELLS_WORDS && CTR_RMQ_OFF == CTR_PAIRS_OFF + CTR_PAIRS_WORDS, "counter regions must be disjoint");
 

@@ -307,7 +307,8 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c);
 	HostBatch &hb = c->hb;
 	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_mzflt(pr, b, s, c->st); }
-	{ EvTimer t(c, &c->stats.ms_seed_lookup); mm355_launch_seed_lookup(c->dix, b, s, c->st); }
+	{ EvTimer t(c, &c->stats.ms_seed_lookup); mm355_launch_seed_lookup(c->dix, b, s, c->ck_read.as<int32_t>(), c->ck_start.as<int32_t>(), (int)c->n_chunks,
+	                                                                   c->counters.as<unsigned long long>() + CTR_HITS_OFF, c->st); }
 	++c->stats.n_launch_seed;
 	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_seed_select(c->dix, pr, b, s, c->st); }
 	HIPCHK(hipGetLastError());
@@ -319,9 +320,12 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 		HIPCHK(hipMemcpyAsync(hb.rep_len.data(), c->rep_len.p, n * 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipMemcpyAsync(hb.n_mini.data(), c->n_mini.p, n * 4, hipMemcpyDeviceToHost, c->st));
 	}
-	unsigned long long ctr[8];
+	unsigned long long ctr[8], hits[CTR_HITS_WORDS];
 	HIPCHK(hipMemcpyAsync(ctr, c->counters.p, 64, hipMemcpyDeviceToHost, c->st));
+	HIPCHK(hipMemcpyAsync(hits, c->counters.as<unsigned long long>() + CTR_HITS_OFF, CTR_HITS_WORDS * 8, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
+	ctr[0] = 0;
+	for (int k = 0; k < CTR_HITS_WORDS; ++k) ctr[0] += hits[k];
 	int64_t tot = 0, tmz = 0;
 	for (int64_t i = 0; i < n; ++i) { hb.aoff[i] = tot; tot += hb.n_a[i]; tmz += hb.n_mz[i]; }
 	hb.aoff[n] = tot; hb.tot_a = tot;

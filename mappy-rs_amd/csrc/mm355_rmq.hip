@@ -308,8 +308,10 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 					const uint32_t mark = (uint32_t)i + 1u;
 					const int32_t y_lo = yi32 - max_dist_inner;
 					// walk in descending j; on the way check that this IS descending (y, j): y must never increase along the walk
+					// (the check runs over ALL candidates, also behind the point where the walk stops: a candidate further down in j with a
+					// larger y would have been met earlier by the reference)
 					const RqWalk w_saved = w;
-					int32_t carry = INT32_MAX; bool sortit = false;
+					int32_t carry = INT32_MAX; bool sortit = false, stopped = false;
 					for (int jb = i0 - 1; jb >= st_in; jb -= WAVE) {
 						const int jj = jb - lane;
 						bool in = false, valid = false; int32_t sc2 = 0, pj = -1, y2 = 0;
@@ -322,13 +324,14 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 						if (__ballot(in && y2 > pmn)) { sortit = true; break; }
 						const int32_t cm = wave_reduce_max(neg);
 						if (cm != INT32_MIN && -cm < carry) carry = -cm;
+						if (stopped) continue;
 						if (in) {
 							bool ex2; int32_t width2;
 							sc2 = rf[jj & RQ_RMASK] + rq_comput_sc(xi, yi, rx[jj & RQ_RMASK], yj, pen_gap, pen_skip, &ex2, &width2);
 							valid = width2 <= bw;
 							if (valid) pj = rpp[jj & RQ_RMASK];
 						}
-						if (rq_walk_step(w, tw, mark, jj, valid, sc2, pj, st_in, max_skip)) break;
+						stopped = rq_walk_step(w, tw, mark, jj, valid, sc2, pj, st_in, max_skip);
 					}
 					if (sortit) {
 						w = w_saved;                                                   // (the marks of the abandoned attempt carry `mark`; the redo uses another value)

@@ -199,18 +199,16 @@ static void mm_update_cigar_eqx(mmo_reg1_t *r, const uint8_t *qseq, const uint8_
 	r->p = np;
 }
 
-static void mm_update_extra(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int is_eqx, int log_gap)
+/* the per-base walk of U:align.c::mm_update_extra (after mm_fix_cigar): mlen, blen, n_ambi and dp_max of a CIGAR over given code strings.
+ * Exported: mm_update_extra below runs it, and the parity test of the device walk (k_extra) calls it as its stage oracle. */
+void mmo_extra_walk(const uint32_t *cigar, int n_cigar, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int log_gap,
+                    int32_t *mlen_, int32_t *blen_, int32_t *n_ambi_, int32_t *dp_max_, int32_t *q_len, int32_t *t_len)
 {
-	uint32_t k, l;
-	int32_t qshift, tshift, toff = 0, qoff = 0;
+	int32_t k, toff = 0, qoff = 0, mlen = 0, blen = 0, n_ambi_tot = 0;
+	uint32_t l;
 	double s = 0.0, max = 0.0;
-	mmo_extra_t *p = r->p;
-	if (p == 0) return;
-	mm_fix_cigar(r, qseq, tseq, &qshift, &tshift);
-	qseq += qshift, tseq += tshift; /* qseq and tseq may be shifted due to the removal of leading I/D */
-	r->blen = r->mlen = 0;
-	for (k = 0; k < p->n_cigar; ++k) {
-		uint32_t op = p->cigar[k]&0xf, len = p->cigar[k]>>4;
+	for (k = 0; k < n_cigar; ++k) {
+		uint32_t op = cigar[k]&0xf, len = cigar[k]>>4;
 		if (op == MM_CIGAR_MATCH) {
 			int n_ambi = 0, n_diff = 0;
 			for (l = 0; l < len; ++l) {
@@ -221,13 +219,13 @@ static void mm_update_extra(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *t
 				if (s < 0) s = 0;
 				else max = max > s? max : s;
 			}
-			r->blen += len - n_ambi, r->mlen += len - (n_ambi + n_diff), p->n_ambi += n_ambi;
+			blen += len - n_ambi, mlen += len - (n_ambi + n_diff), n_ambi_tot += n_ambi;
 			toff += len, qoff += len;
 		} else if (op == MM_CIGAR_INS) {
 			int n_ambi = 0;
 			for (l = 0; l < len; ++l)
 				if (qseq[qoff + l] > 3) ++n_ambi;
-			r->blen += len - n_ambi, p->n_ambi += n_ambi;
+			blen += len - n_ambi, n_ambi_tot += n_ambi;
 			if (log_gap) s -= q + (double)e * mg_log2(1.0 + len);
 			else s -= q + e;
 			if (s < 0) s = 0;
@@ -236,7 +234,7 @@ static void mm_update_extra(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *t
 			int n_ambi = 0;
 			for (l = 0; l < len; ++l)
 				if (tseq[toff + l] > 3) ++n_ambi;
-			r->blen += len - n_ambi, p->n_ambi += n_ambi;
+			blen += len - n_ambi, n_ambi_tot += n_ambi;
 			if (log_gap) s -= q + (double)e * mg_log2(1.0 + len);
 			else s -= q + e;
 			if (s < 0) s = 0;
@@ -245,7 +243,20 @@ static void mm_update_extra(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *t
 			toff += len;
 		}
 	}
-	p->dp_max = (int32_t)(max + .499);
+	*mlen_ = mlen; *blen_ = blen; *n_ambi_ = n_ambi_tot; *dp_max_ = (int32_t)(max + .499);
+	if (q_len) *q_len = qoff;
+	if (t_len) *t_len = toff;
+}
+
+static void mm_update_extra(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int is_eqx, int log_gap)
+{
+	int32_t qshift, tshift, toff = 0, qoff = 0, n_ambi = 0;
+	mmo_extra_t *p = r->p;
+	if (p == 0) return;
+	mm_fix_cigar(r, qseq, tseq, &qshift, &tshift);
+	qseq += qshift, tseq += tshift; /* qseq and tseq may be shifted due to the removal of leading I/D */
+	mmo_extra_walk(p->cigar, (int)p->n_cigar, qseq, tseq, mat, q, e, log_gap, &r->mlen, &r->blen, &n_ambi, &p->dp_max, &qoff, &toff);
+	p->n_ambi += n_ambi;
 	assert(qoff == r->qe - r->qs && toff == r->re - r->rs);
 	if (is_eqx) mm_update_cigar_eqx(r, qseq, tseq); /* here: the shifts of qseq/tseq are local to this function */
 }

@@ -41,16 +41,14 @@ static void get_seqs(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq, 
 	*qseq_ = qseq, *tseq_ = tseq;
 }
 
-char *mmo_gen_cs(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq, int no_iden)
+/* U:format.c::write_cs_core on given code strings (0..4) and CIGAR; also the stage entry the parity test of the device walk (k_extra) calls */
+char *mmo_cs_core(const uint32_t *cigar, int n_cigar, const uint8_t *qseq, const uint8_t *tseq, int no_iden, int *q_len, int *t_len)
 {
 	int i, q_off, t_off;
-	uint8_t *qseq, *tseq;
 	kstr_t s = {0,0,0};
 	ks_put(&s, "", 0);
-	if (r->p == 0) return s.s;
-	get_seqs(mi, r, seq, &qseq, &tseq);
-	for (i = q_off = t_off = 0; i < (int)r->p->n_cigar; ++i) {
-		int j, op = r->p->cigar[i]&0xf, len = r->p->cigar[i]>>4;
+	for (i = q_off = t_off = 0; i < n_cigar; ++i) {
+		int j, op = cigar[i]&0xf, len = cigar[i]>>4;
 		if (op == MM_CIGAR_MATCH || op == 7 || op == 8) {
 			int l_tmp = 0;
 			for (j = 0; j < len; ++j) {
@@ -86,9 +84,22 @@ char *mmo_gen_cs(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq, int 
 			t_off += len;
 		}
 	}
+	if (q_len) *q_len = q_off;
+	if (t_len) *t_len = t_off;
+	return s.s;
+}
+
+char *mmo_gen_cs(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq, int no_iden)
+{
+	int q_off, t_off;
+	uint8_t *qseq, *tseq;
+	char *out;
+	if (r->p == 0) { kstr_t s = {0,0,0}; ks_put(&s, "", 0); return s.s; }
+	get_seqs(mi, r, seq, &qseq, &tseq);
+	out = mmo_cs_core(r->p->cigar, (int)r->p->n_cigar, qseq, tseq, no_iden, &q_off, &t_off);
 	assert(t_off == r->re - r->rs && q_off == r->qe - r->qs);
 	free(qseq); free(tseq);
-	return s.s;
+	return out;
 }
 
 char *mmo_gen_MD(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq)

@@ -88,6 +88,17 @@ def test_map_parity_chimeric_and_sv(ont):
     assert n_hits > len(reads)   # splits produce more than one hit per read
 
 
+@pytest.mark.parametrize("preset", ["map-ont", "asm20"])
+def test_map_parity_tandem_arrays(built, tmp_path, preset):
+    """end to end over reads whose re-chain takes every route of row a9: device (order-checked and sorted inner walks), host fallback on equal
+    range-minimum priorities, and -- asm20 -- the primary RMQ chainer followed by the long-join pass"""
+    import mappy_rs
+    from test_gpu_stages import _tandem_world
+    fa, reads = _tandem_world(tmp_path)
+    n_hits, _ = check_reads(mappy_rs.Aligner(fa, preset=preset), O.OracleAligner(fa, preset=preset), reads[:80])
+    assert n_hits >= 80
+
+
 def test_map_parity_edge_reads(ont):
     g = ont["g"]
     reads = ["ACGT", "A" * 500, "N" * 300, S.codes_to_str(g[0][1000:1400]), S.codes_to_str(g[1][50000:50100]),
@@ -896,9 +907,11 @@ def test_update_extra_and_cs_on_device(ont):
     sr = al._stage_runner()
     _ffi.check(L.mm355_stage_extra(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, cig.ctypes.data, len(cig) - 1, 1, res, cs.ctypes.data, cap))
     for i, (t_st, ops) in enumerate(jobs):
-        exp = _update_extra_ref(qs[i], t_all[t_st:], ops, mo.a, mo.b, mo.sc_ambi, mo.q, mo.e)
+        t_len = sum(ln for op, ln in ops if op != 1)
+        exp = O.update_extra_stage(qs[i], t_all[t_st:t_st + t_len + 8], ops, mo.a, mo.b, mo.sc_ambi, mo.q, mo.e)   # the oracle's own walk + write_cs_core
         got = (res[i].mlen, res[i].blen, res[i].n_ambi, res[i].dp_max, bytes(cs[res[i].cs_off:res[i].cs_off + res[i].cs_len]).decode())
         assert got == exp, (i, len(ops), got[:4], exp[:4])
+        assert exp == _update_extra_ref(qs[i], t_all[t_st:], ops, mo.a, mo.b, mo.sc_ambi, mo.q, mo.e), i       # (and the independent restatement in this file)
     sr.close()
 
 

@@ -160,6 +160,52 @@ def test_rmq_primary_chainer_parity(built, tmp_path, preset):
     sr.close()
 
 
+def _tandem_world(tmp_path):
+    """a genome full of tandem arrays (exact and 1 % diverged copies of 171 / 350 / 700 bp units) and reads across them: chains of
+    neighbouring diagonals interleave (the inner walk of mg_lchain_rmq has to order its candidates) and symmetric anchor pairs share a
+    range-minimum priority (the device hands those reads to the literal host code)"""
+    rng = np.random.default_rng(5)
+    bg = S.random_codes(rng, 300000)
+    pieces, pos = [], 0
+    for k in range(12):
+        seg = bg[pos:pos + 20000]; pos += 20000
+        unit = S.random_codes(rng, int(rng.choice([171, 350, 700])))
+        ncopy = int(rng.integers(3, 12))
+        pieces += [seg, np.concatenate([S.mutate(unit, rng, 0.0 if k % 2 == 0 else 0.01, 0, 0) for _ in range(ncopy)])]
+    g = [np.concatenate(pieces).astype(np.uint8)]
+    fa = str(tmp_path / "tandem.fa")
+    S.write_fasta(fa, g, ["chrT"])
+    reads = []
+    for i in range(200):
+        st = int(rng.integers(0, len(g[0]) - 9000)); ln = int(rng.integers(2000, 9000))
+        err = 0.0 if i % 2 == 0 else 0.01
+        reads.append(S.codes_to_str(S.mutate(g[0][st:st + ln], rng, err, err / 2, err / 2)))
+    return fa, reads
+
+
+@pytest.mark.parametrize("preset", ["map-ont", "asm20", "map-hifi"])
+def test_rmq_tandem_arrays_order_and_fallback(built, tmp_path, preset):
+    import mappy_rs
+    fa, reads = _tandem_world(tmp_path)
+    al = mappy_rs.Aligner(fa, preset=preset)
+    orc = O.OracleAligner(fa, preset=preset)
+    sr = al._stage_runner()
+    got = sr.rmq(reads)
+    n_dev = n_host = 0
+    for i, rd in enumerate(reads):
+        u, a, state = got[i]
+        if state >= 2:
+            n_host += 1
+            continue
+        ea, _, _, _ = orc.anchors(rd, sorted_=True)
+        eu, eb, did = orc.chains_final(ea, len(rd))
+        assert np.array_equal(u, eu) and np.array_equal(a, eb), (i, state, did)
+        n_dev += did != 0
+    sr.close()
+    assert n_host > 0 and n_dev > 0, (n_dev, n_host)          # both routes taken: equal priorities exist here, and they are the minority
+    assert n_host < len(reads) // 2, (n_dev, n_host)
+
+
 def test_empty_and_ragged_batches(world):
     sr = world["sr"]
     assert sr.sketch([]) == []
