@@ -316,6 +316,7 @@ __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jo
 }
 
 #include "mm355_dpreg.h"
+#include "mm355_dpmw.h"
 #include "mm355_dprow.h"
 
 // U:ksw2.h::ksw_backtrack (is_rot = 1).  The walk is a chain of dependent 1-byte loads (one per CIGAR column), i.e. pure
@@ -653,8 +654,12 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		hipStream_t gst; int rc2;
 		if ((rc2 = group_stream(7, &gst))) return rc2;
 		if ((rc2 = group_begin(DP_G_REGW, gst))) return rc2;
-		hipLaunchKernelGGL(k_ksw_regw, dim3((unsigned)n_grp[DP_G_REGW]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
-		                   c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * DP_G_REGW);
+		// eight waves per alignment (mm355_dpmw.h); MM355_DP_REGW8=0: the single-wave kernel of round 2 (same results)
+		static const bool regw8 = [] { const char *e = getenv("MM355_DP_REGW8"); return !(e && atoi(e) == 0); }();
+		if (regw8) hipLaunchKernelGGL(k_ksw_regw8, dim3((unsigned)n_grp[DP_G_REGW]), dim3(64 * MW_WAVES), 0, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
+		                              c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * DP_G_REGW);
+		else hipLaunchKernelGGL(k_ksw_regw, dim3((unsigned)n_grp[DP_G_REGW]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
+		                        c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * DP_G_REGW);
 		if ((rc2 = group_end(DP_G_REGW, gst, false))) return rc2;
 	}
 	if (n_grp[DP_G_ROWL]) {   // the eight-wave row sweep of the long full-band fills: a few hundred blocks at most, outside the turn as well

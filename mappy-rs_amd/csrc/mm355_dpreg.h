@@ -113,6 +113,12 @@ __device__ __forceinline__ void dp_score(const DpDiag &g, const DpK &k, const in
 }
 
 // one block of one anti-diagonal; pX/pV/pX2 = registers of block J-1 (previous anti-diagonal)
+// HASF: fx / fv / fx2 = the registers of the cell pair just below this block (lane 63 of block J-1 on the previous anti-diagonal); the
+// multi-wave kernel (mm355_dpmw.h) passes them in from its neighbour wave's mailbox
+template <int J, bool IS_LO, bool IS_HI, bool RIGHT, bool ANYBLK, bool HASF>
+__device__ __forceinline__ void dp_core_f(const DpDiag &g, const DpK &k, const int lane, uint8_t *p,
+                                          uint32_t &U, uint32_t &V, uint32_t &X, uint32_t &Y, uint32_t &X2, uint32_t &Y2, const uint32_t SC,
+                                          const uint32_t fx, const uint32_t fv, const uint32_t fx2);
 template <int J, bool IS_LO, bool IS_HI, bool RIGHT, bool ANYBLK>
 __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int lane, uint8_t *p,
                                         uint32_t &U, uint32_t &V, uint32_t &X, uint32_t &Y, uint32_t &X2, uint32_t &Y2, const uint32_t SC,
@@ -120,8 +126,15 @@ __device__ __forceinline__ void dp_core(const DpDiag &g, const DpK &k, const int
 {
 	uint32_t fx = 0, fv = 0, fx2 = 0;
 	if (J > 0) { fx = rdlane(pX, 63); fv = rdlane(pV, 63); fx2 = rdlane(pX2, 63); }
+	dp_core_f<J, IS_LO, IS_HI, RIGHT, ANYBLK, (J > 0)>(g, k, lane, p, U, V, X, Y, X2, Y2, SC, fx, fv, fx2);
+}
+template <int J, bool IS_LO, bool IS_HI, bool RIGHT, bool ANYBLK, bool HASF>
+__device__ __forceinline__ void dp_core_f(const DpDiag &g, const DpK &k, const int lane, uint8_t *p,
+                                          uint32_t &U, uint32_t &V, uint32_t &X, uint32_t &Y, uint32_t &X2, uint32_t &Y2, const uint32_t SC,
+                                          const uint32_t fx, const uint32_t fv, const uint32_t fx2)
+{
 	uint32_t nx_, nv_, nx2_;
-	if (J > 0) { nx_ = lane_shr1(fx, X); nv_ = lane_shr1(fv, V); nx2_ = lane_shr1(fx2, X2); }
+	if (HASF) { nx_ = lane_shr1(fx, X); nv_ = lane_shr1(fv, V); nx2_ = lane_shr1(fx2, X2); }
 	else { nx_ = lane_shr1_z(X); nv_ = lane_shr1_z(V); nx2_ = lane_shr1_z(X2); }   // lane 0 of block 0: t-1 = -1, always a boundary value (IS_LO below)
 	// (ANYBLK: the catch-all instance, whose first / last ACTIVE block is only known at run time -- every block compares its cells'
 	// position with that of st / of the top-row cell: selects, no branch, so that the eight blocks of an anti-diagonal stay ONE
