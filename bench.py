@@ -46,6 +46,7 @@ def _parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pcie", "--no-resident", dest="no_pcie", action="store_true", help="skip the second timed region (PCIe-inclusive: mm355_map_batch on host buffers)")
     ap.add_argument("--pcie-steps", type=int, default=3, help="blocks of the second (PCIe-inclusive) timed region")
+    ap.add_argument("--no-bin", action="store_true", help="deal the reads of a step to its sub-batches round-robin instead of by length")
     return ap.parse_args()
 
 
@@ -332,11 +333,20 @@ def main():
     t0 = time.time()
     packed, rlens_np, block_bases = {}, {}, []
     pcie_blocks = 0 if args.no_pcie else min(args.pcie_steps, n_timed_blocks)
+    from mappy_rs import shard_by_bases, order_by_length
     for b in range(n_blocks):
         blk = reads[b * per_block:(b + 1) * per_block]
         block_bases.append(sum(len(r) for r in blk))
+        # sub-batches of a step: reads of similar length together (the per-read kernels of a sub-batch cost the latency of its longest read),
+        # cut at equal cumulative bases -- mappy_rs.map_batch cuts its sub-batches the same way (order_by_length)
+        if args.no_bin:
+            subs = [blk[si::n_str] for si in range(n_str)]
+        else:
+            blk = [blk[i] for i in order_by_length([len(r) for r in blk])]
+            cut = shard_by_bases([len(r) for r in blk], n_str)
+            subs = [blk[cut[si]:cut[si + 1]] for si in range(n_str)]
         for si in range(n_str):
-            pk = _ffi.pack_reads(blk[si::n_str])
+            pk = _ffi.pack_reads(subs[si])
             rlens_np[(b, si)] = np.asarray(pk[1], dtype=np.int64)
             _ffi.check(L.mm355_batch_select(ctxs[si % n_thr], b * depth + si // n_thr))
             _ffi.check(L.mm355_batch_upload(ctxs[si % n_thr], len(pk[2]), pk[0], pk[1]))
@@ -347,6 +357,7 @@ def main():
     del reads
     log("[bench] %d blocks of %d reads uploaded (%d resident sub-batches of ~%d reads) in %.1fs" %
         (n_blocks, per_block, n_blocks * n_str, per_block // n_str, time.time() - t0))
+    reads_per_sub_nominal = per_block // n_str
 
     def step_one(b, si, resident):
         ctx = ctxs[si % n_thr]

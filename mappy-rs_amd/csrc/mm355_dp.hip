@@ -604,12 +604,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	static const bool legacy_groups = [] { const char *e = getenv("MM355_DP_SPLIT_LONG"); return e && atoi(e) != 0; }();
 	const DpJobDev *dj = c->dp_jobs.as<DpJobDev>();
 	mm355_dpres_t *dres = c->dp_res.as<mm355_dpres_t>();
-	auto group_stream = [&](int sidx, hipStream_t *out) -> int {
-		hipStream_t *slot = &c->dp_st[sidx];
-		if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
-		*out = *slot;
-		return 0;
-	};
+	auto group_stream = [&](int sidx, hipStream_t *out) -> int { return mm355_dp_stream(c, sidx, out); };
 	auto group_begin = [&](int g, hipStream_t gst) -> int {
 		if (c->dp_ev[g] == 0) HIPCHK(hipEventCreateWithFlags(&c->dp_ev[g], hipEventDisableTiming));
 		HIPCHK(hipStreamWaitEvent(gst, c->dp_up_ev, 0));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <stdlib.h>
 #include "mm355_host.h"
 #include "mm355_dev.h"
 
@@ -13,6 +14,8 @@ struct DBuf {
 		// grow-only with 50 % headroom: a re-allocation is a hipFree + hipMalloc (both synchronise the device and stall every other context), and
 		// the sub-batches of a read stream differ by tens of per cent in anchors and extension cells; a context's buffers are ~10 GB of 288 GB
 		// (the direction matrices of the extension rounds -- the one buffer of ten and more GB -- take 25 %)
+		static const int slack_env = [] { const char *e = getenv("MM355_BUF_SLACK_DIV"); return e? atoi(e) : 0; }();   // (experiments: 8 = 12.5 % headroom)
+		if (slack_env > 0 && slack_env > slack_div) slack_div = slack_env;
 		const size_t slack = bytes / (size_t)slack_div;
 		size_t want = bytes + slack + 256;
 		if (hipMalloc(&p, want) != hipSuccess) { p = 0; cap = 0; return -1; }
@@ -77,7 +80,7 @@ struct mm355_ctx {
 	// per-batch device buffers
 	DBuf heavy, seq, roff, rlen, order, ck_read, ck_start, ck_n, ck_r0;
 	int64_t n_chunks = 0;
-	int prio_low = 0, prio_high = 0; bool use_prio = false;
+	int prio_low = 0, prio_high = 0; bool use_prio = false; int ord = 0;   // ord: creation ordinal of the context
 	DBuf sort_tmp, sort_flag, tie_list;   // fast anchor sort (mm355_fastsort.hip)
 	int n_heavy = 0; hipStream_t aux_st = 0; hipEvent_t aux_ev = 0, aux_ev2 = 0; DBuf sort_tasks;
 	DBuf mz, mz_tmp, n_mz, sn, sv, sflt, hl, soff, n_a, rep_len, n_mini, mini_pos, counters, err;
@@ -102,6 +105,8 @@ struct mm355_ctx {
 };
 
 DevParams mm355_make_params(const mm355_mapopt_t *mo, const mm355_index *mi);
+bool mm355_dp_shared_streams();
+int mm355_dp_stream(mm355_ctx *c, int sidx, hipStream_t *out);   // stream of an extension kernel class (shared by the contexts of a device)
 int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi);
 
 // stage drivers (each leaves its outputs resident on the device and the per-read counts in ctx->hb)

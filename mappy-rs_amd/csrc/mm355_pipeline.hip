@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <numeric>
 #include <mutex>
+#include <atomic>
 #include "mm355_pipeline.h"
 #include "mm355_rmq.h"
 
@@ -68,6 +69,46 @@ extern "C" int mm355_device_synchronize(int device_id)
 	return 0;
 }
 
+// Streams of the extension rounds.  The runtime multiplexes the HIP streams of a priority level over GPU_MAX_HW_QUEUES (8) hardware queues,
+// handed out round-robin at stream creation; a kernel waits for everything in front of it on its QUEUE, whatever stream that came from.
+// With eight extension streams per context (round 2) the long latency chains of one context (k_ksw_regw8 / k_ksw_rowl: a few dozen
+// alignments for 10-20 ms) sat on the queue of another context's k_ksw_row<2> -- a kernel of the TURN, which every other context's round is
+// waiting for (rocprofv3 trace of round 3: a turn kernel started 17 ms late behind such a chain; the turn kernels covered 56 % of the time).
+// The rounds take turns anyway, so the classes need no stream per context: one pool of eight per device, each class on a queue of its own
+//   0 row<2> + approximate targets <= 256    2 row<8> + approximate 1024    3 row<4> + approximate 512        (the turn)
+//   1 exact register classes   4 eight-wave LDS kernel (all long targets)   6 k_ksw_rowl   5 / 7 k_ksw_regw8 (contexts alternate)
+// Measured (round 3, default bench, alternating runs on one box): shared pool 853 / 795 Mbases/s against 876 / 865 with eight streams per
+// context -- the exact classes and the long chains of different contexts then wait for one another on their one stream, which costs more
+// than the occasional held turn.  Kept as an experiment switch (MM355_DP_SHARED_STREAMS=1); the default is a set of streams per context.
+bool mm355_dp_shared_streams() { static const bool on = [] { const char *e = getenv("MM355_DP_SHARED_STREAMS"); return e && atoi(e) != 0; }(); return on; }
+int mm355_dp_stream(mm355_ctx *c, int sidx, hipStream_t *out)
+{
+	static std::mutex mu;
+	static hipStream_t pool[16][8];
+	static bool ready[16];
+	if (!mm355_dp_shared_streams()) {
+		hipStream_t *slot = &c->dp_st[sidx];
+		if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
+		*out = *slot;
+		return 0;
+	}
+	const int d = c->dev & 15;
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		if (!ready[d]) {
+			for (int i = 0; i < 8; ++i) {
+				if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&pool[d][i], hipStreamNonBlocking, c->prio_low));
+				else HIPCHK(hipStreamCreateWithFlags(&pool[d][i], hipStreamNonBlocking));
+			}
+			ready[d] = true;
+		}
+	}
+	if (sidx == 5) sidx = 4;                            // one stream for every long-target launch
+	if (sidx == 7 && (c->ord & 1)) sidx = 5;            // k_ksw_regw8: two streams, the contexts alternate
+	*out = pool[d][sidx];
+	return 0;
+}
+
 extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ctx_t **out)
 {
 	*out = 0;
@@ -85,15 +126,18 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		if (use_prio && hi < lo) HIPCHK(hipStreamCreateWithPriority(&c->st, hipStreamDefault, hi));
 		else HIPCHK(hipStreamCreate(&c->st));
 		c->prio_low = use_prio && hi < lo? lo : 0; c->prio_high = use_prio && hi < lo? hi : 0; c->use_prio = use_prio && hi < lo;
-		// The four streams of the wide extension classes are created here, back to back under a lock: the runtime hands out hardware
-		// queues round-robin at stream creation, and the classes of one context must not share a queue (they would run one after the
-		// other: +6 ms on a 16 ms round when contexts created their streams concurrently on first use).
+		// The streams of the extension classes are created here, back to back under a lock: the runtime hands out hardware queues round-robin at
+		// stream creation, and the classes of one context must not share a queue (MM355_DP_SHARED_STREAMS=1: one pool per device, mm355_dp_stream).
 		static std::mutex mk;
 		std::lock_guard<std::mutex> lk(mk);
-		for (int i = 0; i < 6; ++i) {   // 0..3 the register classes, 4 and 5 the eight-wave kernel (mm355_dp_run): with the main and the sort stream, 8 per context
-			if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, c->prio_low));
-			else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[i], hipStreamNonBlocking));
-		}
+		static std::atomic<int> n_ctx(0);
+		c->ord = n_ctx.fetch_add(1);
+		if (!mm355_dp_shared_streams()) {
+			for (int i = 0; i < 6; ++i) {   // 0..3 the register classes, 4 and 5 the eight-wave kernel (mm355_dp_run): with the main and the sort stream, 8 per context
+				if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, c->prio_low));
+				else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[i], hipStreamNonBlocking));
+			}
+		} else { hipStream_t t; int rc = mm355_dp_stream(c, 0, &t); if (rc) { delete c; return rc; } }
 		// the stream of the block-level sort of anchor-rich reads: same consideration (7 streams per context, 8 hardware queues)
 		if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->aux_st, hipStreamNonBlocking, c->prio_high)); else HIPCHK(hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking));
 		HIPCHK(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev2, hipEventDisableTiming));

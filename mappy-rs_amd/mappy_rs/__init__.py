@@ -27,7 +27,7 @@ import numpy as np
 
 from . import _ffi
 
-__all__ = ["Aligner", "Mapping", "shard_by_bases"]
+__all__ = ["Aligner", "Mapping", "shard_by_bases", "order_by_length"]
 
 _CIGAR_OPS = "MIDNSHP=X"
 
@@ -191,6 +191,13 @@ def shard_by_bases(lengths, n_shards):
     mid2 = 2 * cum - lengths                      # twice the midpoint, exact in integers
     shard = np.minimum(n_shards - 1, (mid2 * n_shards) // (2 * total))
     return [int(np.searchsorted(shard, s, side="left")) for s in range(n_shards)] + [n]
+
+
+def order_by_length(lengths):
+    """indices of the reads, longest first (stable).  The per-read kernels of a sub-batch cost the latency of its longest read, so a
+    dispatcher that has a window of pending reads cuts its sub-batches from this order: sub-batches of similar reads, the few very long
+    ones together"""
+    return np.argsort(-np.asarray(lengths, dtype=np.int64), kind="stable").tolist()
 
 
 class _Channel:
