@@ -201,9 +201,10 @@ int mm355_stage_dp(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_jobs, c
                    mm355_dpres_t *res, uint32_t *cigar, int64_t cigar_cap);
 /* the per-base walk of an aligned region (minimap2 align.c::mm_update_extra after mm_fix_cigar: mlen, blen, n_ambi, dp_max) and its cs
    string (format.c::write_cs_core, short form), as the mapping path runs them on the device for all regions of a batch (k_extra).
-   Stage entry for parity tests: the query codes (0..4 per byte) come from the caller, the target from the index (contig rid, from t_st). */
+   Stage entry for parity tests: the query codes (0..4 per byte) come from the caller, the target from the index (contig rid, from t_st).
+   want_cs: bit 0 = cs, bit 1 = MD (format.c::write_MD_core); both strings land in `cs` (cs_off / md_off). */
 typedef struct { int64_t q_off; int64_t cigar_off; int32_t rid, t_st, n_cigar, pad; } mm355_extrajob_t;
-typedef struct { int32_t mlen, blen, n_ambi, dp_max; int64_t cs_off; int32_t cs_len, pad; } mm355_extrares_t;
+typedef struct { int32_t mlen, blen, n_ambi, dp_max; int64_t cs_off; int32_t cs_len, pad; int64_t md_off; int32_t md_len, pad2; } mm355_extrares_t;
 int mm355_stage_extra(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_regions, const mm355_extrajob_t *jobs,
                       const uint8_t *qcodes, int64_t n_q, const uint32_t *cigar, int64_t n_cigar, int want_cs,
                       mm355_extrares_t *res, char *cs, int64_t cs_cap);

@@ -35,4 +35,4 @@ int mm355_run_read_codes(mm355_ctx *c);
 #include "mm355_extra.h"
 // segs / seg_first / cig: pinned host arrays (mm355_glue_extra_fill); results: out[n_regions] (pinned, c->h_xout) and the compacted cs bytes (c->h_xcs)
 int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob *segs, size_t n_segs, const int64_t *seg_first, size_t n_regions,
-                    const uint32_t *cig, size_t n_cig, size_t cs_cap, bool want_cs, const Mm355ExtraOut **out, const char **cs);
+                    const uint32_t *cig, size_t n_cig, size_t cs_cap, int want, const Mm355ExtraOut **out, const char **cs);   // want: bit 0 cs, bit 1 MD

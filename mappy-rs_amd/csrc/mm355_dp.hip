@@ -757,20 +757,22 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	return 0;
 }
 
-// ------------------------------------------------------------------ row f2: mm_update_extra's walk + cs on the device
+// ------------------------------------------------------------------ row f2: mm_update_extra's walk, cs and MD on the device
 // U:align.c::mm_update_extra (after mm_fix_cigar, which stays on the host: it edits the CIGAR) walks every aligned column of a region for
-// mlen / blen / n_ambi and the local-maximum score dp_max; U:format.c::write_cs_core (short form) walks the same columns again for the cs
-// string.  On the host that was ~17 us of CPU per GRCh38-scale read.  Here: all regions of a batch in one launch after the last extension
-// round, one LANE per SEGMENT of 64 CIGAR operations (~500 columns) -- a lane per region was a 45 ms tail on a 100 kb read, every column
-// two dependent-latency loads; ~150 000 equal segments hide that latency behind one another.  What makes the cut exact:
-//   * counts and cs pieces simply add up / concatenate (write_cs_core flushes its match run at the end of every M operation);
-//   * the score walk s <- max(0, s + d) with running maximum is a max-plus map: a segment leaves (A, m, C, P) (Mm355ExtraSegOut) and
-//     k_extra_compose replays the segments of a region in order.  s is a double as in the reference; every partial sum of integer match
-//     scores and float-valued log gap costs is exact in double (< 2^20 in magnitude, fractions of 2^-23), so regrouping the additions
-//     changes nothing.
-// The cs bytes go to worst-case sized slots and are compacted afterwards (k_extra_scan / k_extra_compact): only real bytes cross PCIe.
+// mlen / blen / n_ambi and the local-maximum score dp_max; U:format.c::write_cs_core (short form) and write_MD_core walk the same columns
+// again for the cs / MD strings.  On the host that was ~17 us of CPU per GRCh38-scale read.  Here: all regions of a batch in one launch after
+// the last extension round, one LANE per SEGMENT of at most 64 CIGAR operations and 2048 columns -- a lane per region was a 45 ms tail on a
+// 100 kb read, every column two dependent-latency loads; ~150 000 equal segments hide that latency behind one another.  Long match
+// operations (HiFi) are cut between segments.  What makes the cut exact (mm355_extra.h):
+//   * counts add up;
+//   * the score walk s <- max(0, s + d) with running maximum is a max-plus map: a segment leaves (A, m, C, P) and k_extra_compose replays
+//     the segments of a region in order.  s is a double as in the reference; every partial sum of integer match scores and float-valued log
+//     gap costs is exact in double (< 2^20 in magnitude, fractions of 2^-23), so regrouping the additions changes nothing;
+//   * a run of matches that crosses a cut is printed once: a segment leaves the first number it would print to the composer (its `lead` plus
+//     the `tail` carried over from the segments before it) and never prints what is still pending at its end.
+// The string bytes go to worst-case sized slots and are compacted afterwards (k_extra_scan / k_extra_compact): only real bytes cross PCIe.
 __global__ __launch_bounds__(WAVE) void k_extra(DevIndex ix, const uint8_t *rq, const Mm355ExtraJob *segs, int n_segs, const uint32_t *cig, Mm355ExtraScore sc,
-                                                 char *cs, Mm355ExtraSegOut *out, int want_cs)
+                                                 char *cs, Mm355ExtraSegOut *out, int want)
 {
 	const int k = blockIdx.x * WAVE + threadIdx.x;
 	if (k >= n_segs) return;
@@ -778,29 +780,36 @@ __global__ __launch_bounds__(WAVE) void k_extra(DevIndex ix, const uint8_t *rq, 
 	const uint8_t *q = rq + jb.q_src;
 	const uint64_t tb = ix.seq_off[jb.rid] + (uint64_t)jb.t_st;
 	const uint32_t *cg = cig + jb.cig_off;
-	char *o = cs + jb.cs_off;
-	int32_t n_out = 0, qoff = 0, toff = 0, mlen = 0, blen = 0, n_ambi_tot = 0;
+	char *o = cs + jb.cs_off, *om = cs + jb.md_off;
+	const bool want_cs = want & 1, want_md = want & 2;
+	int32_t n_out = 0, n_md = 0, qoff = 0, toff = 0, mlen = 0, blen = 0, n_ambi_tot = 0;
+	int32_t cs_lead = 0, md_lead = 0, flushed = 0, cs_pre = 0;
+	unsigned run = 0, l_md = 0;      // matches pending for cs (inside the current match operation) and for MD (across operations)
 	double A = 0.0, m = 1e300, C = -1e300, P = -1e300;
-	const char *nt = "acgtn";
+	const char *nt = "acgtn", *NT = "ACGTN";
 #define EX_T(off) ((uint32_t)(ix.S[(tb + (uint64_t)(off)) >> 3] >> (((tb + (uint64_t)(off)) & 7) << 2)) & 0xfu)
-#define EX_NUM(lead, v) do { char bf_[12]; int nb_ = 0; unsigned v_ = (v); do { bf_[nb_++] = (char)('0' + v_ % 10); v_ /= 10; } while (v_); o[n_out++] = (lead); while (nb_ > 0) o[n_out++] = bf_[--nb_]; } while (0)
+#define EX_PUT(buf, pos, lead, v) do { char bf_[12]; int nb_ = 0; unsigned v_ = (v); do { bf_[nb_++] = (char)('0' + v_ % 10); v_ /= 10; } while (v_); if (lead) buf[pos++] = (lead); while (nb_ > 0) buf[pos++] = bf_[--nb_]; } while (0)
+#define EX_FLUSH_CS() do { if (!(flushed & 1)) { cs_lead = (int32_t)run; cs_pre = n_out; flushed |= 1; } else if (run) EX_PUT(o, n_out, ':', run); run = 0; } while (0)
+#define EX_FLUSH_MD() do { if (!(flushed & 2)) { md_lead = (int32_t)l_md; flushed |= 2; } else EX_PUT(om, n_md, 0, l_md); l_md = 0; } while (0)
 #define EX_STEP(d) do { A += (d); m = A < m? A : m; C = A > C? A : C; const double am_ = A - m; P = am_ > P? am_ : P; } while (0)
 	for (int c = 0; c < jb.n_cigar; ++c) {
-		const uint32_t op = cg[c] & 0xf, len = cg[c] >> 4;
-		if (op == 0) {
+		const uint32_t op = cg[c] & 0xf, full = cg[c] >> 4;
+		const uint32_t l0 = c == 0? (uint32_t)jb.skip0 : 0u, l1 = c == jb.n_cigar - 1 && jb.end_last > 0? (uint32_t)jb.end_last : full;
+		const uint32_t len = l1 - l0;
+		if (op == 0 || op == 7 || op == 8) {
 			int n_ambi = 0, n_diff = 0;
-			unsigned run = 0;
 			for (uint32_t l = 0; l < len; ++l) {
 				const uint32_t cq = q[qoff + l], ct = EX_T(toff + l);
 				if (ct > 3 || cq > 3) ++n_ambi;
 				else if (ct != cq) ++n_diff;
 				EX_STEP((double)sc.mat[ct * 5 + cq]);
-				if (want_cs) {
-					if (cq == ct) ++run;
-					else { if (run) { EX_NUM(':', run); run = 0; } o[n_out++] = '*'; o[n_out++] = nt[ct]; o[n_out++] = nt[cq]; }
+				if (cq == ct) { ++run; ++l_md; }
+				else {
+					if (want_cs) { EX_FLUSH_CS(); o[n_out++] = '*'; o[n_out++] = nt[ct]; o[n_out++] = nt[cq]; }
+					if (want_md) { EX_FLUSH_MD(); om[n_md++] = NT[ct]; }
 				}
 			}
-			if (want_cs && run) EX_NUM(':', run);
+			if (want_cs && l1 == full) EX_FLUSH_CS();          // the end of a match operation ends its run (a cut does not)
 			blen += (int32_t)len - n_ambi; mlen += (int32_t)len - (n_ambi + n_diff); n_ambi_tot += n_ambi;
 			toff += (int32_t)len; qoff += (int32_t)len;
 		} else if (op == 1) {
@@ -813,48 +822,72 @@ __global__ __launch_bounds__(WAVE) void k_extra(DevIndex ix, const uint8_t *rq, 
 		} else if (op == 2) {
 			int n_ambi = 0;
 			if (want_cs) o[n_out++] = '-';
-			for (uint32_t l = 0; l < len; ++l) { const uint32_t ct = EX_T(toff + l); if (ct > 3) ++n_ambi; if (want_cs) o[n_out++] = nt[ct]; }
+			if (want_md) { EX_FLUSH_MD(); om[n_md++] = '^'; }
+			for (uint32_t l = 0; l < len; ++l) { const uint32_t ct = EX_T(toff + l); if (ct > 3) ++n_ambi; if (want_cs) o[n_out++] = nt[ct]; if (want_md) om[n_md++] = NT[ct]; }
 			blen += (int32_t)len - n_ambi; n_ambi_tot += n_ambi;
 			EX_STEP(-((double)sc.q + (double)sc.e * (double)mm_log2f_approx((float)(1.0 + (double)len))));
 			toff += (int32_t)len;
 		} else if (op == 3) toff += (int32_t)len;
 	}
 #undef EX_T
-#undef EX_NUM
+#undef EX_PUT
+#undef EX_FLUSH_CS
+#undef EX_FLUSH_MD
 #undef EX_STEP
 	Mm355ExtraSegOut r;
-	r.A = A; r.m = m; r.C = C; r.P = P; r.mlen = mlen; r.blen = blen; r.n_ambi = n_ambi_tot; r.cs_len = n_out; r.cs_dense = 0;
+	r.A = A; r.m = m; r.C = C; r.P = P; r.mlen = mlen; r.blen = blen; r.n_ambi = n_ambi_tot;
+	r.cs_len = n_out; r.md_len = n_md; r.flushed = flushed;
+	r.cs_lead = (flushed & 1)? cs_lead : (int32_t)run; r.cs_tail = (flushed & 1)? (int32_t)run : 0;      // never flushed: everything it counted joins the carry
+	r.md_lead = (flushed & 2)? md_lead : (int32_t)l_md; r.md_tail = (flushed & 2)? (int32_t)l_md : 0;
+	r.cs_num = r.md_num = -1; r.cs_dense = r.md_dense = 0; r.cs_pre = (flushed & 1)? cs_pre : 0; r.pad = 0;
 	out[k] = r;
 }
 
-// exclusive prefix sum of the regions' cs lengths (one block of 256 threads: a batch has a few thousand regions; the per-segment offsets
+__device__ inline int ex_digits(unsigned v) { int n = 1; while (v >= 10) { v /= 10; ++n; } return n; }
+
+// exclusive prefix sum of the regions' string lengths (one block of 256 threads: a batch has a few thousand regions; the per-segment offsets
 // inside a region come from k_extra_compose -- a scan over the ~10^5 segments in one 1024-thread block waited milliseconds for a CU under load)
 __global__ __launch_bounds__(256) void k_extra_scan(Mm355ExtraOut *out, int n)
 {
 	__shared__ long long part[256];
 	const int t = threadIdx.x, per = (n + 255) / 256, lo = t * per < n? t * per : n, hi = lo + per < n? lo + per : n;
 	long long sum = 0;
-	for (int i = lo; i < hi; ++i) sum += out[i].cs_len;
+	for (int i = lo; i < hi; ++i) sum += out[i].cs_len + out[i].md_len;
 	part[t] = sum;
 	__syncthreads();
 	if (t == 0) { long long acc = 0; for (int i = 0; i < 256; ++i) { const long long v = part[i]; part[i] = acc; acc += v; } }
 	__syncthreads();
 	long long acc = part[t];
-	for (int i = lo; i < hi; ++i) { out[i].cs_dense = acc; acc += out[i].cs_len; }
+	for (int i = lo; i < hi; ++i) { out[i].cs_dense = acc; acc += out[i].cs_len + out[i].md_len; }
 }
 
-// one lane per region: its segments in order (U:align.c::mm_update_extra's `s` and `max`, `dp_max = (int32_t)(max + .499)`)
-__global__ __launch_bounds__(256) void k_extra_compose(Mm355ExtraSegOut *seg, const int64_t *seg_first, int n_regions, Mm355ExtraOut *out)
+// one lane per region: its segments in order (U:align.c::mm_update_extra's `s` and `max`, `dp_max = (int32_t)(max + .499)`; the numbers that
+// stand between the segments' string pieces)
+__global__ __launch_bounds__(256) void k_extra_compose(Mm355ExtraSegOut *seg, const int64_t *seg_first, int n_regions, Mm355ExtraOut *out, int want)
 {
 	const int k = blockIdx.x * 256 + threadIdx.x;
 	if (k >= n_regions) return;
 	double s = 0.0, mx = 0.0;
-	Mm355ExtraOut r; r.mlen = r.blen = r.n_ambi = 0; r.cs_len = 0; r.cs_dense = 0; r.pad = 0;
+	Mm355ExtraOut r; r.mlen = r.blen = r.n_ambi = 0; r.cs_len = r.md_len = 0; r.cs_dense = 0; r.md_end_num = -1; r.pad = 0;
+	unsigned cs_carry = 0, md_carry = 0;
 	const int64_t g0 = seg_first[k], g1 = seg_first[k + 1];
 	for (int64_t g = g0; g < g1; ++g) {
 		const Mm355ExtraSegOut e = seg[g];
-		seg[g].cs_dense = r.cs_len;   // offset of the segment's cs piece inside its region
-		r.mlen += e.mlen; r.blen += e.blen; r.n_ambi += e.n_ambi; r.cs_len += e.cs_len;
+		r.mlen += e.mlen; r.blen += e.blen; r.n_ambi += e.n_ambi;
+		int32_t cs_num = -1, md_num = -1;
+		if (want & 1) {
+			if (e.flushed & 1) { const unsigned nn = cs_carry + (unsigned)e.cs_lead; if (nn) cs_num = (int32_t)nn; cs_carry = (unsigned)e.cs_tail; }
+			else cs_carry += (unsigned)e.cs_lead;
+			seg[g].cs_dense = r.cs_len;   // offset of [number][body] inside the region's cs string
+			r.cs_len += (cs_num >= 0? 1 + ex_digits((unsigned)cs_num) : 0) + e.cs_len;
+		}
+		if (want & 2) {
+			if (e.flushed & 2) { md_num = (int32_t)(md_carry + (unsigned)e.md_lead); md_carry = (unsigned)e.md_tail; }
+			else md_carry += (unsigned)e.md_lead;
+			seg[g].md_dense = r.md_len;
+			r.md_len += (md_num >= 0? ex_digits((unsigned)md_num) : 0) + e.md_len;
+		}
+		seg[g].cs_num = cs_num; seg[g].md_num = md_num;
 		if (e.C > -1e299) {   // the segment had score steps
 			const double a = s + e.C, hi = a > e.P? a : e.P;
 			mx = hi > mx? hi : mx;
@@ -862,20 +895,45 @@ __global__ __launch_bounds__(256) void k_extra_compose(Mm355ExtraSegOut *seg, co
 			s = e.A + (s > nm? s : nm);
 		}
 	}
+	if ((want & 2) && md_carry > 0) { r.md_end_num = (int32_t)md_carry; r.md_len += ex_digits(md_carry); }   // write_MD_core: the run still open at the end
 	r.dp_max = (int32_t)(mx + .499);
 	out[k] = r;
 }
 
-__global__ __launch_bounds__(256) void k_extra_compact(const Mm355ExtraJob *segs, const Mm355ExtraSegOut *out, const Mm355ExtraOut *reg, int n, const char *cs, char *dense)
+__device__ inline int ex_put_num(char *dst, char lead, unsigned v)
+{
+	char bf[12]; int nb = 0, n = 0;
+	do { bf[nb++] = (char)('0' + v % 10); v /= 10; } while (v);
+	if (lead) dst[n++] = lead;
+	while (nb > 0) dst[n++] = bf[--nb];
+	return n;
+}
+__global__ __launch_bounds__(256) void k_extra_compact(const Mm355ExtraJob *segs, const Mm355ExtraSegOut *out, const Mm355ExtraOut *reg, const int64_t *seg_first, int n, const char *cs, char *dense, int want)
 {
 	const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per segment
 	if (k >= n) return;
-	const char *src = cs + segs[k].cs_off; char *dst = dense + reg[segs[k].region].cs_dense + out[k].cs_dense;
-	for (int i = lane; i < out[k].cs_len; i += 64) dst[i] = src[i];
+	const Mm355ExtraJob jb = segs[k];
+	const Mm355ExtraSegOut so = out[k];
+	const Mm355ExtraOut ro = reg[jb.region];
+	if (want & 1) {
+		char *dst = dense + ro.cs_dense + so.cs_dense;
+		int nn = 0;
+		if (so.cs_num >= 0) { nn = 1 + ex_digits((unsigned)so.cs_num); if (lane == 0) ex_put_num(dst + so.cs_pre, ':', (unsigned)so.cs_num); }   // behind the text of leading gaps
+		const char *src = cs + jb.cs_off;
+		for (int i = lane; i < so.cs_len; i += 64) dst[i < so.cs_pre? i : nn + i] = src[i];
+	}
+	if (want & 2) {
+		char *dst = dense + ro.cs_dense + ro.cs_len + so.md_dense;
+		int nn = 0;
+		if (so.md_num >= 0) { nn = ex_digits((unsigned)so.md_num); if (lane == 0) ex_put_num(dst, 0, (unsigned)so.md_num); }
+		const char *src = cs + jb.md_off;
+		for (int i = lane; i < so.md_len; i += 64) dst[nn + i] = src[i];
+		if (ro.md_end_num >= 0 && (int64_t)k == seg_first[jb.region + 1] - 1 && lane == 0) ex_put_num(dst + nn + so.md_len, 0, (unsigned)ro.md_end_num);
+	}
 }
 
 int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob *segs, size_t n_segs, const int64_t *seg_first, size_t n_regions,
-                    const uint32_t *cig, size_t n_cig, size_t cs_cap, bool want_cs, const Mm355ExtraOut **out, const char **cs)
+                    const uint32_t *cig, size_t n_cig, size_t cs_cap, int want, const Mm355ExtraOut **out, const char **cs)
 {
 	*out = 0; *cs = 0;
 	if (n_regions == 0) return 0;
@@ -898,19 +956,19 @@ int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob 
 	if (n_cig) HIPCHK(hipMemcpyAsync(c->x_cig.p, cig, n_cig * 4, hipMemcpyHostToDevice, c->st));
 	if (n_segs) {
 		hipLaunchKernelGGL(k_extra, dim3((unsigned)((n_segs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dix, c->rq.as<uint8_t>(), d_segs, (int)n_segs,
-		                   c->x_cig.as<uint32_t>(), sc, c->x_cs.as<char>(), d_so, want_cs? 1 : 0);
+		                   c->x_cig.as<uint32_t>(), sc, c->x_cs.as<char>(), d_so, want);
 	}
-	hipLaunchKernelGGL(k_extra_compose, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, c->st, d_so, d_first, (int)n_regions, d_ro);
-	if (want_cs) hipLaunchKernelGGL(k_extra_scan, dim3(1), dim3(256), 0, c->st, d_ro, (int)n_regions);
+	hipLaunchKernelGGL(k_extra_compose, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, c->st, d_so, d_first, (int)n_regions, d_ro, want);
+	if (want) hipLaunchKernelGGL(k_extra_scan, dim3(1), dim3(256), 0, c->st, d_ro, (int)n_regions);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(c->h_xout.p, d_ro, n_regions * sizeof(Mm355ExtraOut), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
 	const Mm355ExtraOut *ho = (const Mm355ExtraOut*)c->h_xout.p;
-	if (want_cs) {
+	if (want) {
 		size_t tot = 0;
-		for (size_t k = 0; k < n_regions; ++k) tot += (size_t)ho[k].cs_len;
+		for (size_t k = 0; k < n_regions; ++k) tot += (size_t)ho[k].cs_len + (size_t)ho[k].md_len;
 		if (c->x_dense.ensure(tot + 64) || c->h_xcs.ensure(tot + 64)) return MM355_ENOMEM;
-		if (n_segs) hipLaunchKernelGGL(k_extra_compact, dim3((unsigned)((n_segs + 3) / 4)), dim3(256), 0, c->st, d_segs, d_so, d_ro, (int)n_segs, c->x_cs.as<char>(), c->x_dense.as<char>());
+		if (n_segs) hipLaunchKernelGGL(k_extra_compact, dim3((unsigned)((n_segs + 3) / 4)), dim3(256), 0, c->st, d_segs, d_so, d_ro, d_first, (int)n_segs, c->x_cs.as<char>(), c->x_dense.as<char>(), want);
 		HIPCHK(hipGetLastError());
 		if (tot) HIPCHK(hipMemcpyAsync(c->h_xcs.p, c->x_dense.p, tot, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(mm355_wait_stream(c->st));
@@ -973,7 +1031,7 @@ extern "C" int mm355_stage_dp(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t 
 	return 0;
 }
 
-// C-ABI: the device form of mm_update_extra's walk + cs on caller-provided regions (parity tests)
+// C-ABI: the device form of mm_update_extra's walk + cs / MD on caller-provided regions (parity tests).  want_cs: bit 0 cs, bit 1 MD
 extern "C" int mm355_stage_extra(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t n_regions, const mm355_extrajob_t *jobs,
                                  const uint8_t *qcodes, int64_t n_q, const uint32_t *cigar, int64_t n_cigar, int want_cs,
                                  mm355_extrares_t *res, char *cs, int64_t cs_cap)
@@ -983,29 +1041,31 @@ extern "C" int mm355_stage_extra(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64
 	HIPCHK(hipSetDevice(c->dev));
 	if (c->rq.ensure((size_t)n_q + 64)) return MM355_ENOMEM;
 	if (n_q) HIPCHK(hipMemcpyAsync(c->rq.p, qcodes, (size_t)n_q, hipMemcpyHostToDevice, c->st));
-	size_t n_segs = 0, slot = 0;
+	size_t n_segs = 0;
 	for (int64_t k = 0; k < n_regions; ++k) {
 		if (jobs[k].n_cigar < 0 || jobs[k].cigar_off < 0 || jobs[k].cigar_off + jobs[k].n_cigar > n_cigar || (uint32_t)jobs[k].rid >= c->mi->n_seq) return MM355_EINVAL;
-		n_segs += (size_t)mm355_extra_n_segs(cigar + jobs[k].cigar_off, jobs[k].n_cigar);
-		slot += (size_t)mm355_extra_cs_cap(cigar + jobs[k].cigar_off, jobs[k].n_cigar);
+		n_segs += (size_t)mm355_extra_split(cigar + jobs[k].cigar_off, jobs[k].n_cigar, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
 	}
 	const size_t seg_b = (n_segs * sizeof(Mm355ExtraJob) + 63) & ~(size_t)63;
 	if (c->h_xjobs.ensure(seg_b + ((size_t)n_regions + 1) * 8 + 64) || c->h_xcig.ensure(((size_t)n_cigar + 16) * 4)) return MM355_ENOMEM;
 	Mm355ExtraJob *segs = (Mm355ExtraJob*)c->h_xjobs.p; int64_t *first = (int64_t*)((char*)c->h_xjobs.p + seg_b);
 	if (n_cigar) memcpy(c->h_xcig.p, cigar, (size_t)n_cigar * 4);
-	size_t g = 0; int64_t cso = 0;
+	size_t g = 0; int64_t slot = 0;
 	for (int64_t k = 0; k < n_regions; ++k) {
 		first[k] = (int64_t)g;
-		g += (size_t)mm355_extra_split(cigar + jobs[k].cigar_off, jobs[k].n_cigar, jobs[k].q_off, (uint32_t)jobs[k].rid, jobs[k].t_st, jobs[k].cigar_off, cso, (int32_t)k, segs + g);
-		cso += mm355_extra_cs_cap(cigar + jobs[k].cigar_off, jobs[k].n_cigar);
+		int64_t cc = 0, mc = 0;
+		mm355_extra_split(cigar + jobs[k].cigar_off, jobs[k].n_cigar, 0, 0, 0, 0, 0, 0, 0, 0, &cc, &mc);
+		g += (size_t)mm355_extra_split(cigar + jobs[k].cigar_off, jobs[k].n_cigar, jobs[k].q_off, (uint32_t)jobs[k].rid, jobs[k].t_st, jobs[k].cigar_off, slot, slot + cc, (int32_t)k, segs + g, 0, 0);
+		slot += cc + mc;
 	}
 	first[n_regions] = (int64_t)g;
 	const Mm355ExtraOut *xo = 0; const char *xcs = 0;
-	int rc = mm355_extra_run(c, mo, segs, n_segs, first, (size_t)n_regions, (const uint32_t*)c->h_xcig.p, (size_t)n_cigar, slot, want_cs != 0, &xo, &xcs);
+	int rc = mm355_extra_run(c, mo, segs, n_segs, first, (size_t)n_regions, (const uint32_t*)c->h_xcig.p, (size_t)n_cigar, (size_t)slot, want_cs & 3, &xo, &xcs);
 	if (rc) return rc;
 	for (int64_t k = 0; k < n_regions; ++k) {
-		mm355_extrares_t o; o.mlen = xo[k].mlen; o.blen = xo[k].blen; o.n_ambi = xo[k].n_ambi; o.dp_max = xo[k].dp_max; o.cs_off = xo[k].cs_dense; o.cs_len = want_cs? xo[k].cs_len : 0; o.pad = 0;
-		if (want_cs) { if (o.cs_off + o.cs_len > cs_cap) return MM355_ENOMEM; memcpy(cs + o.cs_off, xcs + o.cs_off, (size_t)o.cs_len); }
+		mm355_extrares_t o; o.mlen = xo[k].mlen; o.blen = xo[k].blen; o.n_ambi = xo[k].n_ambi; o.dp_max = xo[k].dp_max; o.cs_off = xo[k].cs_dense; o.cs_len = (want_cs & 1)? xo[k].cs_len : 0; o.pad = 0;
+		o.md_off = xo[k].cs_dense + xo[k].cs_len; o.md_len = (want_cs & 2)? xo[k].md_len : 0; o.pad2 = 0;
+		if (want_cs & 3) { if (o.cs_off + xo[k].cs_len + xo[k].md_len > cs_cap) return MM355_ENOMEM; memcpy(cs + o.cs_off, xcs + o.cs_off, (size_t)xo[k].cs_len + (size_t)xo[k].md_len); }
 		res[k] = o;
 	}
 	return 0;

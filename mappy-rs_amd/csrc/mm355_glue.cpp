@@ -1129,7 +1129,7 @@ static void update_extra(Reg *r, const uint8_t *qseq, const uint8_t *tseq, const
 	{ ProfScope pf2(PF_X2); fix_cigar(r, qseq, tseq, &qshift, &tshift); }
 	qseq += qshift, tseq += tshift;
 	r->blen = r->mlen = 0;
-	if (loc && !(out_flags & MM355_OUT_MD) && !eqx && mm355_extra_device_ok(p->cigar.data(), (int)p->cigar.size())) {   // the walk below and cs: on the device, for all regions of the batch at once (k_extra)
+	if (loc && !eqx && !p->cigar.empty()) {   // the walk below, cs and MD: on the device, for all regions of the batch at once (k_extra); '=' / 'X' CIGARs are rewritten here
 		p->deferred = true;
 		p->x_strand = loc->strand; p->x_qst = loc->q_st + qshift; p->x_rid = loc->rid; p->x_tst = loc->t_st + tshift;
 		return;
@@ -1769,14 +1769,14 @@ void mm355_glue_finish(const mm355_index *mi, const mm355_mapopt_t *opt, ReadSta
 	}
 }
 
-// ---- regions whose mm_update_extra walk / cs were left to the device
-static inline int64_t extra_cs_cap(const std::vector<uint32_t> &cg) { return mm355_extra_cs_cap(cg.data(), (int)cg.size()); }
+// ---- regions whose mm_update_extra walk / cs / MD were left to the device
 void mm355_glue_extra_count(const ReadState &rs, int64_t *n_regions, int64_t *n_segs, int64_t *n_cig, int64_t *n_cs)
 {
 	*n_regions = *n_segs = *n_cig = *n_cs = 0;
 	for (const Reg &r : rs.regs) if (r.p && r.p->deferred) {
-		++*n_regions; *n_segs += mm355_extra_n_segs(r.p->cigar.data(), (int)r.p->cigar.size());
-		*n_cig += (int64_t)r.p->cigar.size(); *n_cs += extra_cs_cap(r.p->cigar);
+		int64_t cc = 0, mc = 0;
+		++*n_regions; *n_segs += mm355_extra_split(r.p->cigar.data(), (int)r.p->cigar.size(), 0, 0, 0, 0, 0, 0, 0, 0, &cc, &mc);
+		*n_cig += (int64_t)r.p->cigar.size(); *n_cs += cc + mc;
 	}
 }
 // segs: this read's segment descriptors (global index seg0 + ...); seg_first[reg0 + k]: global index of region k's first segment
@@ -1788,17 +1788,20 @@ void mm355_glue_extra_fill(const ReadState &rs, int64_t q_base, Mm355ExtraJob *s
 		const int n = (int)cg.size();
 		seg_first[reg0 + k] = seg0 + g;
 		if (n) memcpy(cig + cig0, cg.data(), (size_t)n * 4);
-		g += mm355_extra_split(cg.data(), n, q_base + (r.p->x_strand? rs.qlen : 0) + r.p->x_qst, (uint32_t)r.p->x_rid, r.p->x_tst, cig0, cs0, (int32_t)(reg0 + k), segs + g);
-		++k; cig0 += n; cs0 += extra_cs_cap(cg);
+		int64_t cc = 0, mc = 0;
+		mm355_extra_split(cg.data(), n, 0, 0, 0, 0, 0, 0, 0, 0, &cc, &mc);
+		g += mm355_extra_split(cg.data(), n, q_base + (r.p->x_strand? rs.qlen : 0) + r.p->x_qst, (uint32_t)r.p->x_rid, r.p->x_tst, cig0, cs0, cs0 + cc, (int32_t)(reg0 + k), segs + g, 0, 0);
+		++k; cig0 += n; cs0 += cc + mc;
 	}
 }
-void mm355_glue_extra_apply(ReadState &rs, const Mm355ExtraOut *out, const char *cs, bool want_cs)
+void mm355_glue_extra_apply(ReadState &rs, const Mm355ExtraOut *out, const char *cs, int want)
 {
 	int64_t k = 0;
 	for (Reg &r : rs.regs) if (r.p && r.p->deferred) {
 		const Mm355ExtraOut &o = out[k++];
 		r.mlen = o.mlen; r.blen = o.blen; r.p->n_ambi += (uint32_t)o.n_ambi; r.p->dp_max = o.dp_max;
-		if (want_cs) r.p->cs.assign(cs + o.cs_dense, (size_t)o.cs_len);
+		if (want & MM355_OUT_CS) r.p->cs.assign(cs + o.cs_dense, (size_t)o.cs_len);
+		if (want & MM355_OUT_MD) r.p->md.assign(cs + o.cs_dense + o.cs_len, (size_t)o.md_len);
 		r.p->deferred = false;
 	}
 }

@@ -101,4 +101,4 @@ void mm355_glue_release(ReadState &rs);
 // apply: results back into the regions (same order as fill)
 void mm355_glue_extra_count(const ReadState &rs, int64_t *n_regions, int64_t *n_segs, int64_t *n_cig, int64_t *n_cs);
 void mm355_glue_extra_fill(const ReadState &rs, int64_t q_base, Mm355ExtraJob *segs, int64_t *seg_first, int64_t reg0, int64_t seg0, uint32_t *cig, int64_t cig0, int64_t cs0);
-void mm355_glue_extra_apply(ReadState &rs, const Mm355ExtraOut *out, const char *cs, bool want_cs);
+void mm355_glue_extra_apply(ReadState &rs, const Mm355ExtraOut *out, const char *cs, int want);   // want: MM355_OUT_CS | MM355_OUT_MD

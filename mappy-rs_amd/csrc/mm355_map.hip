@@ -370,7 +370,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	// ... and only for batches of a thousand reads or more: the extra launch (CIGARs up, three kernels, two synchronisations, cs down) costs a
 	// single read 0.65 ms and a batch of 256 reads 1.3 ms more than the host walk; at 4096 reads it is 7 ms cheaper
 	const int64_t extra_min_reads = [] { const char *e = getenv("MM355_EXTRA_MIN_READS"); return (int64_t)(e? atoll(e) : 1024); }();
-	const bool defer_extra = !extra_host && !(flags & MM355_OUT_MD) && !(mo->flag & MMF_EQX) && n_reads >= extra_min_reads;
+	const bool defer_extra = !extra_host && !(mo->flag & MMF_EQX) && n_reads >= extra_min_reads;
 	std::vector<ReadState> rs(n_reads);
 	parallel_for(n_reads, nt, [&](int64_t i, int) {
 		ReadState &r = rs[i];
@@ -429,7 +429,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 				if (xr[i + 1] > xr[i]) mm355_glue_extra_fill(rs[i], 2 * c->hb.roff[i], xsegs + xg[i], xfirst, xr[i], xg[i], xcig, xc[i], xs[i]);
 			});
 			const Mm355ExtraOut *xo = 0; const char *xcs = 0;
-			const bool want_cs = (flags & MM355_OUT_CS) != 0;
+			const int want_cs = flags & (MM355_OUT_CS | MM355_OUT_MD);
 			ms_host += now_ms() - tx0;
 			if ((rc = mm355_extra_run(c, mo, xsegs, (size_t)tg, xfirst, (size_t)tr, xcig, (size_t)tc, (size_t)ts, want_cs, &xo, &xcs))) return rc;
 			const double tx1 = now_ms();

@@ -80,7 +80,8 @@ class ExtraJob(C.Structure):
 
 
 class ExtraRes(C.Structure):
-    _fields_ = [("mlen", C.c_int32), ("blen", C.c_int32), ("n_ambi", C.c_int32), ("dp_max", C.c_int32), ("cs_off", C.c_int64), ("cs_len", C.c_int32), ("pad", C.c_int32)]
+    _fields_ = [("mlen", C.c_int32), ("blen", C.c_int32), ("n_ambi", C.c_int32), ("dp_max", C.c_int32), ("cs_off", C.c_int64), ("cs_len", C.c_int32), ("pad", C.c_int32),
+                ("md_off", C.c_int64), ("md_len", C.c_int32), ("pad2", C.c_int32)]
 
 
 class DpRes(C.Structure):

@@ -288,6 +288,7 @@ mmo_reg1_t *mmo_align_skeleton(const mmo_mapopt_t *opt, const mmo_idx_t *mi, int
 
 /* ---- format.c ---- */
 char *mmo_gen_cs(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq, int no_iden);  /* malloc'd, NUL-terminated */
+char *mmo_md_core(const uint32_t *cigar, int n_cigar, const uint8_t *qseq, const uint8_t *tseq, int *q_len, int *t_len);
 char *mmo_cs_core(const uint32_t *cigar, int n_cigar, const uint8_t *qseq, const uint8_t *tseq, int no_iden, int *q_len, int *t_len);
 void mmo_extra_walk(const uint32_t *cigar, int n_cigar, const uint8_t *qseq, const uint8_t *tseq, const int8_t *mat, int8_t q, int8_t e, int log_gap,
                     int32_t *mlen, int32_t *blen, int32_t *n_ambi, int32_t *dp_max, int32_t *q_len, int32_t *t_len);

@@ -102,16 +102,14 @@ char *mmo_gen_cs(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq, int 
 	return out;
 }
 
-char *mmo_gen_MD(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq)
+/* U:format.c::write_MD_core on given code strings (0..4) and CIGAR; also the stage entry the parity test of the device walk (k_extra) calls */
+char *mmo_md_core(const uint32_t *cigar, int n_cigar, const uint8_t *qseq, const uint8_t *tseq, int *q_len, int *t_len)
 {
 	int i, q_off, t_off, l_MD = 0;
-	uint8_t *qseq, *tseq;
 	kstr_t s = {0,0,0};
 	ks_put(&s, "", 0);
-	if (r->p == 0) return s.s;
-	get_seqs(mi, r, seq, &qseq, &tseq);
-	for (i = q_off = t_off = 0; i < (int)r->p->n_cigar; ++i) {
-		int j, op = r->p->cigar[i]&0xf, len = r->p->cigar[i]>>4;
+	for (i = q_off = t_off = 0; i < n_cigar; ++i) {
+		int j, op = cigar[i]&0xf, len = cigar[i]>>4;
 		if (op == MM_CIGAR_MATCH || op == 7 || op == 8) {
 			for (j = 0; j < len; ++j) {
 				if (qseq[q_off + j] != tseq[t_off + j]) {
@@ -132,7 +130,20 @@ char *mmo_gen_MD(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq)
 		}
 	}
 	if (l_MD > 0) ks_putd(&s, l_MD);
+	if (q_len) *q_len = q_off;
+	if (t_len) *t_len = t_off;
+	return s.s;
+}
+
+char *mmo_gen_MD(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq)
+{
+	int q_off, t_off;
+	uint8_t *qseq, *tseq;
+	char *out;
+	if (r->p == 0) { kstr_t s = {0,0,0}; ks_put(&s, "", 0); return s.s; }
+	get_seqs(mi, r, seq, &qseq, &tseq);
+	out = mmo_md_core(r->p->cigar, (int)r->p->n_cigar, qseq, tseq, &q_off, &t_off);
 	assert(t_off == r->re - r->rs && q_off == r->qe - r->qs);
 	free(qseq); free(tseq);
-	return s.s;
+	return out;
 }

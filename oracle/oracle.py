@@ -142,6 +142,8 @@ def lib():
                                     C.c_int, C.c_int, C.c_int64, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
         L.mmo_cs_core.restype = C.c_void_p
         L.mmo_cs_core.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.mmo_md_core.restype = C.c_void_p
+        L.mmo_md_core.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.mmo_extra_walk.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int8, C.c_int8, C.c_int] + [C.c_void_p] * 6
         L.mmo_lchain_rmq.restype = C.c_void_p
         L.mmo_lchain_rmq.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
@@ -155,7 +157,7 @@ CIGAR_OPS = "MIDNSHP=X"
 
 def update_extra_stage(qcodes, tcodes, ops, a, b, sc_ambi, q, e):
     """the oracle's own mm_update_extra walk (after mm_fix_cigar) and write_cs_core on given code strings and CIGAR [(op, len)]:
-    (mlen, blen, n_ambi, dp_max, cs) -- the stage oracle of the device walk k_extra"""
+    (mlen, blen, n_ambi, dp_max, cs, MD) -- the stage oracle of the device walk k_extra"""
     L = lib()
     cig = np.array([ln << 4 | op for op, ln in ops] + [0], np.uint32)
     qc = np.ascontiguousarray(np.concatenate([qcodes, np.zeros(8, np.uint8)]), np.uint8)
@@ -167,7 +169,10 @@ def update_extra_stage(qcodes, tcodes, ops, a, b, sc_ambi, q, e):
     p = L.mmo_cs_core(cig.ctypes.data, len(ops), qc.ctypes.data, tc.ctypes.data, 1, None, None)
     cs = C.string_at(p).decode()
     L.free(p)
-    return int(out[0]), int(out[1]), int(out[2]), int(out[3]), cs
+    p = L.mmo_md_core(cig.ctypes.data, len(ops), qc.ctypes.data, tc.ctypes.data, None, None)
+    md = C.string_at(p).decode()
+    L.free(p)
+    return int(out[0]), int(out[1]), int(out[2]), int(out[3]), cs, md
 
 
 class OracleAligner:

@@ -865,16 +865,17 @@ def _update_extra_ref(q, t, cigar, a, b, amb, go, ge):
 def test_update_extra_and_cs_on_device(ont):
     """k_extra (row f2) through its stage entry: mlen / blen / n_ambi / dp_max and the cs string of regions with given CIGARs -- one to
     several hundred operations (1 .. 6 segments of 64), long gaps (log cost), runs of mismatches (the score clamps at 0), ambiguous bases,
-    regions that begin or end with a gap, a region without operations"""
+    regions that begin or end with a gap, a region without operations, match operations of up to 12 000 columns (cut between lanes: runs of
+    matches, the cs number and the MD count cross the cuts) -- against the oracle's own mm_update_extra walk, write_cs_core and write_MD_core"""
     from mappy_rs import _ffi
     L = _ffi.lib()
     rng = np.random.default_rng(41)
     al = ont["al"]
     t_all = np.asarray(ont["g"][0], np.uint8)     # codes 0..4 of chr1 (with N runs)
     jobs, qs, cigs, refs = [], [], [], []
-    for i in range(60):
-        n_ops = int([0, 1, 2, 63, 64, 65, 127, 128, 129, 300][i % 10]) if i < 30 else int(rng.integers(1, 400))
-        t_st = int(rng.integers(0, len(t_all) - 60000))
+    for i in range(72):
+        n_ops = int([0, 1, 2, 63, 64, 65, 127, 128, 129, 300][i % 10]) if i < 30 else int(rng.integers(1, 400)) if i < 60 else int(rng.integers(1, 12))
+        t_st = int(rng.integers(0, len(t_all) - (200000 if i >= 60 else 60000)))
         ops, q, to = [], [], 0
         for k in range(n_ops):
             last = ops[-1][0] if ops else -1
@@ -882,9 +883,10 @@ def test_update_extra_and_cs_on_device(ont):
             if op == last: op = 0
             if i % 7 == 3 and k == 0: op = int(rng.choice([1, 2]))        # region that begins with a gap
             ln = int(rng.integers(1, 40)) if op == 0 else int(rng.choice([1, 1, 2, 3, 10, 60, 700, 3000]))
+            if i >= 60 and op == 0: ln = int(rng.choice([500, 1792, 2048, 2049, 2304, 4096, 7000, 12000]))   # HiFi-like: match operations longer than a segment (cut between lanes)
             if op == 0:
                 seg = t_all[t_st + to:t_st + to + ln].copy()
-                mm = rng.random(ln) < (0.6 if (i % 5 == 1 and k % 8 < 4) else 0.08)     # stretches of mismatches: s falls back to 0
+                mm = rng.random(ln) < (0.6 if (i % 5 == 1 and k % 8 < 4) else 0.08 if i < 60 else (0.0 if i % 3 == 0 else 0.002))     # stretches of mismatches: s falls back to 0; long operations: runs of matches across the cuts
                 seg[mm] = (seg[mm] + rng.integers(1, 4, int(mm.sum()))) % 4
                 if i % 6 == 2: seg[rng.random(ln) < 0.05] = 4
                 q.append(seg); to += ln
@@ -901,17 +903,18 @@ def test_update_extra_and_cs_on_device(ont):
         ja[i].q_off, ja[i].cigar_off, ja[i].rid, ja[i].t_st, ja[i].n_cigar = qo, co, 0, t_st, len(ops)
         qo += len(qs[i]); co += len(ops)
     res = (_ffi.ExtraRes * len(jobs))()
-    cap = int(3 * (qcat.size + sum(ln for _, ops in jobs for op, ln in ops)) + 64 * len(cig))
+    cap = int(5 * (qcat.size + sum(ln for _, ops in jobs for op, ln in ops)) + 64 * len(cig))
     cs = np.zeros(cap, np.uint8)
     mo = al._mo
     sr = al._stage_runner()
-    _ffi.check(L.mm355_stage_extra(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, cig.ctypes.data, len(cig) - 1, 1, res, cs.ctypes.data, cap))
+    _ffi.check(L.mm355_stage_extra(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, cig.ctypes.data, len(cig) - 1, 3, res, cs.ctypes.data, cap))   # cs and MD
     for i, (t_st, ops) in enumerate(jobs):
         t_len = sum(ln for op, ln in ops if op != 1)
         exp = O.update_extra_stage(qs[i], t_all[t_st:t_st + t_len + 8], ops, mo.a, mo.b, mo.sc_ambi, mo.q, mo.e)   # the oracle's own walk + write_cs_core
-        got = (res[i].mlen, res[i].blen, res[i].n_ambi, res[i].dp_max, bytes(cs[res[i].cs_off:res[i].cs_off + res[i].cs_len]).decode())
-        assert got == exp, (i, len(ops), got[:4], exp[:4])
-        assert exp == _update_extra_ref(qs[i], t_all[t_st:], ops, mo.a, mo.b, mo.sc_ambi, mo.q, mo.e), i       # (and the independent restatement in this file)
+        got = (res[i].mlen, res[i].blen, res[i].n_ambi, res[i].dp_max, bytes(cs[res[i].cs_off:res[i].cs_off + res[i].cs_len]).decode(),
+               bytes(cs[res[i].md_off:res[i].md_off + res[i].md_len]).decode())
+        assert got == exp, (i, len(ops), got[:4], exp[:4], got[4][:80], exp[4][:80], got[5][:80], exp[5][:80])
+        assert exp[:5] == _update_extra_ref(qs[i], t_all[t_st:], ops, mo.a, mo.b, mo.sc_ambi, mo.q, mo.e), i       # (and the independent restatement in this file)
     sr.close()
 
 
