@@ -520,7 +520,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			// computes (found by the option fuzzer: scoring=(4,10,3,3,12,3)); those options keep the literal anti-diagonal kernels.
 			const bool regular = dc.e > dc.e2 || (dc.e == dc.e2 && dc.q == dc.q2);
 			const bool row_kind = use_row && regular && (j.flag & EZ_APPROX_MAX) && !(j.flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= j.qlen + j.tlen;
-			const bool row = row_kind && j.tlen <= ROW_MAX_T && j.qlen + j.tlen <= ROW_MAX_QT;
+			// (the int16 value range is checked for the row sweep's register sets as for the long variant: a user scoring such as e2 >= 7 or a
+			// large match score would wrap the packed halves; such problems keep the anti-diagonal kernels)
+			const bool row = row_kind && j.tlen <= ROW_MAX_T && j.qlen + j.tlen <= ROW_MAX_QT && rowl_range_ok(dc, j.qlen, j.tlen <= 256? 256 : j.tlen <= 512? 512 : 1024);
 			const bool rowl = row_kind && use_rowl && j.tlen > ROW_MAX_T && j.tlen <= ROWL_MAX_T && j.qlen <= ROWL_MAX_Q && rowl_range_ok(dc, j.qlen, j.tlen);
 			if (row || rowl) {
 				j.pad = 1;

@@ -372,6 +372,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	const int64_t extra_min_reads = [] { const char *e = getenv("MM355_EXTRA_MIN_READS"); return (int64_t)(e? atoll(e) : 1024); }();
 	const bool defer_extra = !extra_host && !(mo->flag & MMF_EQX) && n_reads >= extra_min_reads;
 	std::vector<ReadState> rs(n_reads);
+	struct RegGuard { std::vector<ReadState> &v; ~RegGuard() { for (ReadState &r : v) mm355_glue_release(r); } } reg_guard{rs};   // every return below frees the regions' Extra records
 	parallel_for(n_reads, nt, [&](int64_t i, int) {
 		ReadState &r = rs[i];
 		r.qlen = dl[i]; r.seq = seqs[i]; r.rep_len = hb.rep_len[i]; r.defer_extra = defer_extra;

@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B sweep of bench.py variants on the GPU box: tools/sweep.sh <outdir> [variant-file]
-# variant file: one variant per line, "name|ENV=.. ENV=..|bench args"; default = the stream / hardware-queue variants below
+# variant file: one variant per line, "name|ENV=.. ENV=..|bench args"; default = the variants below (the first and the last are the same: their difference is the noise of the box)
 out=$1; mkdir -p $out
 run() { name=$1; envs=$2; args=$3; echo "== $name: $envs bench.py $args" >> $out/sweep.log
-  env $envs timeout 600 python bench.py --no-cpu --no-resident --steps 3 --warmup 1 $args > $out/$name.json 2> $out/$name.err
+  env $envs timeout 600 python bench.py --no-cpu --no-pcie --steps 6 --warmup 1 $args > $out/$name.json 2> $out/$name.err
   python - "$out/$name.json" >> $out/sweep.log <<'PY'
 import json,sys
 try:
@@ -14,15 +14,16 @@ PY
 if [ -n "$2" ]; then
   while IFS='|' read -r name envs args; do [ -n "$name" ] && run "$name" "${envs:-A=1}" "$args"; done < "$2"
 else
+  # (every knob below exists in the library: MM355_DP_TURNS, MM355_DP_REGW8, MM355_DP_SHARED_STREAMS, MM355_RMQ_ON_HOST, MM355_BUF_SLACK_DIV, GPU_MAX_HW_QUEUES)
   run base "A=1" ""
-  run dpstreams0 "MM355_DP_STREAMS=0" ""
   run q16 "GPU_MAX_HW_QUEUES=16" ""
-  run q16_dps0 "GPU_MAX_HW_QUEUES=16 MM355_DP_STREAMS=0" ""
-  run q24_dps0 "GPU_MAX_HW_QUEUES=24 MM355_DP_STREAMS=0" ""
-  run q24_dps0_glob "GPU_MAX_HW_QUEUES=24 MM355_DP_STREAMS=0 MM355_DP_GLOBAL_STREAMS=1" ""
-  run s8d3 "A=1" "--streams 8 --depth 3"
-  run s12d2 "A=1" "--streams 12 --depth 2"
-  run q24_dps0_s12d2 "GPU_MAX_HW_QUEUES=24 MM355_DP_STREAMS=0" "--streams 12 --depth 2"
+  run q4 "GPU_MAX_HW_QUEUES=4" ""
   run turns2 "MM355_DP_TURNS=2" ""
+  run regw1 "MM355_DP_REGW8=0" ""
+  run shared "MM355_DP_SHARED_STREAMS=1" ""
+  run rmqhost "MM355_RMQ_ON_HOST=1" ""
+  run nobin "A=1" "--no-bin"
+  run s8d2 "MM355_BUF_SLACK_DIV=8" "--reads 98304 --streams 8 --depth 2"
+  run base2 "A=1" ""
 fi
 cat $out/sweep.log
