@@ -27,6 +27,7 @@ struct DpGather {           // where the code strings of a job come from
 };
 
 DpConst mm355_dp_const(const mm355_mapopt_t *mo);
+size_t mm355_dp_matrix_bytes(const mm355_mapopt_t *mo, const DpConst &dc, int qlen, int tlen, int w, int flag);   // direction-matrix bytes mm355_dp_run will lay out for one problem
 int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t n, const uint8_t *d_q, const uint8_t *d_t, HBuf *arena,
                  const mm355_dpres_t **res_out, const uint32_t **cigar_out);   // results live in pinned host buffers (c->h_res, *arena)
 int mm355_dp_gather(mm355_ctx *c, const DpGather *g, size_t n, size_t q_tot, size_t t_tot);   // g: pinned, valid until the next call

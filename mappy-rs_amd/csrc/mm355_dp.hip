@@ -483,6 +483,27 @@ static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc
 
 // runs n jobs whose code strings are already on the device (d_q/d_t).  `jobs` is host memory that stays valid until the call
 // returns (pinned when it comes from the mapping path).  Results: res_out -> c->h_res (pinned, valid until the next call),
+// bytes of direction matrix mm355_dp_run lays out for one extension problem (the caller cuts a round so that a launch fits its HBM budget):
+// the row sweep's row-major matrix for the full-band approximate fills it takes, the reference's anti-diagonal layout otherwise
+size_t mm355_dp_matrix_bytes(const mm355_mapopt_t *mo, const DpConst &dc, int qlen, int tlen, int w_in, int flag)
+{
+	if (qlen <= 0 || tlen <= 0) return 0;
+	if (mo->max_sw_mat > 0 && (int64_t)tlen * qlen > mo->max_sw_mat) return 0;
+	static const bool legacy = [] { const char *e = getenv("MM355_DP_LEGACY"); return e && atoi(e) != 0; }();
+	static const bool use_row = [] { const char *e = getenv("MM355_DP_ROW"); return !legacy && !(e && atoi(e) == 0); }();
+	static const bool use_rowl = [] { const char *e = getenv("MM355_DP_ROWL"); return !(e && atoi(e) == 0); }();
+	const int w = w_in < 0? std::max(qlen, tlen) : w_in;
+	int n_col_ = std::min(qlen, tlen);
+	n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
+	const int T = (tlen + 15) / 16 * 16;
+	const bool regular = dc.e > dc.e2 || (dc.e == dc.e2 && dc.q == dc.q2);
+	const bool row_kind = dc.valid && use_row && regular && (flag & EZ_APPROX_MAX) && !(flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= qlen + tlen;
+	const bool row = row_kind && tlen <= ROW_MAX_T && qlen + tlen <= ROW_MAX_QT && rowl_range_ok(dc, qlen, tlen <= 256? 256 : tlen <= 512? 512 : 1024);
+	const bool rowl = row_kind && use_rowl && tlen > ROW_MAX_T && tlen <= ROWL_MAX_T && qlen <= ROWL_MAX_Q && rowl_range_ok(dc, qlen, tlen);
+	if (row || rowl) return (size_t)qlen * ((size_t)T + 16) + 16;
+	return ((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16;
+}
+
 // cigar_out -> dense CIGAR arena in *arena (pinned, owned by the caller's batch).
 int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t n, const uint8_t *d_q, const uint8_t *d_t, HBuf *arena,
                  const mm355_dpres_t **res_out, const uint32_t **cigar_out)

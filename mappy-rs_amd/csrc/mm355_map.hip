@@ -175,9 +175,13 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 	(void)hipMemGetInfo(&free_b, &total_b);
 	size_t budget = std::min<size_t>((size_t)24 << 30, free_b / 3);
 	if (budget < ((size_t)256 << 20)) budget = (size_t)256 << 20;
+	// what this context already holds for direction matrices costs nothing to use again: with six contexts' buffers resident the free
+	// third alone is below one round's matrices, and a round cut in two is two launch cycles (two turns, twice the tails)
+	if (c->dp_bt.cap > 64 && budget < c->dp_bt.cap - 64) budget = c->dp_bt.cap - 64;
 	const bool verbose = getenv("MM355_VERBOSE") != 0;
 	const int nt = host_threads();
 	std::vector<int64_t> qo, to;
+	const DpConst dpc = mm355_dp_const(mo);
 	size_t i = 0;
 	while (i < reqs.size()) {
 		const double tb0 = now_ms();
@@ -186,11 +190,7 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 		qo.clear(); to.clear();
 		for (; j < reqs.size(); ++j) {
 			const DpReq &q = reqs[j];
-			int w = q.w < 0? std::max(q.qlen, q.tlen) : q.w;
-			int n_col_ = std::min(q.qlen, q.tlen);
-			n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
-			size_t pb = q.qlen > 0 && q.tlen > 0? ((size_t)(q.qlen + q.tlen - 1) * n_col_ + 1) * 16 : 0;
-			if (mo->max_sw_mat > 0 && (int64_t)q.tlen * q.qlen > mo->max_sw_mat) pb = 0;
+			const size_t pb = mm355_dp_matrix_bytes(mo, dpc, q.qlen, q.tlen, q.w, q.flag);   // (as mm355_dp_run lays it out: row-major for the row sweep)
 			if (j > i && p_tot + pb > budget) break;
 			qo.push_back((int64_t)q_tot); to.push_back((int64_t)t_tot);
 			q_tot += (size_t)(q.qlen > 0? q.qlen : 0) + 16; t_tot += (size_t)(q.tlen > 0? q.tlen : 0) + 16; p_tot += pb;
