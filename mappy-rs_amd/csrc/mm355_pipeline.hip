@@ -422,9 +422,11 @@ int mm355_run_sort(mm355_ctx *c)
 		static const int force = [] { const char *e = getenv("MM355_FAST_SORT"); return e? atoi(e) : -1; }();
 		const bool fast = force >= 0? force != 0 : (n_reads > 0 && c->hb.tot_a / n_reads >= 2048);
 		std::vector<uint8_t> flag;
+		const double ts0 = mm355_now_ms();
 		if (fast) {
 			int rc = mm355_fast_sort(c, c->hb.tot_a, n_reads, flag);
 			if (rc) return rc;
+			mm355_trace_add(c, "s:fast", ts0, mm355_now_ms());
 			a.tcnt = c->v.as<int32_t>();   // the literal recursion skips buckets without equal keys (restored by mm355_fast_sort_fix)
 		}
 		// whole-array tasks of the reads that are sorted literally, by size class: 1024-thread levels, 256-thread levels, one wave
@@ -449,12 +451,17 @@ int mm355_run_sort(mm355_ctx *c)
 			}
 			// big tasks first in their list: the longest level walks start at t = 0
 			std::stable_sort(ht, ht + nb, [](const SortTask &x, const SortTask &y) { return x.end > y.end; });
+			const double ts1 = mm355_now_ms();
 			if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
+			mm355_trace_add(c, "s:levels", ts1, mm355_now_ms());
 			if (fast) { int rc = mm355_fast_sort_fix(c, n_reads); if (rc) return rc; }
 		}
 	}
 	HIPCHK(hipGetLastError());
-	return check_err(c);
+	const double ts2 = mm355_now_ms();
+	const int rce = check_err(c);
+	mm355_trace_add(c, "s:tail", ts2, mm355_now_ms());
+	return rce;
 }
 
 int mm355_run_chain(mm355_ctx *c, const DevParams &pr)

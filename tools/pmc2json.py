@@ -10,7 +10,7 @@ out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path
 WIDE_LOADS = ("k_seed_lookup",)
 # bench.py roofline names <- kernel name prefixes
 ALIAS = {"k_ksw_extd2<512> (targets 1025..4096)": "k_ksw_extd2<512>", "k_ksw_extd2<512> (targets > 4096)": "k_ksw_extd2<512>",
-         "k_ksw_rowl (targets 1025..8192)": "k_ksw_rowl", "k_ksw_regw (exact, band <= 832, targets > 1024)": "k_ksw_regw"}
+         "k_ksw_rowl (targets 1025..8192)": "k_ksw_rowl", "k_ksw_regw8 (exact, band <= 832, targets > 1024)": "k_ksw_regw8"}
 
 
 def load(fn):
