@@ -46,6 +46,7 @@ def _parse_args():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-pcie", "--no-resident", dest="no_pcie", action="store_true", help="skip the second timed region (PCIe-inclusive: mm355_map_batch on host buffers)")
     ap.add_argument("--pcie-steps", type=int, default=3, help="blocks of the second (PCIe-inclusive) timed region")
+    ap.add_argument("--synth-procs", type=int, default=0, help="worker processes that synthesise the reads (0 = automatic; 1 under a profiler)")
     ap.add_argument("--no-bin", action="store_true", help="deal the reads of a step to its sub-batches round-robin instead of by length")
     return ap.parse_args()
 
@@ -283,6 +284,12 @@ def main():
     g, names, gdesc, device_index = make_genome(wl["genome"], args.scale)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     procs = max(1, min(16, int((os.cpu_count() or 2) // max(1, local_world)) - 1))
+    # never fork under a profiler: its preloaded tool library may have initialised the GPU before this program started (rocprofv3 --pmc does),
+    # and a forked copy of such a process hangs on the device
+    if args.synth_procs > 0:
+        procs = args.synth_procs
+    elif any(k.startswith(("ROCP", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        procs = 1
     reads = shard_reads(wl, g, n_per_step * n_blocks, rank, world, procs)
 
     dist = None
@@ -544,6 +551,18 @@ def main():
             for ms in mappy_rs._batch_to_mappings(hp, len(sub), names):
                 gpu_sigs.append(None if isinstance(ms, Exception) else hash(tuple(tuple(getattr(m, k) for k in SIG_FIELDS) for m in ms)))
             L.mm355_free_hits(hp)
+            if lo == 0:   # this sub-batch had the GPU to itself: the seed-lookup kernel without other contexts' kernels in front of it on its queue
+                st1 = _ffi.Stats()
+                L.mm355_get_stats(ctxs[0], C.byref(st1))
+                if st1.ms_seed_lookup > 0:
+                    b1 = 16.0 * st1.n_mz + 16.0 * st1.n_hit
+                    a1 = b1 / (st1.ms_seed_lookup * 1e-3) / 1e9
+                    rl = out["roofline_seed_lookup"]
+                    rl["alone"] = dict(reads=len(sub), ms_per_launch=round(st1.ms_seed_lookup, 4), algorithmic_bytes=int(b1), achieved=round(a1, 1), frac=round(a1 / HBM_PEAK_GBS, 5),
+                                       lookups_per_s=round(st1.n_mz / (st1.ms_seed_lookup * 1e-3) / 1e9, 2), unit="GB/s; G lookups/s",
+                                       note="one sub-batch alone on the GPU (the parity sample), same kernel, HIP events on its stream")
+                    if rl.get("traffic"):
+                        rl["alone"]["traffic_gbs"] = round(rl["traffic"] * (st1.n_mz / max(1.0, out["counters_per_step"]["n_mz"] / n_str)) / (st1.ms_seed_lookup * 1e-3) / 1e9, 1)
     for ctx in ctxs:
         L.mm355_ctx_destroy(ctx)
     L.mm355_index_free(idx)
