@@ -68,7 +68,7 @@ void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, c
                          const int64_t *read_chunk0, int32_t *chunk_n, hipStream_t st);
 void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
 void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
-                              unsigned long long *hit_ctr, hipStream_t st);
+                              unsigned long long *hit_ctr, unsigned int *tile_ctr, hipStream_t st);
 void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
 void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st);
 struct SortTask { int32_t read; uint32_t beg, end; int32_t s; };   // a bucket [beg, end) of one read's array, to be sorted from byte shift s

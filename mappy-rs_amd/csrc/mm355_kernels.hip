@@ -168,59 +168,116 @@ __global__ __launch_bounds__(WAVE) void k_mzflt(DevParams pr, DevBatch bt, DevSe
 // (tools/ubench/linebench.hip, profiles/r03_random_line_roof.json): 5.9 TB/s of uniformly random 128-byte lines out of 16 GB = 46 G lookups/s;
 // 64-byte buckets are served at the same request rate (3.1 TB/s), so a narrower bucket would not buy lookups.
 #define LK_PER_GROUP (SK_CHUNK / 32)
-#define LK_TILES 4
-__global__ __launch_bounds__(256) void k_seed_lookup(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, unsigned long long *hit_ctr)
+// the table entries that hold minimizers: entry (read, start) is live when start < n_mz[read]; four fifths are not (a read has ~0.19
+// minimizers per base).  A live entry becomes a 16-byte tile descriptor {read offset, start, n_mz}; one atomic per 1024 entries (a single
+// word takes ~88 atomics per microsecond); the order of the list does not matter.
+__global__ __launch_bounds__(1024) void k_lookup_tiles(DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int4 *tiles, unsigned int *n_tiles)
+{
+	__shared__ unsigned int s_cnt[16], s_base;
+	const int ck = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	int r = 0, s0 = 0, n = 0;
+	if (ck < n_chunks) { r = chunk_read[ck]; s0 = chunk_start[ck]; n = sd.n_mz[r]; }
+	const bool live = s0 < n;
+	const unsigned long long m = __ballot(live);
+	if (lane == 0) s_cnt[w] = (unsigned int)__popcll(m);
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned int tot = 0;
+		for (int i = 0; i < 16; ++i) { const unsigned int c = s_cnt[i]; s_cnt[i] = tot; tot += c; }
+		s_base = tot? atomicAdd(n_tiles, tot) : 0;
+	}
+	__syncthreads();
+	if (live) {
+		const int64_t off = bt.roff[r];
+		tiles[s_base + s_cnt[w] + __popcll(m & LANE_LT_MASK(lane))] = make_int4((int)(uint32_t)off, (int)(off >> 32), s0, n);
+	}
+}
+
+typedef unsigned int lk_u32x4 __attribute__((ext_vector_type(4)));   // one 16-byte slot as ONE load: as a struct of four words the compiler
+                                                                      // sinks the value half into the match branch -- a second round trip
+struct LkTile { int64_t off; int32_t s0, n; uint64_t minier[LK_PER_GROUP]; };
+__device__ __forceinline__ void lk_fetch_tile(LkTile &T, const DevSeeds &sd, const int4 d, int grp)
+{
+	T.off = (int64_t)((uint64_t)(uint32_t)d.x | (uint64_t)(uint32_t)d.y << 32); T.s0 = d.z; T.n = d.w;
+	const mm128 *mz = sd.mz + T.off;
+#pragma unroll
+	for (int u = 0; u < LK_PER_GROUP; ++u) {
+		const int j = T.s0 + u * 32 + grp;
+		T.minier[u] = mz[j < T.n? j : T.n - 1].x;             // unconditional (a branch here costs a full wait per load); a live tile has s0 < n;
+		                                                      // the raw word: nothing here may wait for the load
+	}
+}
+
+// one probe of slot u's line: true when the line was full without the key (the caller reads the next line)
+__device__ __forceinline__ bool lk_probe(const DevSeeds &sd, const LkTile &cu, int u, int grp, int sl, int gsh, const lk_u32x4 raw, unsigned int &hits)
+{
+	const int j = cu.s0 + u * 32 + grp;
+	const bool live = cu.minier[u] != ~0ULL;
+	const uint64_t key = (uint64_t)raw.y << 32 | raw.x, v = (uint64_t)raw.w << 32 | raw.z;
+	const bool match = live && (key >> 1) == cu.minier[u] && key != UINT64_MAX;
+	const bool empty = key == UINT64_MAX;
+	const unsigned int mm = (unsigned int)(__ballot(match) >> gsh) & 0xffu, em = (unsigned int)(__ballot(empty) >> gsh) & 0xffu;
+	if (match) {
+		uint32_t cnt; uint64_t val;
+		if (key & 1) cnt = 1, val = v;
+		else cnt = (uint32_t)v, val = v >> 32;
+		sd.sn[cu.off + j] = cnt; sd.sv[cu.off + j] = val;
+		++hits;
+	}
+	if (mm) return false;
+	if (em || !live) {
+		if (live && sl == 0) { sd.sn[cu.off + j] = 0; sd.sv[cu.off + j] = 0; }
+		return false;
+	}
+	return true;
+}
+
+// Persistent form: a block walks the live tiles b, b + G, b + 2G ...  Three tiles are in flight per block: the table lines of tile t, the
+// minimizers of tile t + G and the descriptor of tile t + 2G, each a single round trip issued behind the older ones (the vector memory
+// counter is in order, so waiting for the line fetches leaves the younger loads in flight).
+__global__ __launch_bounds__(256) void k_seed_lookup(DevIndex ix, DevBatch bt, DevSeeds sd, const int4 *__restrict__ tiles, const unsigned int *__restrict__ n_tiles, unsigned long long *hit_ctr)
 {
 	const int grp = threadIdx.x >> 3, sl = threadIdx.x & 7;          // 32 groups of 8 lanes per block; lane sl owns slot sl of the line
 	const int gsh = (threadIdx.x & 63) & ~7;                          // bit position of this group's 8 lanes in a wave ballot
+	const int n_act = (int)*n_tiles, G = gridDim.x;
 	unsigned int hits = 0;
-	// LK_TILES table entries per block: four fifths of the entries are empty (a read has ~0.19 minimizers per base), and an empty block still
-	// costs its dispatch
-	for (int e = 0; e < LK_TILES; ++e) {
-	const int ck = (int)blockIdx.x * LK_TILES + e;
-	if (ck >= n_chunks) break;
-	const int r = chunk_read[ck], s0 = chunk_start[ck];
-	const int n = sd.n_mz[r];
-	if (s0 >= n) continue;
-	const int64_t off = bt.roff[r];
-	const mm128 *mz = sd.mz + off;
-	uint64_t minier[LK_PER_GROUP], line[LK_PER_GROUP]; uint4 raw[LK_PER_GROUP]; bool live[LK_PER_GROUP];
+	int t = blockIdx.x;
+	if (t >= n_act) return;                                           // (no barrier below is reached by part of a block: t is uniform)
+	LkTile nx;
+	lk_fetch_tile(nx, sd, tiles[t], grp);
+	int4 dn = tiles[min(t + G, n_act - 1)];
+	while (t < n_act) {
+		LkTile cu = nx;
+		uint64_t line[LK_PER_GROUP]; lk_u32x4 raw[LK_PER_GROUP];
 #pragma unroll
-	for (int u = 0; u < LK_PER_GROUP; ++u) {
-		const int j = s0 + u * 32 + grp;
-		live[u] = j < n && u * 32 + grp < SK_CHUNK;
-		minier[u] = live[u]? mz[j].x >> 8 : 0;
-		line[u] = mm_table_hash(minier[u]) & ix.line_mask;
-	}
-#pragma unroll
-	for (int u = 0; u < LK_PER_GROUP; ++u)                            // every line fetch of the group issued back to back
-		raw[u] = live[u]? *(const uint4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl) : make_uint4(~0u, ~0u, 0, 0);
-#pragma unroll
-	for (int u = 0; u < LK_PER_GROUP; ++u) {
-		const int j = s0 + u * 32 + grp;
-		for (;;) {                                                    // uniform per group; groups of a wave only diverge on a full line
-			const uint64_t key = (uint64_t)raw[u].y << 32 | raw[u].x, v = (uint64_t)raw[u].w << 32 | raw[u].z;
-			const bool match = live[u] && (key >> 1) == minier[u] && key != UINT64_MAX;
-			const bool empty = key == UINT64_MAX;
-			const unsigned int mm = (unsigned int)(__ballot(match) >> gsh) & 0xffu, em = (unsigned int)(__ballot(empty) >> gsh) & 0xffu;
-			if (mm) {
-				if (match) {
-					uint32_t cnt; uint64_t val;
-					if (key & 1) cnt = 1, val = v;
-					else cnt = (uint32_t)v, val = v >> 32;
-					sd.sn[off + j] = cnt; sd.sv[off + j] = val;
-					++hits;
-				}
-				break;
-			}
-			if (em || !live[u]) {
-				if (live[u] && sl == 0) { sd.sn[off + j] = 0; sd.sv[off + j] = 0; }
-				break;
-			}
-			line[u] = (line[u] + 1) & ix.line_mask;                   // full line without the key: probe the next one
-			raw[u] = *(const uint4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl);
+		for (int u = 0; u < LK_PER_GROUP; ++u) {
+			const bool in = cu.s0 + u * 32 + grp < cu.n;
+			const uint64_t h = mm_table_hash(cu.minier[u] >> 8) & ix.line_mask;
+			cu.minier[u] = in? cu.minier[u] >> 8 : ~0ULL;             // ~0: no minimizer in this slot
+			line[u] = in? h : 0;                                      // (slots past the end read line 0: cached)
 		}
-	}
+#pragma unroll
+		for (int u = 0; u < LK_PER_GROUP; ++u)                        // every line fetch of the group issued back to back, no branch between them
+			raw[u] = *(const lk_u32x4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl);
+		t += G;
+		lk_fetch_tile(nx, sd, dn, grp);                               // behind the line fetches in the memory queue; unconditional, so that the
+		dn = tiles[min(t + G, n_act - 1)];                            // waits below are by count (past the end: the last tile again, unused)
+		unsigned int pend = 0;                                        // bit u: the first line was full and did not hold the key
+#pragma unroll
+		for (int u = 0; u < LK_PER_GROUP; ++u)                        // first probe: straight-line code, so that each line is waited for by count
+			pend |= (unsigned int)lk_probe(sd, cu, u, grp, sl, gsh, raw[u], hits) << u;
+		if (__ballot(pend != 0) != 0) {                               // rare (a table at most 55 % full): the groups concerned walk on alone
+#pragma unroll
+			for (int u = 0; u < LK_PER_GROUP; ++u) {
+				bool more = pend >> u & 1;
+				while (__ballot(more) != 0) {
+					if (more) line[u] = (line[u] + 1) & ix.line_mask;
+					const lk_u32x4 r2 = *(const lk_u32x4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl);
+					const bool again = lk_probe(sd, cu, u, grp, sl, gsh, r2, hits);
+					more = more && again;
+				}
+			}
+		}
 	}
 	// one atomic per block, spread over 64 words (one word takes ~88 atomics per microsecond)
 	__shared__ unsigned int s_hits[4];
@@ -1063,10 +1120,15 @@ void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, h
 	hipLaunchKernelGGL(k_mzflt, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, sd);
 }
 void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
-                              unsigned long long *hit_ctr, hipStream_t st)
+                              unsigned long long *hit_ctr, unsigned int *tile_ctr, hipStream_t st)
 {
 	if (bt.n_reads == 0 || n_chunks == 0) return;
-	hipLaunchKernelGGL(k_seed_lookup, dim3((n_chunks + LK_TILES - 1) / LK_TILES), dim3(256), 0, st, ix, bt, sd, chunk_read, chunk_start, n_chunks, hit_ctr);
+	int4 *tiles = (int4*)sd.hl;   // (the hit list of k_seed_select: free until then; 4 bytes per minimizer slot >= 16 per 384-slot table entry)
+	(void)hipMemsetAsync(tile_ctr, 0, 4, st);
+	hipLaunchKernelGGL(k_lookup_tiles, dim3((n_chunks + 1023) / 1024), dim3(1024), 0, st, bt, sd, chunk_read, chunk_start, n_chunks, tiles, tile_ctr);
+	static const int lk_grid = []{ const char *e = getenv("MM355_LK_GRID"); return e && atoi(e) > 0? atoi(e) : 2048; }();
+	const int grid = n_chunks < lk_grid? n_chunks : lk_grid;   // resident blocks walk the live tiles
+	hipLaunchKernelGGL(k_seed_lookup, dim3(grid), dim3(256), 0, st, ix, bt, sd, (const int4*)tiles, (const unsigned int*)tile_ctr, hit_ctr);
 }
 void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
 {

@@ -51,7 +51,7 @@ struct HostBatch {            // packed reads of one sub-batch
 struct ResidentBatch { HostBatch hb; DBuf seq, roff, rlen, order, ck_read, ck_start, ck_r0; int64_t n_chunks = 0; };
 
 // Layout of mm355_ctx::counters (u64 words), one definition for every memset / kernel argument / read-back:
-//   [0..7]    seed stage (n_hit, n_a_multi, ...), the extension's total cells (4) and dense-arena pointer (5), k_chain_segments' two list lengths (6)
+//   [0..7]    seed stage (n_a_multi (1), live lookup tiles (2)), the extension's total cells (4) and dense-arena pointer (5), k_chain_segments' two list lengths (6)
 //   CTR_GCELLS_OFF   cells per extension launch group, [CTR_GROUPS][CTR_SPREAD] (slot = block & (CTR_SPREAD - 1): one word takes ~88 atomics / us)
 //   CTR_PAIRS_OFF    chaining pair evaluations, CTR_PAIRS_WORDS slots (slot = block & 63)
 //   CTR_RMQ_OFF      window elements looked at by k_rmq_dp, CTR_RMQ_WORDS slots

@@ -352,7 +352,7 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 	HostBatch &hb = c->hb;
 	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_mzflt(pr, b, s, c->st); }
 	{ EvTimer t(c, &c->stats.ms_seed_lookup); mm355_launch_seed_lookup(c->dix, b, s, c->ck_read.as<int32_t>(), c->ck_start.as<int32_t>(), (int)c->n_chunks,
-	                                                                   c->counters.as<unsigned long long>() + CTR_HITS_OFF, c->st); }
+	                                                                   c->counters.as<unsigned long long>() + CTR_HITS_OFF, (unsigned int*)(c->counters.as<unsigned long long>() + 2), c->st); }
 	++c->stats.n_launch_seed;
 	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_seed_select(c->dix, pr, b, s, c->st); }
 	HIPCHK(hipGetLastError());
