@@ -209,10 +209,10 @@ __device__ __forceinline__ void lk_fetch_tile(LkTile &T, const DevSeeds &sd, con
 }
 
 // one probe of slot u's line: true when the line was full without the key (the caller reads the next line)
-__device__ __forceinline__ bool lk_probe(const DevSeeds &sd, const LkTile &cu, int u, int grp, int sl, int gsh, const lk_u32x4 raw, unsigned int &hits)
+__device__ __forceinline__ bool lk_probe(const DevSeeds &sd, const LkTile &cu, int u, int grp, int sl, int gsh, const lk_u32x4 raw, unsigned int &hits, bool act = true)
 {
 	const int j = cu.s0 + u * 32 + grp;
-	const bool live = cu.minier[u] != ~0ULL;
+	const bool live = act && cu.minier[u] != ~0ULL;        // (act: the groups of a wave that are not walking on must not count or store twice)
 	const uint64_t key = (uint64_t)raw.y << 32 | raw.x, v = (uint64_t)raw.w << 32 | raw.z;
 	const bool match = live && (key >> 1) == cu.minier[u] && key != UINT64_MAX;
 	const bool empty = key == UINT64_MAX;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_seed_lookup(DevIndex ix, DevBatch bt, D
 				while (__ballot(more) != 0) {
 					if (more) line[u] = (line[u] + 1) & ix.line_mask;
 					const lk_u32x4 r2 = *(const lk_u32x4*)(ix.slots + line[u] * MM355_SLOTS_PER_LINE + sl);
-					const bool again = lk_probe(sd, cu, u, grp, sl, gsh, r2, hits);
+					const bool again = lk_probe(sd, cu, u, grp, sl, gsh, r2, hits, more);
 					more = more && again;
 				}
 			}
