@@ -515,6 +515,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	static const bool use_row = [] { const char *e = getenv("MM355_DP_ROW"); return !legacy && !(e && atoi(e) == 0); }();   // MM355_DP_ROW=0: anti-diagonal kernels only
 	static const bool use_rowl = [] { const char *e = getenv("MM355_DP_ROWL"); return !(e && atoi(e) == 0); }();                           // MM355_DP_ROWL=0: no eight-wave row sweep
 	static const bool use_regw = [] { const char *e = getenv("MM355_DP_REGW"); return !legacy && !(e && atoi(e) == 0); }();               // MM355_DP_REGW=0: no windowed register kernel
+	static const bool regw8 = [] { const char *e = getenv("MM355_DP_REGW8"); return !(e && atoi(e) == 0); }();                             // MM355_DP_REGW8=0: the single-wave kernel of round 2 (same results)
+	size_t regw_seq = 0;                       // LDS bytes of the longest (query, target) pair of the eight-wave kernel in this round
 	const DpClass *classes = legacy? DP_CLASSES_LEGACY : DP_CLASSES;
 	// lay out per-job work areas; group = size class * 2 + exact
 	size_t p_tot = 0, off_tot = 0, cig_tot = 0, st_tot = 0;
@@ -553,7 +555,11 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 				p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
 				int cls = 0;
 				while (cls < DP_N_CLASS - 1 && T > classes[cls].cap) ++cls;
-				if (use_regw && T > 1024 && !(j.flag & EZ_APPROX_MAX) && w <= DP_WIN_MAX_W) g = DP_G_REGW;
+				if (use_regw && T > 1024 && !(j.flag & EZ_APPROX_MAX) && w <= DP_WIN_MAX_W && (!regw8 || ((j.qlen + 15) & ~15) + T <= MW_SEQ_MAX)) {
+					g = DP_G_REGW;
+					const size_t sb = (size_t)((j.qlen + 15) & ~15) + (size_t)T;
+					if (sb > regw_seq) regw_seq = sb;
+				}
 				else {
 					if (cls == DP_N_CLASS - 1) { j.st_off = (int64_t)st_tot; st_tot += T; }
 					g = cls * 2 + ((j.flag & EZ_APPROX_MAX)? 0 : 1);
@@ -672,9 +678,10 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		hipStream_t gst; int rc2;
 		if ((rc2 = group_stream(7, &gst))) return rc2;
 		if ((rc2 = group_begin(DP_G_REGW, gst))) return rc2;
-		// eight waves per alignment (mm355_dpmw.h); MM355_DP_REGW8=0: the single-wave kernel of round 2 (same results)
-		static const bool regw8 = [] { const char *e = getenv("MM355_DP_REGW8"); return !(e && atoi(e) == 0); }();
-		if (regw8) hipLaunchKernelGGL(k_ksw_regw8, dim3((unsigned)n_grp[DP_G_REGW]), dim3(64 * MW_WAVES), 0, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
+		// eight waves per alignment (mm355_dpmw.h), the sequences of a block in (dynamic) LDS
+		static const hipError_t lds_attr = hipFuncSetAttribute((const void*)k_ksw_regw8, hipFuncAttributeMaxDynamicSharedMemorySize, MW_SEQ_MAX + 64);
+		if (lds_attr != hipSuccess) return MM355_EHIP;
+		if (regw8) hipLaunchKernelGGL(k_ksw_regw8, dim3((unsigned)n_grp[DP_G_REGW]), dim3(MW_THREADS), regw_seq + 64, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
 		                              c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * DP_G_REGW);
 		else hipLaunchKernelGGL(k_ksw_regw, dim3((unsigned)n_grp[DP_G_REGW]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
 		                        c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * DP_G_REGW);
