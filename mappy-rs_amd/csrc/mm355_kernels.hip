@@ -54,21 +54,43 @@ __global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSe
 	chunk_n[t] = sketch_chunk(bt.seq + off, len, ix.w, ix.k, cs, ce, sd.mz + off + cs, ring + threadIdx.x, WAVE);
 }
 
-// Small batches (a single read is ~20 chunks): one chunk per WAVE, lane 0 only.  With a lane per chunk the wave executes the union
-// of every lane's branches -- both ring rescans on almost every base -- which is what a full grid amortises and a 20-chunk grid
-// does not: alone in its wave a chunk only pays for the rescans it needs (~5x shorter latency), and the chunks spread over the CUs.
-__global__ __launch_bounds__(WAVE) void k_sketch_sparse(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
+// Small batches (a single read is ~20 chunks): lane 0 of a wave alone.  With a lane per chunk the wave executes the union of every lane's
+// branches -- both ring rescans on almost every base -- which is what a full grid amortises and a 20-chunk grid does not.  A chunk is cut
+// once more, into SKS_WAVES pieces of SK_CHUNK / SKS_WAVES bases with a wave each (a piece pays the ~95-base warm-up of the exactness
+// proof again: 64 + 95 base steps on the critical path instead of 384 + 95); the pieces write at their own offsets of the chunk's slot
+// range and wave 0 then packs them to its front, so the chunk looks as if one lane had done it.
+#define SKS_WAVES 6
+#define SKS_PIECE (SK_CHUNK / SKS_WAVES)
+__global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
 {
 	MM355_LATENCY_KERNEL();
-	extern __shared__ mm128 ring[];
-	const int t = blockIdx.x;
-	if (t >= n_chunks || threadIdx.x != 0) return;
+	extern __shared__ mm128 ring[];              // w entries per wave
+	__shared__ int s_n[SKS_WAVES];
+	const int t = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (t >= n_chunks) return;
 	const int r = chunk_read[t], cs = chunk_start[t];
 	const int len = bt.rlen[r];
 	const int64_t off = bt.roff[r];
 	int ce = cs + SK_CHUNK;
 	if (ce > len) ce = len;
-	chunk_n[t] = sketch_chunk(bt.seq + off, len, ix.w, ix.k, cs, ce, sd.mz + off + cs, ring, 1);
+	if (lane == 0) {
+		const int ps = cs + wv * SKS_PIECE;
+		int pe = ps + SKS_PIECE;
+		if (pe > ce) pe = ce;
+		s_n[wv] = ps < pe? sketch_chunk(bt.seq + off, len, ix.w, ix.k, ps, pe, sd.mz + off + ps, ring + wv * ix.w, 1) : 0;
+	}
+	__syncthreads();
+	if (wv != 0) return;
+	mm128 *mz = sd.mz + off + cs;
+	int m = s_n[0];
+	for (int k = 1; k < SKS_WAVES; ++k) {        // a piece holds at most SKS_PIECE = 64 minimizers: one wave-wide move, source read before the write
+		const int n = s_n[k];
+		mm128 v; v.x = v.y = 0;
+		if (lane < n) v = mz[k * SKS_PIECE + lane];
+		if (lane < n && m != k * SKS_PIECE) mz[m + lane] = v;
+		m += n;
+	}
+	if (lane == 0) chunk_n[t] = m;
 }
 
 // packs the per-chunk outputs of a read to the front of its slot range (in place; destination never passes the source)
@@ -1105,7 +1127,7 @@ void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, c
 		const char *e = getenv("MM355_SKETCH_SPARSE_MAX");   // read per launch: the parity tests force either form
 		const int sparse_max = e? atoi(e) : 2048;             // chunks
 		if (n_chunks <= sparse_max) {
-			hipLaunchKernelGGL(k_sketch_sparse, dim3(n_chunks), dim3(WAVE), (size_t)ix.w * sizeof(mm128), st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+			hipLaunchKernelGGL(k_sketch_sparse, dim3(n_chunks), dim3(WAVE * SKS_WAVES), (size_t)ix.w * SKS_WAVES * sizeof(mm128), st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
 		} else {
 			int blocks = (n_chunks + WAVE - 1) / WAVE;
 			size_t lds = (size_t)ix.w * WAVE * sizeof(mm128);
