@@ -679,8 +679,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		if ((rc2 = group_stream(7, &gst))) return rc2;
 		if ((rc2 = group_begin(DP_G_REGW, gst))) return rc2;
 		// eight waves per alignment (mm355_dpmw.h), the sequences of a block in (dynamic) LDS
-		static const hipError_t lds_attr = hipFuncSetAttribute((const void*)k_ksw_regw8, hipFuncAttributeMaxDynamicSharedMemorySize, MW_SEQ_MAX + 64);
-		if (lds_attr != hipSuccess) return MM355_EHIP;
+		// (per launch, not once per process: the attribute belongs to the function on the CURRENT device, and one process may drive several)
+		if (regw8 && regw_seq + 64 > 32768 && hipFuncSetAttribute((const void*)k_ksw_regw8, hipFuncAttributeMaxDynamicSharedMemorySize, MW_SEQ_MAX + 64) != hipSuccess) return MM355_EHIP;
 		if (regw8) hipLaunchKernelGGL(k_ksw_regw8, dim3((unsigned)n_grp[DP_G_REGW]), dim3(MW_THREADS), regw_seq + 64, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,
 		                              c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * DP_G_REGW);
 		else hipLaunchKernelGGL(k_ksw_regw, dim3((unsigned)n_grp[DP_G_REGW]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[DP_G_REGW], (int)n_grp[DP_G_REGW], d_q, d_t,

@@ -379,6 +379,12 @@ def test_dp_kernel_parity(ont):
             q[len(q) // 2:len(q) // 2 + 3] = 4; t[tl // 2 + 100:tl // 2 + 102] = 4
         flag, w, zd = [(EXTZ, 751, 400), (EXTZ | RIGHT | REV, 751, 200), (0, 832, 400), (RIGHT, 300, 400), (EXTZ, 16, 100), (0, 751, 10000)][i % 6]
         jobs.append((len(q), tl, w, zd, -1 if i % 4 else 10, flag)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
+    # ... and two whose query + target need more than 64 KB of LDS (the eight-wave kernel stages both sequences there: dynamic LDS beyond the
+    # default limit, opted into per launch); qlen * tlen stays below max_sw_mat (beyond it the stage answers "z-dropped" without aligning)
+    for tl, fl in ((65000, EXTZ), (64800, EXTZ | RIGHT | REV)):
+        t = S.random_codes(rng, tl)
+        q = S.mutate(t[:1450], rng, 0.05, 0.03, 0.03)[:1500]
+        jobs.append((len(q), tl, 751, 100000, -1, fl)); qs.append(q.astype(np.uint8)); ts.append(t.astype(np.uint8))
     # paths along the matrix border and along the band edge while the band spans five or more 128-cell blocks (the catch-all instance
     # of the register kernels): a global alignment that opens with a 560-base deletion runs through the top-row cells t = r >= 512, whose
     # y / u are boundary values; one that opens with a (w - 1)-base insertion rides the lower band edge, where x[st - 1] / v[st - 1] are
