@@ -1,4 +1,4 @@
-"""throughput of the drop-in surface itself (Aligner.map_batch, Python Mapping objects included): python tools/mapbatch_bench.py [reads=32768] [threads=8]"""
+"""throughput of the drop-in surface itself (Aligner.map_batch, Python Mapping objects included): python tools/mapbatch_bench.py [reads=32768] [threads=8] [result channel capacity]"""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "mappy-rs_amd"))
@@ -6,6 +6,7 @@ import synthdata as S
 import mappy_rs
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 thr = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+if len(sys.argv) > 3: mappy_rs.RESULT_CHANNEL_CAP = int(sys.argv[3])      # (experiments: the reference's bounded(20000) result channel)
 g = S.ecoli_like(1); S.write_fasta("/tmp/mb.fa", g)
 reads, _ = S.make_reads(2, g, n, n50=8000)
 al = mappy_rs.Aligner("/tmp/mb.fa", preset="map-ont")
