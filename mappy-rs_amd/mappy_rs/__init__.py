@@ -204,7 +204,7 @@ def order_by_length(lengths):
 
 
 class _Channel:
-    """bounded multi-producer channel (crossbeam `bounded(20000)`, lib.rs:950): producers block while it is full, the consumer blocks
+    """bounded multi-producer channel (the reference's ArrayQueue(50000) + crossbeam `bounded(20000)`, lib.rs:430, 950): producers block while it is full, the consumer blocks
     while it is empty; both waits release the GIL."""
 
     def __init__(self, cap):
@@ -276,7 +276,7 @@ class _BatchState:
 class AlignmentBatchResultIter:
     """Iterator returned by map_batch (lib.rs:923-991): yields (list[Mapping], dict) in COMPLETION order.
 
-    Mirrors the reference's plumbing: workers push results into a bounded channel (20 000 entries, lib.rs:950) and `__next__`
+    Mirrors the reference's plumbing: workers push results into a bounded channel (RESULT_CHANNEL_CAP entries, lib.rs:430 + 950) and `__next__`
     blocks on it (`rx.recv()`, lib.rs:973) -- here with the GIL released.  A full channel blocks the workers: a slow consumer holds
     back the GPU pipeline instead of growing memory (back-pressure).  `Finished` arrives after every worker is done (lib.rs:804-815)."""
 
