@@ -77,43 +77,12 @@ __device__ __forceinline__ uint32_t row_scan(const uint32_t A, int32_t &C, const
 	return (uint32_t)((ex - sub) & 0xffff) | (uint32_t)(hi - sub) << 16;
 }
 
-// The same for BOTH gap pieces at once: the lane maxima of the two sequences ride in the two int16 halves of one register through the six
-// scan steps (v_mov_b32 dpp + v_pk_max_i16 per step for both, instead of one v_max_i32 dpp chain per piece: 27 VALU per set instead of 48).
-// Cp = carry (piece 1 | piece 2 << 16), the same in every lane.  Out: E1 and E2 of the lane's two cells, minus sub1 / sub2 (packed constants).
-#define ROW_PKNEG 0x80008000u
-__device__ __forceinline__ uint32_t pk_scan_step(const uint32_t x, const int ctrl_sel)
-{
-	uint32_t y;
-	switch (ctrl_sel) {
-	case 0: y = (uint32_t)__builtin_amdgcn_update_dpp((int)ROW_PKNEG, (int)x, 0x111, 0xf, 0xf, false); break;
-	case 1: y = (uint32_t)__builtin_amdgcn_update_dpp((int)ROW_PKNEG, (int)x, 0x112, 0xf, 0xf, false); break;
-	case 2: y = (uint32_t)__builtin_amdgcn_update_dpp((int)ROW_PKNEG, (int)x, 0x114, 0xf, 0xf, false); break;
-	case 3: y = (uint32_t)__builtin_amdgcn_update_dpp((int)ROW_PKNEG, (int)x, 0x118, 0xf, 0xf, false); break;
-	case 4: y = (uint32_t)__builtin_amdgcn_update_dpp((int)ROW_PKNEG, (int)x, 0x142, 0xa, 0xf, false); break;
-	default: y = (uint32_t)__builtin_amdgcn_update_dpp((int)ROW_PKNEG, (int)x, 0x143, 0xc, 0xf, false); break;
-	}
-	return pk_max(x, y);
-}
-__device__ __forceinline__ void row_scan2(const uint32_t A1, const uint32_t A2, uint32_t &Cp, const uint32_t sub1, const uint32_t sub2, uint32_t &E1, uint32_t &E2)
-{
-	uint32_t P = bfi(0xffffu, pk_max_swap(A1), pk_max_swap(A2));          // lo: max of the lane's two cells of piece 1, hi: of piece 2
-	P = pk_scan_step(P, 0); P = pk_scan_step(P, 1); P = pk_scan_step(P, 2); P = pk_scan_step(P, 3); P = pk_scan_step(P, 4); P = pk_scan_step(P, 5);
-	uint32_t EX = (uint32_t)__builtin_amdgcn_update_dpp((int)Cp, (int)P, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 <- carry
-	EX = pk_max(EX, Cp);
-	const uint32_t X1 = __builtin_amdgcn_perm(EX, EX, 0x01000100), X2 = __builtin_amdgcn_perm(EX, EX, 0x03020302);   // the exclusive prefix in both halves
-	// the lane's second cell also sees its first one: (lo: -32768, hi: A.lo)
-	const uint32_t V1 = __builtin_amdgcn_perm(A1, ROW_PKNEG, 0x05040100), V2 = __builtin_amdgcn_perm(A2, ROW_PKNEG, 0x05040100);
-	E1 = pk_sub(pk_max(X1, V1), sub1); E2 = pk_sub(pk_max(X2, V2), sub2);
-	const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)P, 63);
-	Cp = pk_max(Cp, tot);
-}
-
 // one register set (128 target cells) of one row: in: the row above (Hp, Fp, F2p), the cell to the left of the set's first cell in the row
 // above (hi half of carry_h), the prefix maxima of everything to the left in this row (C1, C2); out: this row's H / F / F2 in their place,
 // carries for the next set, the direction bytes of the two cells of this lane at pcell
 template <bool RIGHT>
 __device__ __forceinline__ void row_set(const RowK &K, const uint32_t dmis, const bool any_n, const uint32_t qc2, uint32_t &Hp, uint32_t &Fp, uint32_t &F2p,
-                                        const uint32_t TQ, const uint32_t KE1, const uint32_t KE2, uint32_t &carry_h, uint32_t &Cp, uint8_t *pcell, const bool store)
+                                        const uint32_t TQ, const uint32_t KE1, const uint32_t KE2, uint32_t &carry_h, int32_t &C1, int32_t &C2, uint8_t *pcell, const bool store)
 {
 	// H(t-1, q-1): the row above, shifted one cell to the right
 	const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_h, (int)Hp, 0x138, 0xf, 0xf, false);
@@ -127,9 +96,8 @@ __device__ __forceinline__ void row_set(const RowK &K, const uint32_t dmis, cons
 	const uint32_t F2 = pk_max(pk_sub_s(Hp, K.qe2), pk_sub_s(F2p, K.e2));
 	const uint32_t G = pk_max(pk_max(M, F), F2);
 	// E(t) = max_{k<t} (G(k) + k e) - (q + e) - (t - 1) e = [prefix - q] - t e
-	uint32_t E, E2;
-	row_scan2(pk_add(G, KE1), pk_add(G, KE2), Cp, K.q1, K.q2, E, E2);
-	E = pk_sub(E, KE1); E2 = pk_sub(E2, KE2);
+	const uint32_t E = pk_sub(row_scan(pk_add(G, KE1), C1, K.q1i), KE1);
+	const uint32_t E2 = pk_sub(row_scan(pk_add(G, KE2), C2, K.q2i), KE2);
 	const uint32_t H = pk_max(pk_max(G, E), E2);
 	// direction byte
 	const uint32_t n1 = pk_minu_s(pk_sub(H, E), K.one), n2 = pk_minu_s(pk_sub(H, F), K.one), n3 = pk_minu_s(pk_sub(H, E2), K.one);
@@ -184,12 +152,12 @@ __device__ __forceinline__ void row_sweep(const DpConst &dc, const RowK &K, cons
 		if ((q & 63) == 0) qv = q + lane < qlen? query[q + lane] : 0;
 		const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
 		const uint32_t qc2 = qc | qc << 16;
-		uint32_t Cp = vreg_const(pk2(hl - dc.e, hl - dc.e2));   // the k = -1 term of both prefix maxima: a gap opened at the left border
+		int32_t C1 = hl - dc.e, C2 = hl - dc.e2;       // the k = -1 term of both prefix maxima: a gap opened at the left border
 		uint32_t carry_h = pk2(0, hl_prev);            // (hi half) H of the row above, one cell to the left of this set's first cell
 #pragma unroll
 		for (int k = 0; k < NS; ++k) {
 			if (128 * k >= tlen) break;                // (wave-uniform) sets beyond the target
-			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], carry_h, Cp, prow + 128 * k, 128 * k + 2 * lane < tlen);
+			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], carry_h, C1, C2, prow + 128 * k, 128 * k + 2 * lane < tlen);
 		}
 		prow += tstride;
 		hl_prev = hl;
@@ -286,15 +254,12 @@ __device__ __forceinline__ void rowl_panel(const DpConst &dc, const RowK &K, con
 		if (pw == 0) { hl_cur = row_hb(q, dc); C1 = hl_cur - dc.e; C2 = hl_cur - dc.e2; }      // the k = -1 term: a gap opened at the left border
 		else { C1 = __builtin_amdgcn_readlane(vC1, q & 63); C2 = __builtin_amdgcn_readlane(vC2, q & 63); hl_cur = __builtin_amdgcn_readlane(vH, q & 63); }
 		uint32_t carry_h = pk2(0, hl_prev);
-		uint32_t Cp = vreg_const(pk2(C1, C2));
 #pragma unroll
 		for (int k = 0; k < ROWL_NS; ++k) {
 			if (tb + 128 * k >= tlen) break;            // (wave-uniform) sets beyond the target
-			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], carry_h, Cp, prow + 128 * k, tb + 128 * k + 2 * lane < tlen);
+			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], carry_h, C1, C2, prow + 128 * k, tb + 128 * k + 2 * lane < tlen);
 		}
 		if (!last) {
-			const uint32_t cpu = (uint32_t)__builtin_amdgcn_readfirstlane((int)Cp);
-			C1 = (int32_t)(int16_t)(cpu & 0xffff); C2 = (int32_t)(int16_t)(cpu >> 16);
 			const int32_t he = (int32_t)__builtin_amdgcn_readlane((int)Hp[ROWL_NS - 1], 63) >> 16;     // H(tb + 511, q)
 			if (lane == 0) { colC1[q] = C1; colC2[q] = C2; colH[q] = he; }
 			if ((q & 63) == 63 || q == qlen - 1) __hip_atomic_store(&done[pw], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
