@@ -288,3 +288,32 @@ def test_mapping_views_read_the_hit_rows(ffi):
     m2 = out[2][0]
     assert m2.ctg == "chrA" and m2.cs is None and m2.MD is None and m2.cigar == [(5, 0)] and not m2.is_primary
     assert m == m and m != m2 and "cg:Z:30M7D" in str(m)
+
+
+def test_pack_reads_passes_ascii_str_by_address_and_copies_the_rest(ffi):
+    """plain ASCII str reads go to the library by the address of their own buffer (no encode); bytes, mixed lists and non-ASCII text take the
+    copying path; both give the same pointers' contents and lengths"""
+    import ctypes as C
+    reads = ["ACGTNACGT", "", "G" * 5000]
+    arr, lens, keep = ffi.pack_reads(reads)
+    assert len(keep) == 3 and list(lens) == [9, 0, 5000] and [C.string_at(C.cast(arr, C.POINTER(C.c_void_p))[i], lens[i]) for i in range(3)] == [r.encode() for r in reads]
+    assert list(arr) == [r.encode() for r in reads]
+    arr2, lens2, keep2 = ffi.pack_reads(["ACGT", b"GG"])
+    assert list(arr2) == [b"ACGT", b"GG"] and list(lens2) == [4, 2] and len(keep2) == 2
+    arr3, lens3, _ = ffi.pack_reads(["ACéT"])
+    assert list(lens3) == [5] and list(arr3) == ["ACéT".encode()]
+
+
+def test_map_batch_list_fast_path_and_elementwise_errors(ffi, golden_dir, monkeypatch):
+    """lists of plain dicts are cut a sub-batch at a time; a bad element anywhere still raises what the element-wise loop raises"""
+    import mappy_rs
+    monkeypatch.setattr(mappy_rs, "SUB_BATCH_READS", 64)
+    al, taken, given = _mocked_aligner(golden_dir, monkeypatch)
+    items = [{"seq": "ACGT" * 10, "i": i} for i in range(3000)]
+    out = sorted(d["i"] for _m, d in al.map_batch(items))
+    assert out == list(range(3000)) and all(it == {"seq": "ACGT" * 10, "i": i} for i, it in enumerate(items))
+    for bad, exc in ((("seq", "ACGT"), TypeError), ({"id": 1}, KeyError), ({"seq": b"ACGT"}, ValueError)):
+        broken = list(items); broken[2500] = bad
+        with pytest.raises(exc):
+            al.map_batch(broken)
+    assert sorted(taken) == sorted(given)          # every worker context went back
