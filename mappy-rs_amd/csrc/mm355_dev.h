@@ -6,12 +6,34 @@ struct DevIndex {
 	const mm355_slot *slots;   // n_lines * 8 slots, 128-B lines
 	uint64_t line_mask;        // n_lines - 1
 	const uint64_t *pos;       // y words of multi-occurrence minimizers, ascending inside a run
-	const uint32_t *S;         // 4-bit packed reference (code 0..4), 8 bases per u32
+	const uint32_t *S2;        // 2-bit packed reference, 16 bases per u32 (an ambiguous base is stored as 0 ...
+	const uint64_t *nr;        // ... and listed here: n_nr runs [nr[2i], nr[2i+1]) of ambiguous bases, global offsets, ascending)
+	uint32_t n_nr;
 	const uint64_t *seq_off;   // per contig offset into S (bases)
 	const uint32_t *seq_len;
 	int32_t k, w, b, flag;
 	uint32_t n_seq;
 };
+
+#ifdef __HIPCC__
+// U:index.c::mm_idx_getseq on the 2-bit image: the N runs that can touch [lo, hi) -- `first` = the first run that ends after lo, `cnt` = how
+// many of them start before hi (0 almost always: a genome has a few hundred runs) -- and the code (0..4) of the base at global offset o
+__device__ __forceinline__ void ref_window(const DevIndex &ix, uint64_t lo, uint64_t hi, uint32_t &first, uint32_t &cnt)
+{
+	uint32_t a = 0, b = ix.n_nr;
+	while (a < b) { const uint32_t m = (a + b) >> 1; if (ix.nr[2 * m + 1] > lo) b = m; else a = m + 1; }
+	first = a;
+	uint32_t c = 0;
+	while (a + c < ix.n_nr && ix.nr[2 * (a + c)] < hi) ++c;
+	cnt = c;
+}
+__device__ __forceinline__ uint32_t ref_code(const DevIndex &ix, uint32_t first, uint32_t cnt, uint64_t o)
+{
+	uint32_t c = ix.S2[o >> 4] >> ((o & 15) << 1) & 3u;
+	for (uint32_t k = 0; k < cnt; ++k) if (o >= ix.nr[2 * (first + k)] && o < ix.nr[2 * (first + k) + 1]) c = 4;
+	return c;
+}
+#endif
 
 struct DevParams {           // subset of mm_mapopt_t the kernels read
 	int64_t flag;

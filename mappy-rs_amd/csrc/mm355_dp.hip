@@ -392,7 +392,7 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 }
 
 // gather kernel: materialise query / target code strings of each job (optionally reversed) from the read batch and
-// the 4-bit packed reference (U:index.c::mm_idx_getseq semantics)
+// the 2-bit packed reference + its N-run table (U:index.c::mm_idx_getseq semantics)
 __global__ __launch_bounds__(256) void k_dp_gather(DevIndex ix, const DpGather *g, int n_jobs, const uint8_t *rq, uint8_t *qbuf, uint8_t *tbuf)
 {
 	const int j = blockIdx.x;
@@ -403,10 +403,13 @@ __global__ __launch_bounds__(256) void k_dp_gather(DevIndex ix, const DpGather *
 		qbuf[gj.qoff + i] = rq[gj.q_src + src];
 	}
 	const uint64_t base = ix.seq_off[gj.rid] + (uint64_t)gj.t_st;
+	__shared__ uint32_t s_first, s_cnt;
+	if (threadIdx.x == 0) { uint32_t f = 0, n = 0; if (ix.n_nr) ref_window(ix, base, base + (uint64_t)(gj.tlen > 0? gj.tlen : 0), f, n); s_first = f; s_cnt = n; }
+	__syncthreads();
+	const uint32_t first = s_first, cnt = s_cnt;
 	for (int i = threadIdx.x; i < gj.tlen; i += 256) {
 		const int src = gj.rev? gj.tlen - 1 - i : i;
-		const uint64_t o = base + (uint64_t)src;
-		tbuf[gj.toff + i] = (uint8_t)(ix.S[o >> 3] >> ((o & 7) << 2) & 0xf);
+		tbuf[gj.toff + i] = (uint8_t)ref_code(ix, first, cnt, base + (uint64_t)src);
 	}
 }
 
@@ -787,6 +790,15 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	return 0;
 }
 
+// a target base for k_extra's forward walk: the 2-bit image, and code 4 inside the N run the pointer has reached
+__device__ __forceinline__ uint32_t ex_target(const DevIndex &ix, const uint64_t o, uint32_t &nri)
+{
+	uint32_t c = ix.S2[o >> 4] >> ((o & 15) << 1) & 3u;
+	while (nri < ix.n_nr && ix.nr[2 * nri + 1] <= o) ++nri;
+	if (nri < ix.n_nr && ix.nr[2 * nri] <= o) c = 4;
+	return c;
+}
+
 // ------------------------------------------------------------------ row f2: mm_update_extra's walk, cs and MD on the device
 // U:align.c::mm_update_extra (after mm_fix_cigar, which stays on the host: it edits the CIGAR) walks every aligned column of a region for
 // mlen / blen / n_ambi and the local-maximum score dp_max; U:format.c::write_cs_core (short form) and write_MD_core walk the same columns
@@ -817,7 +829,10 @@ __global__ __launch_bounds__(WAVE) void k_extra(DevIndex ix, const uint8_t *rq, 
 	unsigned run = 0, l_md = 0;      // matches pending for cs (inside the current match operation) and for MD (across operations)
 	double A = 0.0, m = 1e300, C = -1e300, P = -1e300;
 	const char *nt = "acgtn", *NT = "ACGTN";
-#define EX_T(off) ((uint32_t)(ix.S[(tb + (uint64_t)(off)) >> 3] >> (((tb + (uint64_t)(off)) & 7) << 2)) & 0xfu)
+	// the walk moves forward through the target, so the N run that can contain the current base only ever moves forward too
+	uint32_t nri = 0;
+	if (ix.n_nr) { uint32_t c_; ref_window(ix, tb, tb + 1, nri, c_); }
+#define EX_T(off) ex_target(ix, tb + (uint64_t)(off), nri)
 #define EX_PUT(buf, pos, lead, v) do { char bf_[12]; int nb_ = 0; unsigned v_ = (v); do { bf_[nb_++] = (char)('0' + v_ % 10); v_ /= 10; } while (v_); if (lead) buf[pos++] = (lead); while (nb_ > 0) buf[pos++] = bf_[--nb_]; } while (0)
 #define EX_FLUSH_CS() do { if (!(flushed & 1)) { cs_lead = (int32_t)run; cs_pre = n_out; flushed |= 1; } else if (run) EX_PUT(o, n_out, ':', run); run = 0; } while (0)
 #define EX_FLUSH_MD() do { if (!(flushed & 2)) { md_lead = (int32_t)l_md; flushed |= 2; } else EX_PUT(om, n_md, 0, l_md); l_md = 0; } while (0)

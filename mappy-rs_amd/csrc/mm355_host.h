@@ -8,8 +8,9 @@
 #include "../../include/mm355.h"
 #include "mm355_core.h"
 
-// HBM copy of the index on one device (flat table, pos[], 4-bit S, contig offsets/lengths).  Every context of that device shares it.
-struct mm355_replica { int dev = -1; void *slots = 0, *pos = 0, *S = 0, *seq_off = 0, *seq_len = 0; };
+// HBM copy of the index on one device (flat table, pos[], the reference packed to 2 bits per base + its sorted N-run intervals, contig
+// offsets/lengths).  Every context of that device shares it.  S (the .mmi's 4-bit image) only exists while the replica is being made.
+struct mm355_replica { int dev = -1; void *slots = 0, *pos = 0, *S = 0, *seq_off = 0, *seq_len = 0, *S2 = 0, *nr = 0; uint32_t n_nr = 0; };
 
 struct mm355_index {
 	int32_t b, w, k, flag;
@@ -30,7 +31,10 @@ struct mm355_index {
 	// per-device replicas (mm355_upload / first mm355_ctx_create on a device); the index itself stays immutable for the mapping path
 	mutable std::mutex rep_mu;
 	mutable std::vector<mm355_replica> replicas;
+	mutable std::vector<uint64_t> nrun; mutable bool nrun_done = false;   // [beg, end) pairs of the runs of ambiguous bases in S (global offsets), found once
 };
+// turns the replica's 4-bit S (on the device) into the 2-bit image + N-run table the kernels read, and frees S (call under rep_mu)
+int mm355_replica_pack2(const mm355_index *mi, mm355_replica *rp);
 // finds the replica of `dev`, creating it when absent: H2D from the host image, or a peer copy from the device the index was built on
 int mm355_index_replica(const mm355_index *mi, int dev, mm355_replica *out);
 void mm355_index_free_replicas(mm355_index *mi);

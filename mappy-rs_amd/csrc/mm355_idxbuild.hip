@@ -262,7 +262,13 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		if (hipMalloc(&rp.seq_off, (size_t)n_seq * 8) != hipSuccess || hipMalloc(&rp.seq_len, (size_t)n_seq * 4) != hipSuccess) { if (rp.seq_off) (void)hipFree(rp.seq_off); mi->dev_resident = false; FAIL(MM355_ENOMEM); }
 		(void)hipMemcpy(rp.seq_off, mi->seq_off.data(), (size_t)n_seq * 8, hipMemcpyHostToDevice);
 		(void)hipMemcpy(rp.seq_len, mi->seq_len.data(), (size_t)n_seq * 4, hipMemcpyHostToDevice);
+		{   // 2-bit image + N-run table for the kernels; the 4-bit image leaves HBM (the host keeps it for mm_idx_getseq and the .mmi)
+			std::lock_guard<std::mutex> lk(mi->rep_mu);
+			rc = mm355_replica_pack2(mi, &rp);
+			mi->d_S = rp.S;
+		}
 		mi->replicas.push_back(rp);
+		if (rc) { mi->dev_resident = false; goto done; }
 	}
 done:
 	d_seq.release(); d_slots16.release(); d_cn.release(); d_co.release(); d_keys.release(); d_vals.release(); d_keys2.release(); d_vals2.release(); d_tmp.release(); d_err.release();

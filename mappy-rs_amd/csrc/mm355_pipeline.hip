@@ -147,7 +147,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 	mm355_replica rp;
 	{ int rc = mm355_index_replica(mi, device_id, &rp); if (rc) { delete c; return rc; } }
 	c->dix.slots = (const mm355_slot*)rp.slots; c->dix.line_mask = mi->n_lines - 1;
-	c->dix.pos = (const uint64_t*)rp.pos; c->dix.S = (const uint32_t*)rp.S;
+	c->dix.pos = (const uint64_t*)rp.pos; c->dix.S2 = (const uint32_t*)rp.S2; c->dix.nr = (const uint64_t*)rp.nr; c->dix.n_nr = rp.n_nr;
 	c->dix.seq_off = (const uint64_t*)rp.seq_off; c->dix.seq_len = (const uint32_t*)rp.seq_len;
 	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
 	if (c->counters.ensure(CTR_BYTES) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
@@ -172,6 +172,55 @@ void mm355_kprof_dump(mm355_ctx *c)
 }
 
 // ------------------------------------------------------------------ index replicas (one per device)
+// The reference in HBM is packed 2 bits per base (16 bases per word: half the bytes of the .mmi's 4-bit image for the same gather); the
+// positions of ambiguous bases -- a few hundred runs in an assembly -- are a sorted interval table beside it.
+__global__ void k_pack2(const uint32_t *S4, uint32_t *S2, uint64_t n_w2, uint64_t n_w4)
+{
+	const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= n_w2) return;
+	uint32_t v = 0;
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const uint64_t w4 = 2 * w + h;
+		const uint32_t x = w4 < n_w4? S4[w4] : 0u;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) { const uint32_t c = x >> (4 * j) & 0xfu; v |= (c < 4? c : 0u) << (16 * h + 2 * j); }
+	}
+	S2[w] = v;
+}
+int mm355_replica_pack2(const mm355_index *mi, mm355_replica *rp)
+{
+	const uint64_t sum_len = mi->n_seq? mi->seq_off[mi->n_seq - 1] + mi->seq_len[mi->n_seq - 1] : 0;
+	if (!mi->nrun_done) {   // the runs of ambiguous bases, from the host image (words without one are skipped eight bases at a time)
+		std::vector<uint64_t> &nr = mi->nrun;
+		nr.clear();
+		const uint64_t nw = (sum_len + 7) / 8;
+		bool in = false;
+		for (uint64_t w = 0; w < nw && w < mi->S.size(); ++w) {
+			const uint32_t x = mi->S[w];
+			if ((x & 0xccccccccu) == 0) { if (in) { nr.push_back(w * 8); in = false; } continue; }   // (codes are 0..4: any of bits 2, 3 = ambiguous)
+			for (int j = 0; j < 8; ++j) {
+				const uint64_t o = w * 8 + j;
+				if (o >= sum_len) break;
+				const bool n = (x >> (4 * j) & 0xfu) > 3;
+				if (n && !in) { nr.push_back(o); in = true; }
+				else if (!n && in) { nr.push_back(o); in = false; }
+			}
+		}
+		if (in) nr.push_back(sum_len);
+		mi->nrun_done = true;
+	}
+	const uint64_t n_w4 = (sum_len + 7) / 8 + 2, n_w2 = (sum_len + 15) / 16 + 2;
+	if (hipMalloc(&rp->S2, n_w2 * 4 + 16) != hipSuccess) return MM355_ENOMEM;
+	if (hipMalloc(&rp->nr, mi->nrun.size() * 8 + 16) != hipSuccess) return MM355_ENOMEM;
+	hipLaunchKernelGGL(k_pack2, dim3((unsigned)((n_w2 + 255) / 256)), dim3(256), 0, 0, (const uint32_t*)rp->S, (uint32_t*)rp->S2, n_w2, n_w4);
+	if (hipGetLastError() != hipSuccess) return MM355_EHIP;
+	if (!mi->nrun.empty() && hipMemcpy(rp->nr, mi->nrun.data(), mi->nrun.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return MM355_EHIP;
+	if (hipDeviceSynchronize() != hipSuccess) return MM355_EHIP;
+	rp->n_nr = (uint32_t)(mi->nrun.size() / 2);
+	(void)hipFree(rp->S); rp->S = 0;
+	return 0;
+}
 int mm355_index_replica(const mm355_index *mi, int dev, mm355_replica *out)
 {
 	std::lock_guard<std::mutex> lk(mi->rep_mu);
@@ -183,7 +232,7 @@ int mm355_index_replica(const mm355_index *mi, int dev, mm355_replica *out)
 	const size_t np = mi->dev_resident? (size_t)mi->n_pos : mi->pos.size(), pb = (np + 2) * 8;
 	uint64_t sum_len = mi->n_seq? mi->seq_off[mi->n_seq - 1] + mi->seq_len[mi->n_seq - 1] : 0;
 	const size_t Sw = (sum_len + 7) / 8 + 2, Sb = Sw * 4;
-	auto fail = [&](int code) { if (rp.slots) (void)hipFree(rp.slots); if (rp.pos) (void)hipFree(rp.pos); if (rp.S) (void)hipFree(rp.S);
+	auto fail = [&](int code) { if (rp.slots) (void)hipFree(rp.slots); if (rp.pos) (void)hipFree(rp.pos); if (rp.S) (void)hipFree(rp.S); if (rp.S2) (void)hipFree(rp.S2); if (rp.nr) (void)hipFree(rp.nr);
 	                            if (rp.seq_off) (void)hipFree(rp.seq_off); if (rp.seq_len) (void)hipFree(rp.seq_len); (void)hipSetDevice(prev); return code; };
 	if (hipMalloc(&rp.slots, sb) != hipSuccess || hipMalloc(&rp.pos, pb) != hipSuccess || hipMalloc(&rp.S, Sb + 16) != hipSuccess ||
 	    hipMalloc(&rp.seq_off, (size_t)mi->n_seq * 8 + 8) != hipSuccess || hipMalloc(&rp.seq_len, (size_t)mi->n_seq * 4 + 8) != hipSuccess) return fail(MM355_ENOMEM);
@@ -201,6 +250,7 @@ int mm355_index_replica(const mm355_index *mi, int dev, mm355_replica *out)
 	if (!mi->S.empty() && hipMemcpy(rp.S, mi->S.data(), std::min(Sb, mi->S.size() * 4), hipMemcpyHostToDevice) != hipSuccess) return fail(MM355_EHIP);
 	if (hipMemcpy(rp.seq_off, mi->seq_off.data(), (size_t)mi->n_seq * 8, hipMemcpyHostToDevice) != hipSuccess ||
 	    hipMemcpy(rp.seq_len, mi->seq_len.data(), (size_t)mi->n_seq * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(MM355_EHIP);
+	{ const int rc2 = mm355_replica_pack2(mi, &rp); if (rc2) return fail(rc2); }
 	mi->replicas.push_back(rp);
 	(void)hipSetDevice(prev);
 	*out = rp;
@@ -214,7 +264,7 @@ void mm355_index_free_replicas(mm355_index *mi)
 	for (mm355_replica &r : mi->replicas) {
 		(void)hipSetDevice(r.dev);
 		if (r.slots) (void)hipFree(r.slots); if (r.pos) (void)hipFree(r.pos); if (r.S) (void)hipFree(r.S);
-		if (r.seq_off) (void)hipFree(r.seq_off); if (r.seq_len) (void)hipFree(r.seq_len);
+		if (r.seq_off) (void)hipFree(r.seq_off); if (r.seq_len) (void)hipFree(r.seq_len); if (r.S2) (void)hipFree(r.S2); if (r.nr) (void)hipFree(r.nr);
 	}
 	if (!mi->replicas.empty()) (void)hipSetDevice(prev);
 	mi->replicas.clear();

@@ -565,6 +565,43 @@ def test_resident_batch_slots(ont):
         L.mm355_ctx_destroy(ctx)
 
 
+def test_map_parity_reads_running_into_n_runs(built, tmp_path):
+    """the reference lives in HBM as a 2-bit image plus a sorted table of its N runs: reads that end inside a run, start inside one, span a
+    short one, and single ambiguous bases scattered in the target (runs of length 1, several per extension window) against the oracle,
+    which reads the 4-bit image"""
+    import mappy_rs
+    rng = np.random.default_rng(77)
+    g = S.make_genome(131, [260000, 140000, 30], repeats=((3000, 4, 0.01), (800, 10, 0.02)), n_runs=0)
+    runs = [(0, 40000, 700), (0, 90000, 37), (0, 150000, 1), (1, 20000, 1500), (1, 139000, 1000), (0, 0, 120)]   # (contig, start, length); the last: a contig that starts with N
+    for ci, st, ln in runs:
+        g[ci][st:st + ln] = 4
+    for p_ in range(200000, 203000, 61):         # lone ambiguous bases, ~50 in a 3 kb stretch
+        g[0][p_] = 4
+    g[2][:] = 4                                    # a contig of nothing but N
+    fa = str(tmp_path / "n.fa")
+    S.write_fasta(fa, g, ["c0", "c1", "c2"])
+    al = mappy_rs.Aligner(fa, preset="map-ont")
+    orc = O.OracleAligner(fa, preset="map-ont")
+    reads = []
+    def take(ci, a, b, rc=False):
+        c = g[ci][max(0, a):b].copy()
+        n = c > 3
+        c[n] = rng.integers(0, 4, int(n.sum()))     # the read has real bases where the assembly has none
+        c = S.mutate(c, rng, 0.04, 0.02, 0.02)
+        if rc: c = S._COMP[c[::-1]]
+        reads.append(S.codes_to_str(c))
+    for ci, st, ln in runs:
+        take(ci, st - 4000, st + ln // 2)            # ends inside the run
+        take(ci, st + ln // 2, st + ln + 4000, True)  # starts inside it
+        take(ci, st - 3000, st + ln + 3000)           # spans it
+        take(ci, st - 2500, st + 10, True)            # touches its first bases
+    take(0, 198000, 205000); take(0, 199500, 204000, True); take(0, 200100, 201900)
+    n_hits, _ = check_reads(al, orc, reads)
+    assert n_hits >= 20
+    from mappy_rs import _ffi
+    assert al.seq("c0", 39990, 40010) == "".join("ACGT"[x] for x in g[0][39990:40000]) + "N" * 10   # (host image, U:index.c::mm_idx_getseq)
+
+
 def test_committed_golden_vectors_on_gpu(built, golden_dir):
     """the HIP path reproduces the committed golden hits (tests/golden/oracle_ont_small.json) without running the oracle"""
     import json
