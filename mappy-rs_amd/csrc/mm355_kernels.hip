@@ -73,12 +73,14 @@ __global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix,
 	const int64_t off = bt.roff[r];
 	int ce = cs + SK_CHUNK;
 	if (ce > len) ce = len;
+	KPROF_BEGIN(bt);
 	if (lane == 0) {
 		const int ps = cs + wv * SKS_PIECE;
 		int pe = ps + SKS_PIECE;
 		if (pe > ce) pe = ce;
 		s_n[wv] = ps < pe? sketch_chunk(bt.seq + off, len, ix.w, ix.k, ps, pe, sd.mz + off + ps, ring + wv * ix.w, 1) : 0;
 	}
+	KPROF(24);
 	__syncthreads();
 	if (wv != 0) return;
 	mm128 *mz = sd.mz + off + cs;
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix,
 		m += n;
 	}
 	if (lane == 0) chunk_n[t] = m;
+	KPROF(25);
 }
 
 // packs the per-chunk outputs of a read to the front of its slot range (in place; destination never passes the source)

@@ -165,7 +165,7 @@ void mm355_kprof_dump(mm355_ctx *c)
 	if (hipMemcpy(h, c->kprof.p, 512, hipMemcpyDeviceToHost) != hipSuccess) return;
 	(void)hipMemset(c->kprof.p, 0, 512);
 	static const char *nm[32] = { "bt:zlist", "bt:zsort", "bt:walk", "bt:compact", "sel:hits", "sel:streaks", "sel:tail", "-",
-	                              "srt:total", "-", "-", "-", "chb:total", "chs:total", "-", "-", "mzf:total", "rmq:windows", "rmq:dp", "-", "rbt:zlist", "rbt:zsort", "rbt:walk", "rbt:compact", "-", "-", "-", "-", "-", "-", "-", "-" };
+	                              "srt:total", "-", "-", "-", "chb:total", "chs:total", "-", "-", "mzf:total", "rmq:windows", "rmq:dp", "-", "rbt:zlist", "rbt:zsort", "rbt:walk", "rbt:compact", "sk:piece", "sk:pack", "-", "-", "-", "-", "-", "-" };
 	fprintf(stderr, "[mm355] kprof (Mcycles: sum over reads / slowest read):");
 	for (int i = 0; i < 32; ++i) if (h[i]) fprintf(stderr, " %s %.1f/%.2f", nm[i], h[i] / 1e6, h[32 + i] / 1e6);
 	fprintf(stderr, "\n");
