@@ -267,8 +267,11 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 			rc = mm355_replica_pack2(mi, &rp);
 			mi->d_S = rp.S;
 		}
+		if (rc) {   // (the table buffers still belong to the build: free_build_buffers releases them, the replica only its own pieces)
+			(void)hipFree(rp.seq_off); (void)hipFree(rp.seq_len); if (rp.S2) (void)hipFree(rp.S2); if (rp.nr) (void)hipFree(rp.nr);
+			mi->dev_resident = false; goto done;
+		}
 		mi->replicas.push_back(rp);
-		if (rc) { mi->dev_resident = false; goto done; }
 	}
 done:
 	d_seq.release(); d_slots16.release(); d_cn.release(); d_co.release(); d_keys.release(); d_vals.release(); d_keys2.release(); d_vals2.release(); d_tmp.release(); d_err.release();
