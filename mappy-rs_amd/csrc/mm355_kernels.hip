@@ -56,10 +56,10 @@ __global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSe
 
 // Small batches (a single read is ~20 chunks): lane 0 of a wave alone.  With a lane per chunk the wave executes the union of every lane's
 // branches -- both ring rescans on almost every base -- which is what a full grid amortises and a 20-chunk grid does not.  A chunk is cut
-// once more, into SKS_WAVES pieces of SK_CHUNK / SKS_WAVES bases with a wave each (a piece pays the ~95-base warm-up of the exactness
-// proof again: 64 + 95 base steps on the critical path instead of 384 + 95); the pieces write at their own offsets of the chunk's slot
+// once more, into SKS_WAVES pieces of SK_CHUNK / SKS_WAVES bases with a wave each (a piece pays the ~45-base warm-up of the exactness
+// proof again: 32 + 45 base steps on the critical path instead of 384 + 45); the pieces write at their own offsets of the chunk's slot
 // range and wave 0 then packs them to its front, so the chunk looks as if one lane had done it.
-#define SKS_WAVES 6
+#define SKS_WAVES 12
 #define SKS_PIECE (SK_CHUNK / SKS_WAVES)
 __global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
 {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix,
 	if (wv != 0) return;
 	mm128 *mz = sd.mz + off + cs;
 	int m = s_n[0];
-	for (int k = 1; k < SKS_WAVES; ++k) {        // a piece holds at most SKS_PIECE = 64 minimizers: one wave-wide move, source read before the write
+	for (int k = 1; k < SKS_WAVES; ++k) {        // a piece holds at most SKS_PIECE <= 64 minimizers: one wave-wide move, source read before the write
 		const int n = s_n[k];
 		mm128 v; v.x = v.y = 0;
 		if (lane < n) v = mz[k * SKS_PIECE + lane];

@@ -16,7 +16,9 @@ __device__ int sketch_chunk(const uint8_t *seq, int len, int w, int k, int cs, i
 {
 	const uint64_t shift1 = 2 * (k - 1), mask = (1ULL << 2 * k) - 1;
 #define BUF(j) buf[(j) * bstride]
-	int warm = 2 * (w + k) + 2 * w + 24;
+	// first attempt: what the proof below needs on plain sequence ((w + k) counted k-mers, then w + 1 ring writes) plus a margin; the proof, not
+	// this length, is what makes the chunk exact -- a start that does not complete it is retried four times further back
+	int warm = (w + k) + (w + 1) + (k & 1? 8 : k + 8);
 	for (;;) {
 		int s0 = cs - warm;
 		if (s0 < 0) s0 = 0;
