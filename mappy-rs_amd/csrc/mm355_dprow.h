@@ -30,6 +30,8 @@
 
 __device__ __forceinline__ uint32_t pk8w(int v) { const uint32_t h = (uint32_t)(uint16_t)(int16_t)v; return h | h << 16; }   // plain int16 in both halves
 __device__ __forceinline__ uint32_t pk_sign16(uint32_t a) { uint32_t r; asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a)); return r; }   // 0xffff where the half is negative
+__device__ __forceinline__ uint32_t pk_rsubsat_s(uint32_t c, uint32_t a) { uint32_t r; asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "s"(c), "v"(a)); return r; }   // max(c - a, 0), unsigned
+__device__ __forceinline__ uint32_t pk_mad_vsv(uint32_t a, uint32_t b, uint32_t c) { uint32_t r; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c)); return r; }
 __device__ __forceinline__ int32_t wave_incl_scan_max32(int32_t x)   // inclusive prefix maximum over lanes 0..lane (DPP row shifts + row broadcasts)
 {
 	int32_t y;
@@ -44,6 +46,7 @@ __device__ __forceinline__ int32_t wave_incl_scan_max32(int32_t x)   // inclusiv
 
 struct RowK {                       // wave-uniform constants (SGPRs)
 	uint32_t qe1, e1, qe2, e2, q1, q2, mch, N, one, two, three, four, f8, f16, f32, f64;
+	uint32_t q1p, q2p;              // q + 1, q2 + 1 (the ">= 0" continuation test of KSW_EZ_RIGHT)
 	int32_t q1i, q2i;
 };
 
@@ -62,19 +65,21 @@ __device__ __forceinline__ int row_hb(int t, const DpConst &dc)
 __device__ __forceinline__ uint32_t pk2(int lo, int hi) { return (uint32_t)(uint16_t)(int16_t)lo | (uint32_t)(uint16_t)(int16_t)hi << 16; }
 __device__ __forceinline__ uint32_t pk_max_swap(uint32_t a) { uint32_t r; asm("v_pk_max_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }   // both halves = max(lo, hi)
 
-// exclusive prefix maximum of A over the cells of one set, with carry-in C (value for every cell, includes all earlier sets);
-// returns the packed prefix minus `sub` (a wave-uniform int), and the carry for the next set in C
-__device__ __forceinline__ uint32_t row_scan(const uint32_t A, int32_t &C, const int32_t sub)
+// exclusive prefix maximum of A over the cells of one set, with carry-in C (includes all earlier sets); returns the packed prefix (lo: the
+// lane's first cell, hi: its second, which also sees the first) and the carry for the next set in C.  The scan runs on "doubled" words --
+// the 16-bit value in BOTH halves, which as an int32 orders like the value itself -- so that neither the lane maximum has to be sign-extended
+// nor the result re-packed: v_pk_max (swap), six v_max_i32 dpp, the shifted carry, one v_pk_max against {-inf, A.lo}.  C is doubled too (row_dbl).
+// (The caller subtracts q + t e in ONE packed operation: the constant is folded into its per-set register.)
+#define ROW_PKNEG 0x80008000u
+__device__ __forceinline__ int32_t row_dbl(int v) { return (int32_t)((uint32_t)(v & 0xffff) * 0x10001u); }
+__device__ __forceinline__ uint32_t row_scan(const uint32_t A, int32_t &C)
 {
-	const int32_t lm = (int32_t)pk_max_swap(A) >> 16;                     // max(lo, hi) of the lane, sign-extended
-	const int32_t incl = wave_incl_scan_max32(lm);
+	const int32_t incl = wave_incl_scan_max32((int32_t)pk_max_swap(A));
 	int32_t ex = __builtin_amdgcn_update_dpp(C, incl, 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 <- carry
 	ex = ex > C? ex : C;
-	const int32_t lo32 = (int32_t)(A << 16) >> 16;
-	const int32_t hi = ex > lo32? ex : lo32;
 	const int32_t tot = __builtin_amdgcn_readlane(incl, 63);
 	C = C > tot? C : tot;
-	return (uint32_t)((ex - sub) & 0xffff) | (uint32_t)(hi - sub) << 16;
+	return pk_max((uint32_t)ex, __builtin_amdgcn_perm(A, ROW_PKNEG, 0x05040100));   // {ex, max(ex, A.lo)}
 }
 
 // one register set (128 target cells) of one row: in: the row above (Hp, Fp, F2p), the cell to the left of the set's first cell in the row
@@ -82,7 +87,7 @@ __device__ __forceinline__ uint32_t row_scan(const uint32_t A, int32_t &C, const
 // carries for the next set, the direction bytes of the two cells of this lane at pcell
 template <bool RIGHT>
 __device__ __forceinline__ void row_set(const RowK &K, const uint32_t dmis, const bool any_n, const uint32_t qc2, uint32_t &Hp, uint32_t &Fp, uint32_t &F2p,
-                                        const uint32_t TQ, const uint32_t KE1, const uint32_t KE2, uint32_t &carry_h, int32_t &C1, int32_t &C2, uint8_t *pcell, const bool store)
+                                        const uint32_t TQ, const uint32_t KE1, const uint32_t KE2, const uint32_t KQ1, const uint32_t KQ2, uint32_t &carry_h, int32_t &C1, int32_t &C2, uint8_t *pcell, const bool store)
 {
 	// H(t-1, q-1): the row above, shifted one cell to the right
 	const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_h, (int)Hp, 0x138, 0xf, 0xf, false);
@@ -96,11 +101,12 @@ __device__ __forceinline__ void row_set(const RowK &K, const uint32_t dmis, cons
 	const uint32_t F2 = pk_max(pk_sub_s(Hp, K.qe2), pk_sub_s(F2p, K.e2));
 	const uint32_t G = pk_max(pk_max(M, F), F2);
 	// E(t) = max_{k<t} (G(k) + k e) - (q + e) - (t - 1) e = [prefix - q] - t e
-	const uint32_t E = pk_sub(row_scan(pk_add(G, KE1), C1, K.q1i), KE1);
-	const uint32_t E2 = pk_sub(row_scan(pk_add(G, KE2), C2, K.q2i), KE2);
+	const uint32_t E = pk_sub(row_scan(pk_add(G, KE1), C1), KQ1);        // KQ = KE + q: [prefix - q] - t e in one subtraction
+	const uint32_t E2 = pk_sub(row_scan(pk_add(G, KE2), C2), KQ2);
 	const uint32_t H = pk_max(pk_max(G, E), E2);
 	// direction byte
-	const uint32_t n1 = pk_minu_s(pk_sub(H, E), K.one), n2 = pk_minu_s(pk_sub(H, F), K.one), n3 = pk_minu_s(pk_sub(H, E2), K.one);
+	const uint32_t xE = pk_sub(H, E), xF = pk_sub(H, F), xE2 = pk_sub(H, E2), xF2 = pk_sub(H, F2);   // >= 0: H is the maximum
+	const uint32_t n1 = pk_minu_s(xE, K.one), n2 = pk_minu_s(xF, K.one), n3 = pk_minu_s(xE2, K.one);
 	uint32_t d;
 	if (!RIGHT) {   // first maximum
 		const uint32_t n0 = pk_minu_s(pk_sub(H, M), K.one);
@@ -109,22 +115,19 @@ __device__ __forceinline__ void row_set(const RowK &K, const uint32_t dmis, cons
 		d = pk_mad_vvs(n1, d, K.one);
 		d = pk_mul(n0, d);
 	} else {        // last maximum
-		const uint32_t n4 = pk_minu_s(pk_sub(H, F2), K.one);
+		const uint32_t n4 = pk_minu_s(xF2, K.one);
 		d = pk_rsub_s(K.one, n1);
 		d = pk_mad_vvs(n2, pk_sub_s(d, K.two), K.two);
 		d = pk_mad_vvs(n3, pk_sub_s(d, K.three), K.three);
 		d = pk_mad_vvs(n4, pk_sub_s(d, K.four), K.four);
 	}
-	const uint32_t t1 = pk_sub_s(H, K.q1), t2 = pk_sub_s(H, K.q2);
-	uint32_t fa, fb, fa2, fb2;
-	if (!RIGHT) {   // > 0: the sign of the reversed difference (plain int16 halves: any positive value, not only multiples of 256)
-		fa = K.f8 & pk_sign16(pk_sub(t1, E)); fb = K.f16 & pk_sign16(pk_sub(t1, F));
-		fa2 = K.f32 & pk_sign16(pk_sub(t2, E2)); fb2 = K.f64 & pk_sign16(pk_sub(t2, F2));
-	} else {        // >= 0
-		fa = K.f8 & ~pk_sign16(pk_sub(E, t1)); fb = K.f16 & ~pk_sign16(pk_sub(F, t1));
-		fa2 = K.f32 & ~pk_sign16(pk_sub(E2, t2)); fb2 = K.f64 & ~pk_sign16(pk_sub(F2, t2));
-	}
-	d = d | fa | fb; d = d | fa2 | fb2;
+	// continuation flags: X - H + q > 0 (RIGHT: >= 0)  <=>  H - X < q (RIGHT: < q + 1) -- a saturating q - (H - X) is non-zero exactly then;
+	// its 0 / 1 image times the flag bit is accumulated into d (the bits are disjoint: + is |)
+	const uint32_t c1 = RIGHT? K.q1p : K.q1, c2 = RIGHT? K.q2p : K.q2;
+	d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c1, xE), K.one), K.f8, d);
+	d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c1, xF), K.one), K.f16, d);
+	d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c2, xE2), K.one), K.f32, d);
+	d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c2, xF2), K.one), K.f64, d);
 	if (store) *(uint16_t*)pcell = (uint16_t)__builtin_amdgcn_perm(0, d, 0x0c0c0200);
 	Hp = H; Fp = F; F2p = F2;
 }
@@ -134,7 +137,7 @@ __device__ __forceinline__ void row_sweep(const DpConst &dc, const RowK &K, cons
                                           const bool any_n, const int lane, int32_t &score_out)
 {
 	const int qlen = jb.qlen, tlen = jb.tlen;
-	uint32_t Hp[NS], Fp[NS], F2p[NS], TQ[NS], KE1[NS], KE2[NS];
+	uint32_t Hp[NS], Fp[NS], F2p[NS], TQ[NS], KE1[NS], KE2[NS], KQ1[NS], KQ2[NS];
 #pragma unroll
 	for (int k = 0; k < NS; ++k) {
 		const int t0 = 128 * k + 2 * lane;
@@ -143,6 +146,8 @@ __device__ __forceinline__ void row_sweep(const DpConst &dc, const RowK &K, cons
 		TQ[k] = (t0 < tlen? (uint32_t)target[t0] : 0u) | (t0 + 1 < tlen? (uint32_t)target[t0 + 1] : 0u) << 16;
 		KE1[k] = pk2(t0 * dc.e, (t0 + 1) * dc.e);
 		KE2[k] = pk2(t0 * dc.e2, (t0 + 1) * dc.e2);
+		KQ1[k] = pk2(t0 * dc.e + dc.q, (t0 + 1) * dc.e + dc.q);
+		KQ2[k] = pk2(t0 * dc.e2 + dc.q2, (t0 + 1) * dc.e2 + dc.q2);
 	}
 	const uint32_t dmis = vreg_const(pk8w(dc.sc_mis - dc.sc_mch));
 	int32_t hl_prev = 0, hl = row_hb(0, dc);          // H(-1, q - 1), H(-1, q)
@@ -152,12 +157,12 @@ __device__ __forceinline__ void row_sweep(const DpConst &dc, const RowK &K, cons
 		if ((q & 63) == 0) qv = q + lane < qlen? query[q + lane] : 0;
 		const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
 		const uint32_t qc2 = qc | qc << 16;
-		int32_t C1 = hl - dc.e, C2 = hl - dc.e2;       // the k = -1 term of both prefix maxima: a gap opened at the left border
+		int32_t C1 = row_dbl(hl - dc.e), C2 = row_dbl(hl - dc.e2);   // the k = -1 term of both prefix maxima: a gap opened at the left border
 		uint32_t carry_h = pk2(0, hl_prev);            // (hi half) H of the row above, one cell to the left of this set's first cell
 #pragma unroll
 		for (int k = 0; k < NS; ++k) {
 			if (128 * k >= tlen) break;                // (wave-uniform) sets beyond the target
-			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], carry_h, C1, C2, prow + 128 * k, 128 * k + 2 * lane < tlen);
+			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], KQ1[k], KQ2[k], carry_h, C1, C2, prow + 128 * k, 128 * k + 2 * lane < tlen);
 		}
 		prow += tstride;
 		hl_prev = hl;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(64) void k_ksw_row(DpConst dc, const DpJobDev *jobs
 	RowK K;
 	K.qe1 = pk8w(dc.q + dc.e); K.e1 = pk8w(dc.e); K.qe2 = pk8w(dc.q2 + dc.e2); K.e2 = pk8w(dc.e2); K.q1 = pk8w(dc.q); K.q2 = pk8w(dc.q2);
 	K.mch = pk8w(dc.sc_mch); K.N = pk8w(dc.sc_N); K.one = 0x00010001u; K.two = 0x00020002u; K.three = 0x00030003u; K.four = 0x00040004u;
-	K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u; K.q1i = dc.q; K.q2i = dc.q2;
+	K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u; K.q1i = dc.q; K.q2i = dc.q2; K.q1p = pk8w(dc.q + 1); K.q2p = pk8w(dc.q2 + 1);
 	bool n = false;
 	for (int i = lane; i < jb.tlen; i += 64) n |= target[i] > 3;
 	for (int i = lane; i < jb.qlen; i += 64) n |= query[i] > 3;
@@ -223,7 +228,7 @@ __device__ __forceinline__ void rowl_panel(const DpConst &dc, const RowK &K, con
                                            const bool any_n, const int lane, const int pw, int32_t *colC1, int32_t *colC2, int32_t *colH, int *done, int32_t &score_out)
 {
 	const int qlen = jb.qlen, tlen = jb.tlen, tb = pw * ROWL_PANEL;
-	uint32_t Hp[ROWL_NS], Fp[ROWL_NS], F2p[ROWL_NS], TQ[ROWL_NS], KE1[ROWL_NS], KE2[ROWL_NS];
+	uint32_t Hp[ROWL_NS], Fp[ROWL_NS], F2p[ROWL_NS], TQ[ROWL_NS], KE1[ROWL_NS], KE2[ROWL_NS], KQ1[ROWL_NS], KQ2[ROWL_NS];
 #pragma unroll
 	for (int k = 0; k < ROWL_NS; ++k) {
 		const int t0 = tb + 128 * k + 2 * lane;
@@ -232,6 +237,8 @@ __device__ __forceinline__ void rowl_panel(const DpConst &dc, const RowK &K, con
 		TQ[k] = (t0 < tlen? (uint32_t)target[t0] : 0u) | (t0 + 1 < tlen? (uint32_t)target[t0 + 1] : 0u) << 16;
 		KE1[k] = pk2(t0 * dc.e, (t0 + 1) * dc.e);
 		KE2[k] = pk2(t0 * dc.e2, (t0 + 1) * dc.e2);
+		KQ1[k] = pk2(t0 * dc.e + dc.q, (t0 + 1) * dc.e + dc.q);
+		KQ2[k] = pk2(t0 * dc.e2 + dc.q2, (t0 + 1) * dc.e2 + dc.q2);
 	}
 	const uint32_t dmis = vreg_const(pk8w(dc.sc_mis - dc.sc_mch));
 	const bool last = tb + ROWL_PANEL >= tlen;         // nobody reads this panel's edge
@@ -251,13 +258,13 @@ __device__ __forceinline__ void rowl_panel(const DpConst &dc, const RowK &K, con
 		const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
 		const uint32_t qc2 = qc | qc << 16;
 		int32_t C1, C2, hl_cur;
-		if (pw == 0) { hl_cur = row_hb(q, dc); C1 = hl_cur - dc.e; C2 = hl_cur - dc.e2; }      // the k = -1 term: a gap opened at the left border
+		if (pw == 0) { hl_cur = row_hb(q, dc); C1 = row_dbl(hl_cur - dc.e); C2 = row_dbl(hl_cur - dc.e2); }      // the k = -1 term: a gap opened at the left border (carries travel doubled, also through LDS)
 		else { C1 = __builtin_amdgcn_readlane(vC1, q & 63); C2 = __builtin_amdgcn_readlane(vC2, q & 63); hl_cur = __builtin_amdgcn_readlane(vH, q & 63); }
 		uint32_t carry_h = pk2(0, hl_prev);
 #pragma unroll
 		for (int k = 0; k < ROWL_NS; ++k) {
 			if (tb + 128 * k >= tlen) break;            // (wave-uniform) sets beyond the target
-			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], carry_h, C1, C2, prow + 128 * k, tb + 128 * k + 2 * lane < tlen);
+			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], KQ1[k], KQ2[k], carry_h, C1, C2, prow + 128 * k, tb + 128 * k + 2 * lane < tlen);
 		}
 		if (!last) {
 			const int32_t he = (int32_t)__builtin_amdgcn_readlane((int)Hp[ROWL_NS - 1], 63) >> 16;     // H(tb + 511, q)
@@ -300,7 +307,7 @@ __global__ __launch_bounds__(64 * ROWL_WAVES) void k_ksw_rowl(DpConst dc, const 
 	RowK K;
 	K.qe1 = pk8w(dc.q + dc.e); K.e1 = pk8w(dc.e); K.qe2 = pk8w(dc.q2 + dc.e2); K.e2 = pk8w(dc.e2); K.q1 = pk8w(dc.q); K.q2 = pk8w(dc.q2);
 	K.mch = pk8w(dc.sc_mch); K.N = pk8w(dc.sc_N); K.one = 0x00010001u; K.two = 0x00020002u; K.three = 0x00030003u; K.four = 0x00040004u;
-	K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u; K.q1i = dc.q; K.q2i = dc.q2;
+	K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u; K.q1i = dc.q; K.q2i = dc.q2; K.q1p = pk8w(dc.q + 1); K.q2p = pk8w(dc.q2 + 1);
 	const int tstride = (jb.tlen + 15) / 16 * 16 + 16;
 	int32_t score = KSW_NEG_INF;
 	bool last_mine = false;
