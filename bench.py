@@ -492,8 +492,17 @@ def main():
         # dominant kernel = the extension kernel with the largest summed duration (each is timed alone with HIP events on the stream it is launched
         # on; the rocprofv3 kernel statistics of the same command, profiles/, name the same kernel at the top).  The front stages are timed as
         # event spans on the context's main stream, where kernels of other contexts interleave: they stay in roofline_all.
-        gi = int(np.argmax(agg["ms_dp_group"]))
+        # Among them only the kernels whose launches fill the machine (one wave per alignment, 10^4..10^5 alignments per launch): a roofline
+        # fraction says nothing about the three classes of few, long problems (targets > 1024: k_ksw_regw8, k_ksw_rowl, k_ksw_extd2<512>) -- a
+        # launch of a few hundred blocks whose length is the dependent chain of its longest alignment, beside which the wide grids run.
+        # They are in roofline_all and in `latency_chains` with their own figure of merit (ms per launch).
+        LATENCY_GROUPS = (8, 10, 17, 18)
+        ms_wide = [0.0 if i in LATENCY_GROUPS else agg["ms_dp_group"][i] for i in range(len(agg["ms_dp_group"]))]
+        gi = int(np.argmax(ms_wide))
         dom = gnames[gi]
+        latency_chains = {gnames[i]: dict(ms_per_launch=round(agg["ms_dp_group"][i] / max(1.0, nl_g[i]), 3), ms_per_step=round(agg["ms_dp_group"][i] / K, 3),
+                                          cells_per_launch=int(cells_g[i] / max(1.0, nl_g[i])))
+                          for i in LATENCY_GROUPS if nl_g[i] > 0 and agg["ms_dp_group"][i] > 0}
         # the kernel the north star names: seed lookup against the HBM roof, and against what the memory system delivers for uniformly random
         # 128-byte lines of a table this size (profiles/r03_random_line_roof.json, measured by tools/linebench on the same chip)
         rl = dict(roof["k_seed_lookup"])
@@ -524,7 +533,9 @@ def main():
             "step_ms": dict(median=float(np.median(step_ms)), min=min(step_ms), max=max(step_ms), all=step_ms,
                             note="completion of the last sub-batch of every step, rank 0 (the threads do not wait for one another between steps)"),
             "pcie_inclusive_mbases_per_s": None if dt_p is None else round(aligned_p / dt_p / 1e6, 3),
-            "roofline": roof[dom], "roofline_seed_lookup": rl, "roofline_all": roof, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
+            "roofline": dict(roof[dom], rule="the extension kernel with the largest summed duration among those whose launches fill the machine; "
+                                                "the classes of few long alignments are latency chains (latency_chains, roofline_all)"),
+            "roofline_seed_lookup": rl, "roofline_all": roof, "latency_chains": latency_chains, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
             "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(19) if nl_g[i] > 0},
             "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(19) if nl_g[i] > 0},
             "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
