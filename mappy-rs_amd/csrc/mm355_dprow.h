@@ -18,7 +18,7 @@
 //     E, E2 (gaps that consume target) run ALONG the row: E(t) = max_{k<t} (G(k) + k e) - q - e - (t - 1) e with G = max(M, F, F2)
 //     (opening a gap from an H that is itself an E never beats extending that E), i.e. an exclusive prefix maximum over the lanes:
 //     six v_max_i32 DPP steps per set and gap type, the carry between sets through one v_readlane.
-// About 80 VALU per 128 cells of a row, all of them cells of the matrix: ~0.7 VALU per cell against ~1.6 for the anti-diagonal form.
+// About 74 VALU per 128 cells of a row, all of them cells of the matrix: ~0.6 VALU per cell against ~1.6 for the anti-diagonal form.
 // The direction bytes are written row-major (q * tstride + t; 2-byte stores per lane, 128 B per set and row, coalesced); the job
 // descriptor says so (DpJobDev::pad = 1) and k_ksw_backtrack reads them that way.  ez: only `score` is defined for these problems
 // (max = 0, max_t = max_q = -1, not z-dropped), as in the approximate full-band path of k_ksw_reg.
