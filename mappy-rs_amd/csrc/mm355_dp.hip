@@ -358,7 +358,7 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 			uint32_t tmp;
 			if (i < st) force_state = 2;
 			if (i > en) force_state = 1;
-			tmp = force_state < 0? (jb.pad? p[(size_t)j * row_stride + i] : p[(size_t)rr * n_col + i - st]) : 0;   // pad = 1: k_ksw_row's row-major matrix
+			tmp = force_state < 0? (jb.pad? p[row_cell_off(j, i, row_stride)] : p[(size_t)rr * n_col + i - st]) : 0;   // pad = 1: the row sweep's tiled matrix (mm355_dprow.h)
 			if (state == 0) state = tmp & 7;
 			else if (!(tmp >> (state + 2) & 1)) state = 0;
 			if (state == 0) state = tmp & 7;
@@ -487,7 +487,7 @@ static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc
 // runs n jobs whose code strings are already on the device (d_q/d_t).  `jobs` is host memory that stays valid until the call
 // returns (pinned when it comes from the mapping path).  Results: res_out -> c->h_res (pinned, valid until the next call),
 // bytes of direction matrix mm355_dp_run lays out for one extension problem (the caller cuts a round so that a launch fits its HBM budget):
-// the row sweep's row-major matrix for the full-band approximate fills it takes, the reference's anti-diagonal layout otherwise
+// the row sweep's tiled matrix (mm355_dprow.h) for the full-band approximate fills it takes, the reference's anti-diagonal layout otherwise
 size_t mm355_dp_matrix_bytes(const mm355_mapopt_t *mo, const DpConst &dc, int qlen, int tlen, int w_in, int flag)
 {
 	if (qlen <= 0 || tlen <= 0) return 0;
@@ -503,7 +503,7 @@ size_t mm355_dp_matrix_bytes(const mm355_mapopt_t *mo, const DpConst &dc, int ql
 	const bool row_kind = dc.valid && use_row && regular && (flag & EZ_APPROX_MAX) && !(flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= qlen + tlen;
 	const bool row = row_kind && tlen <= ROW_MAX_T && qlen + tlen <= ROW_MAX_QT && rowl_range_ok(dc, qlen, tlen <= 256? 256 : tlen <= 512? 512 : 1024);
 	const bool rowl = row_kind && use_rowl && tlen > ROW_MAX_T && tlen <= ROWL_MAX_T && qlen <= ROWL_MAX_Q && rowl_range_ok(dc, qlen, tlen);
-	if (row || rowl) return (size_t)qlen * ((size_t)T + 16) + 16;
+	if (row || rowl) return row_matrix_bytes(qlen, T) + 64;   // (+ the alignment of its first tile)
 	return ((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16;
 }
 
@@ -552,7 +552,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			const bool rowl = row_kind && use_rowl && j.tlen > ROW_MAX_T && j.tlen <= ROWL_MAX_T && j.qlen <= ROWL_MAX_Q && rowl_range_ok(dc, j.qlen, j.tlen);
 			if (row || rowl) {
 				j.pad = 1;
-				p_tot += (size_t)j.qlen * ((size_t)T + 16) + 16;
+				p_tot = (p_tot + 63) & ~(size_t)63;            // tiles are 64-byte lines
+				j.p_off = (int64_t)p_tot;
+				p_tot += row_matrix_bytes(j.qlen, T);
 				g = rowl? DP_G_ROWL : j.tlen <= 256? DP_G_ROW2 : j.tlen <= 512? DP_G_ROW4 : DP_G_ROW8;
 			} else {
 				p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;

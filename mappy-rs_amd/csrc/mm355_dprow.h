@@ -19,12 +19,20 @@
 //     (opening a gap from an H that is itself an E never beats extending that E), i.e. an exclusive prefix maximum over the lanes:
 //     six v_max_i32 DPP steps per set and gap type, the carry between sets through one v_readlane.
 // About 74 VALU per 128 cells of a row, all of them cells of the matrix: ~0.6 VALU per cell against ~1.6 for the anti-diagonal form.
-// The direction bytes are written row-major (q * tstride + t; 2-byte stores per lane, 128 B per set and row, coalesced); the job
-// descriptor says so (DpJobDev::pad = 1) and k_ksw_backtrack reads them that way.  ez: only `score` is defined for these problems
+// The direction bytes are written in TILES of 4 query rows x 16 target cells (64 B, one HBM fetch granule): a lane keeps the bytes of its
+// two cells over four rows in two registers and stores them as ONE 8-byte word per set (512 B per wave and set, every line written whole,
+// once) -- byte (q, t) of a job's matrix is at row_cell_off(q, t, tstride) = (q >> 2) * 4 tstride + (t >> 1) * 8 + (q & 3) * 2 + (t & 1).
+// k_ksw_backtrack's walk moves at most one row and one column per step: along a diagonal it enters a new tile every 3.2 steps (1/4 + 1/16
+// per step) instead of a new row -- a new line -- on every step of a row-major matrix (PMC: 53 B fetched per CIGAR column before).  The job
+// descriptor names the layout (DpJobDev::pad = 1) and k_ksw_backtrack reads it that way.  ez: only `score` is defined for these problems
 // (max = 0, max_t = max_q = -1, not z-dropped), as in the approximate full-band path of k_ksw_reg.
 #pragma once
 
 #define ROW_NEG (-16384)
+#define ROW_TILE_ROWS 4
+// bytes of the tiled direction matrix of a qlen x tlen problem (T = tlen rounded up to 16; the matrix starts on a 64-byte boundary)
+__host__ __device__ __forceinline__ size_t row_matrix_bytes(int qlen, int T) { return (size_t)((qlen + ROW_TILE_ROWS - 1) & ~(ROW_TILE_ROWS - 1)) * ((size_t)T + 16) + 64; }
+__host__ __device__ __forceinline__ size_t row_cell_off(int q, int t, int tstride) { return (size_t)(q >> 2) * (size_t)(4 * tstride) + (size_t)(t >> 1) * 8 + (size_t)((q & 3) * 2 + (t & 1)); }
 #define ROW_MAX_T 1024              // eight register sets
 #define ROW_MAX_QT 6000             // qlen + tlen: keeps every value inside int16
 
@@ -84,10 +92,11 @@ __device__ __forceinline__ uint32_t row_scan(const uint32_t A, int32_t &C)
 
 // one register set (128 target cells) of one row: in: the row above (Hp, Fp, F2p), the cell to the left of the set's first cell in the row
 // above (hi half of carry_h), the prefix maxima of everything to the left in this row (C1, C2); out: this row's H / F / F2 in their place,
-// carries for the next set, the direction bytes of the two cells of this lane at pcell
+// carries for the next set, the direction bytes of the two cells of this lane in accw (rows 0 / 2 of a tile: the low half, the high half
+// cleared; rows 1 / 3 -- `odd`, a constant after unrolling -- the high half)
 template <bool RIGHT>
 __device__ __forceinline__ void row_set(const RowK &K, const uint32_t dmis, const bool any_n, const uint32_t qc2, uint32_t &Hp, uint32_t &Fp, uint32_t &F2p,
-                                        const uint32_t TQ, const uint32_t KE1, const uint32_t KE2, const uint32_t KQ1, const uint32_t KQ2, uint32_t &carry_h, int32_t &C1, int32_t &C2, uint8_t *pcell, const bool store)
+                                        const uint32_t TQ, const uint32_t KE1, const uint32_t KE2, const uint32_t KQ1, const uint32_t KQ2, uint32_t &carry_h, int32_t &C1, int32_t &C2, const bool odd, uint32_t &accw)
 {
 	// H(t-1, q-1): the row above, shifted one cell to the right
 	const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)carry_h, (int)Hp, 0x138, 0xf, 0xf, false);
@@ -128,7 +137,8 @@ __device__ __forceinline__ void row_set(const RowK &K, const uint32_t dmis, cons
 	d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c1, xF), K.one), K.f16, d);
 	d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c2, xE2), K.one), K.f32, d);
 	d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c2, xF2), K.one), K.f64, d);
-	if (store) *(uint16_t*)pcell = (uint16_t)__builtin_amdgcn_perm(0, d, 0x0c0c0200);
+	if (!odd) accw = __builtin_amdgcn_perm(0, d, 0x0c0c0200);          // { d.lo, d.hi, 0, 0 }
+	else accw = __builtin_amdgcn_perm(d, accw, 0x06040100);            // { accw.b0, accw.b1, d.lo, d.hi }
 	Hp = H; Fp = F; F2p = F2;
 }
 
@@ -152,21 +162,32 @@ __device__ __forceinline__ void row_sweep(const DpConst &dc, const RowK &K, cons
 	const uint32_t dmis = vreg_const(pk8w(dc.sc_mis - dc.sc_mch));
 	int32_t hl_prev = 0, hl = row_hb(0, dc);          // H(-1, q - 1), H(-1, q)
 	uint32_t qv = 0;
-	uint8_t *prow = p + 2 * lane;
-	for (int q = 0; q < qlen; ++q) {
-		if ((q & 63) == 0) qv = q + lane < qlen? query[q + lane] : 0;
-		const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
-		const uint32_t qc2 = qc | qc << 16;
-		int32_t C1 = row_dbl(hl - dc.e), C2 = row_dbl(hl - dc.e2);   // the k = -1 term of both prefix maxima: a gap opened at the left border
-		uint32_t carry_h = pk2(0, hl_prev);            // (hi half) H of the row above, one cell to the left of this set's first cell
+	uint32_t A0[NS], A1[NS];                           // direction bytes of rows (0, 1) and (2, 3) of the current tile row
 #pragma unroll
-		for (int k = 0; k < NS; ++k) {
-			if (128 * k >= tlen) break;                // (wave-uniform) sets beyond the target
-			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], KQ1[k], KQ2[k], carry_h, C1, C2, prow + 128 * k, 128 * k + 2 * lane < tlen);
+	for (int k = 0; k < NS; ++k) A0[k] = A1[k] = 0;
+	uint8_t *ptile = p + 8 * lane;                     // the lane's 8-byte word of set 0 in the current tile row
+	for (int q0 = 0; q0 < qlen; q0 += ROW_TILE_ROWS) {
+#pragma unroll
+		for (int u = 0; u < ROW_TILE_ROWS; ++u) {
+			const int q = q0 + u;
+			if (q >= qlen) break;                      // (wave-uniform) the last tile row may be short: its other bytes are never read
+			if ((q & 63) == 0) qv = q + lane < qlen? query[q + lane] : 0;
+			const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
+			const uint32_t qc2 = qc | qc << 16;
+			int32_t C1 = row_dbl(hl - dc.e), C2 = row_dbl(hl - dc.e2);   // the k = -1 term of both prefix maxima: a gap opened at the left border
+			uint32_t carry_h = pk2(0, hl_prev);        // (hi half) H of the row above, one cell to the left of this set's first cell
+#pragma unroll
+			for (int k = 0; k < NS; ++k) {
+				if (128 * k >= tlen) break;            // (wave-uniform) sets beyond the target
+				row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], KQ1[k], KQ2[k], carry_h, C1, C2, (u & 1) != 0, u < 2? A0[k] : A1[k]);
+			}
+			hl_prev = hl;
+			hl = row_hb(q + 1, dc);
 		}
-		prow += tstride;
-		hl_prev = hl;
-		hl = row_hb(q + 1, dc);
+#pragma unroll
+		for (int k = 0; k < NS; ++k)
+			if (128 * k + 2 * lane < tlen) *(uint2*)(ptile + 512 * k) = make_uint2(A0[k], A1[k]);
+		ptile += 4 * tstride;
 	}
 	// H(tlen - 1, qlen - 1)
 	const int tl = tlen - 1;
@@ -245,8 +266,15 @@ __device__ __forceinline__ void rowl_panel(const DpConst &dc, const RowK &K, con
 	int32_t hl_prev = row_hb(tb - 1, dc);              // H(tb - 1, q - 1): the boundary row above the first row
 	int32_t vC1 = 0, vC2 = 0, vH = 0;                  // lane l: the left neighbour's edge values of row (q & ~63) + l
 	uint32_t qv = 0;
-	uint8_t *prow = p + tb + 2 * lane;
-	for (int q = 0; q < qlen; ++q) {
+	uint32_t A0[ROWL_NS], A1[ROWL_NS];
+#pragma unroll
+	for (int k = 0; k < ROWL_NS; ++k) A0[k] = A1[k] = 0;
+	uint8_t *ptile = p + 4 * tb + 8 * lane;            // (tb >> 1) * 8: the panel's first cell pair
+	for (int q0 = 0; q0 < qlen; q0 += ROW_TILE_ROWS) {
+#pragma unroll
+	for (int u = 0; u < ROW_TILE_ROWS; ++u) {
+		const int q = q0 + u;
+		if (q >= qlen) break;
 		if ((q & 63) == 0) {
 			qv = q + lane < qlen? query[q + lane] : 0;
 			if (pw > 0) {
@@ -264,15 +292,19 @@ __device__ __forceinline__ void rowl_panel(const DpConst &dc, const RowK &K, con
 #pragma unroll
 		for (int k = 0; k < ROWL_NS; ++k) {
 			if (tb + 128 * k >= tlen) break;            // (wave-uniform) sets beyond the target
-			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], KQ1[k], KQ2[k], carry_h, C1, C2, prow + 128 * k, tb + 128 * k + 2 * lane < tlen);
+			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], KQ1[k], KQ2[k], carry_h, C1, C2, (u & 1) != 0, u < 2? A0[k] : A1[k]);
 		}
 		if (!last) {
 			const int32_t he = (int32_t)__builtin_amdgcn_readlane((int)Hp[ROWL_NS - 1], 63) >> 16;     // H(tb + 511, q)
 			if (lane == 0) { colC1[q] = C1; colC2[q] = C2; colH[q] = he; }
 			if ((q & 63) == 63 || q == qlen - 1) __hip_atomic_store(&done[pw], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		prow += tstride;
 		hl_prev = hl_cur;
+	}
+#pragma unroll
+		for (int k = 0; k < ROWL_NS; ++k)
+			if (tb + 128 * k + 2 * lane < tlen) *(uint2*)(ptile + 512 * k) = make_uint2(A0[k], A1[k]);
+		ptile += 4 * tstride;
 	}
 	if (last) {
 		const int tl = tlen - 1 - tb;

@@ -190,7 +190,7 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 		qo.clear(); to.clear();
 		for (; j < reqs.size(); ++j) {
 			const DpReq &q = reqs[j];
-			const size_t pb = mm355_dp_matrix_bytes(mo, dpc, q.qlen, q.tlen, q.w, q.flag);   // (as mm355_dp_run lays it out: row-major for the row sweep)
+			const size_t pb = mm355_dp_matrix_bytes(mo, dpc, q.qlen, q.tlen, q.w, q.flag);   // (as mm355_dp_run lays it out: tiled for the row sweep)
 			if (j > i && p_tot + pb > budget) break;
 			qo.push_back((int64_t)q_tot); to.push_back((int64_t)t_tot);
 			q_tot += (size_t)(q.qlen > 0? q.qlen : 0) + 16; t_tot += (size_t)(q.tlen > 0? q.tlen : 0) + 16; p_tot += pb;
