@@ -33,13 +33,18 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	KPROF_BEGIN(bt);
 	// z[] = (f, i) for f >= min_sc, in anchor order
 	int n_z = 0;
-	for (int base = 0; base < n; base += WAVE) {
-		int i = base + lane;
-		int32_t fi = i < n? f[i] : INT32_MIN;
-		bool keep = i < n && fi >= min_sc;
-		unsigned long long mask = __ballot(keep);
-		if (keep) z[n_z + __popcll(mask & LANE_LT_MASK(lane))] = (uint64_t)(uint32_t)fi << 32 | (uint32_t)i;
-		n_z += __popcll(mask);
+	for (int base = 0; base < n; base += 4 * WAVE) {   // four independent loads in flight per step (the loop is a chain of round trips otherwise)
+		int32_t fi[4];
+#pragma unroll
+		for (int h = 0; h < 4; ++h) { const int i = base + h * WAVE + lane; fi[h] = i < n? f[i] : INT32_MIN; }
+#pragma unroll
+		for (int h = 0; h < 4; ++h) {
+			const int i = base + h * WAVE + lane;
+			const bool keep = i < n && fi[h] >= min_sc;
+			const unsigned long long mask = __ballot(keep);
+			if (keep) z[n_z + __popcll(mask & LANE_LT_MASK(lane))] = (uint64_t)(uint32_t)fi[h] << 32 | (uint32_t)i;
+			n_z += __popcll(mask);
+		}
 	}
 	__syncthreads();
 	KPROF(kp_base + 0);
@@ -54,7 +59,13 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	// the reset and collect passes of U:lchain.c::mg_chain_bk_end / mg_chain_backtrack store without chasing again; and the "already used"
 	// test of the n_z candidates is prefetched 64 at a time by the whole wave (a mark is final once it is 1, only zeros are re-read).
 	int2 *pf = (int2*)u2;
-	for (int i = lane; i < n; i += WAVE) pf[i] = make_int2(p[i] + 1, f[i]);
+	for (int base = 0; base < n; base += 4 * WAVE) {
+		int2 w4[4];
+#pragma unroll
+		for (int h = 0; h < 4; ++h) { const int i = base + h * WAVE + lane; w4[h] = i < n? make_int2(p[i] + 1, f[i]) : make_int2(0, 0); }
+#pragma unroll
+		for (int h = 0; h < 4; ++h) { const int i = base + h * WAVE + lane; if (i < n) pf[i] = w4[h]; }
+	}
 	__syncthreads();
 	KPROF(kp_base + 1);
 	uint32_t *visited = (uint32_t*)zstage;                    // 2 * Z_STAGE entries
@@ -120,16 +131,34 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	n_u = s_nu; n_v = s_nv;
 	KPROF(kp_base + 2);
 	if (n_u == 0) return;
-	// compact_a: chains written forward; then chains re-ordered by the x of their first anchor
-	// (1) per-chain start offsets into wk[].y (k<<32|i), b[] filled in forward order
-	if (lane == 0) {
-		int k = 0;
-		for (int i = 0; i < n_u; ++i) { wk[i].y = (uint64_t)(uint32_t)k << 32 | (uint32_t)i; k += (int32_t)u[i]; }
+	// compact_a: chains written forward; then chains re-ordered by the x of their first anchor.  Every step is a loop over ANCHORS, 64 at a
+	// time, whatever the chains look like (a loop over chains -- one gather round trip per chain, most lanes idle on short chains -- was a
+	// quarter of the slowest read's time: thousands of short chains on a repeat-rich read): the chain of position v is found by a prefix
+	// maximum over head marks (chain index + 1 at the first position of a chain, 0 elsewhere; z[] is dead after the walk and holds them).
+	int32_t *head = (int32_t*)z;                               // n_v entries (n_z >= n_v entries of 8 bytes are there)
+	for (int v0 = 0; v0 < n_v; v0 += WAVE) if (v0 + lane < n_v) head[v0 + lane] = 0;
+	__syncthreads();
+	// (1) per-chain start offsets into wk[].y (k<<32|i), head marks
+	for (int c0 = 0, k = 0; c0 < n_u; c0 += WAVE) {
+		const int c = c0 + lane;
+		const int32_t ni = c < n_u? (int32_t)u[c] : 0;
+		const int32_t incl = wave_incl_scan_add(ni);
+		if (c < n_u) { const int k0 = k + incl - ni; wk[c].y = (uint64_t)(uint32_t)k0 << 32 | (uint32_t)c; head[k0] = c + 1; }
+		k += __builtin_amdgcn_readlane(incl, 63);
 	}
 	__syncthreads();
-	for (int c = 0; c < n_u; ++c) {
-		const int k0 = (int)(wk[c].y >> 32), ni = (int32_t)u[c];
-		for (int j = lane; j < ni; j += WAVE) b[k0 + j] = a[vi[k0 + (ni - j - 1)]];
+	// b[] filled in forward order: position v of chain c (start k0, ni anchors) takes the walk's entry k0 + (ni - 1 - (v - k0))
+	for (int v0 = 0, carry = 0; v0 < n_v; v0 += WAVE) {
+		const int v = v0 + lane;
+		const int32_t h = v < n_v? head[v] : 0;
+		int32_t cid = wave_incl_scan_max(h);
+		cid = cid > carry? cid : carry;
+		carry = __builtin_amdgcn_readlane(cid, 63);
+		if (v < n_v) {
+			const int c = cid - 1;
+			const int k0 = (int)(wk[c].y >> 32), ni = (int32_t)u[c];
+			b[v] = a[vi[2 * k0 + ni - 1 - v]];
+		}
 	}
 	__syncthreads();
 	for (int c = lane; c < n_u; c += WAVE) wk[c].x = b[wk[c].y >> 32].x;
@@ -138,19 +167,29 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	__syncthreads();
 	// (2) final order: anchors go back into a[] region as the compacted list (written to an.a, length n_v)
 	mm128 *aout = an.a + o;
-	if (lane == 0) {
-		int k = 0;
-		for (int i = 0; i < n_u; ++i) {
-			const int j = (int)(uint32_t)wk[i].y;
-			u2[i] = u[j];
-			wk[i].x = (uint64_t)(uint32_t)k;   // destination offset
-			k += (int32_t)u[j];
-		}
+	for (int v0 = 0; v0 < n_v; v0 += WAVE) if (v0 + lane < n_v) head[v0 + lane] = 0;
+	__syncthreads();
+	for (int c0 = 0, k = 0; c0 < n_u; c0 += WAVE) {
+		const int c = c0 + lane;
+		uint64_t uj = 0;
+		if (c < n_u) uj = u[(uint32_t)wk[c].y];
+		const int32_t ni = (int32_t)uj;
+		const int32_t incl = wave_incl_scan_add(ni);
+		if (c < n_u) { const int dst = k + incl - ni; u2[c] = uj; wk[c].x = (uint64_t)(uint32_t)dst; head[dst] = c + 1; }   // destination offset
+		k += __builtin_amdgcn_readlane(incl, 63);
 	}
 	__syncthreads();
-	for (int c = 0; c < n_u; ++c) {
-		const int src = (int)(wk[c].y >> 32), dst = (int)wk[c].x, ni = (int32_t)u2[c];
-		for (int j = lane; j < ni; j += WAVE) aout[dst + j] = b[src + j];
+	for (int v0 = 0, carry = 0; v0 < n_v; v0 += WAVE) {
+		const int v = v0 + lane;
+		const int32_t h = v < n_v? head[v] : 0;
+		int32_t cid = wave_incl_scan_max(h);
+		cid = cid > carry? cid : carry;
+		carry = __builtin_amdgcn_readlane(cid, 63);
+		if (v < n_v) {
+			const int c = cid - 1;
+			const int src = (int)(wk[c].y >> 32), dst = (int)wk[c].x;
+			aout[v] = b[src + (v - dst)];
+		}
 	}
 	__syncthreads();
 	for (int c = lane; c < n_u; c += WAVE) u[c] = u2[c];
