@@ -80,49 +80,64 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 		unsigned long long todo = __ballot(cand);
 		if (todo == 0) continue;                                  // wave-uniform
 		const uint32_t zlo = (uint32_t)zk, zhi = (uint32_t)(zk >> 32);
-		if (lane == 0) {
-			while (todo) {
-				const int l = __builtin_ctzll(todo); todo &= todo - 1;
-				const int zi = (int)(uint32_t)__builtin_amdgcn_readlane((int)zlo, l);
-				const int32_t zx = (int32_t)__builtin_amdgcn_readlane((int)zhi, l);
+		while (todo) {                                            // wave-uniform: lane 0 probes, the whole wave marks
+			const int l = __builtin_ctzll(todo); todo &= todo - 1;
+			const int zi = (int)(uint32_t)__builtin_amdgcn_readlane((int)zlo, l);
+			const int32_t zx = (int32_t)__builtin_amdgcn_readlane((int)zhi, l);
+			int end_i = -1, max_i = zi, nvis = 0, q = 0;
+			int32_t max_s = 0;
+			int over = 0, skip = 0;
+			if (lane == 0) {
 				int2 w = pf[zi];
-				if (PF_MARK(w) != 0) continue;
-				// mg_chain_bk_end
-				int i = zi, end_i, max_i = zi, nvis = 0, q = 0;
-				int32_t max_s = 0;
-				bool over = false;
-				for (;;) {
-					pf[i].x = w.x | (int)(2u << 30);                      // t[i] = 2
-					if (nvis < VCAP) visited[nvis] = (uint32_t)i; else over = true;
-					++nvis;
-					end_i = i = PF_P(w);
-					int32_t sv = zx;
-					if (i >= 0) { w = pf[i]; sv = zx - w.y; }
-					if (sv > max_s) { max_s = sv; max_i = i; q = nvis; }
-					else if (max_s - sv > max_drop) break;
-					if (i < 0 || PF_MARK(w) != 0) break;
-				}
-				const int n_v0 = n_v;
-				if (!over) {   // marks: the first q visited nodes join the chain (1), the others are released (0)
-					for (int t = 0; t < nvis; ++t) {
-						const uint32_t vn = visited[t];
-						const uint32_t keep = t < q? 1u : 0u;
-						pf[vn].x = (int)(((uint32_t)pf[vn].x & 0x3fffffffu) | keep << 30);
-						if (keep) vi[n_v++] = (int)vn;
+				if (PF_MARK(w) != 0) skip = 1;
+				else {   // mg_chain_bk_end
+					int i = zi;
+					for (;;) {
+						pf[i].x = w.x | (int)(2u << 30);                      // t[i] = 2
+						if (nvis < VCAP) visited[nvis] = (uint32_t)i; else over = 1;
+						++nvis;
+						end_i = i = PF_P(w);
+						int32_t sv = zx;
+						if (i >= 0) { w = pf[i]; sv = zx - w.y; }
+						if (sv > max_s) { max_s = sv; max_i = i; q = nvis; }
+						else if (max_s - sv > max_drop) break;
+						if (i < 0 || PF_MARK(w) != 0) break;
 					}
-				} else {       // a probe longer than the LDS list: the reference's two passes, chasing again
-					for (i = zi; i >= 0 && i != end_i; i = PF_P(pf[i])) pf[i].x = (int)((uint32_t)pf[i].x & 0x3fffffffu);
-					for (i = zi; i != max_i; i = PF_P(pf[i])) { vi[n_v++] = i; pf[i].x = (int)(((uint32_t)pf[i].x & 0x3fffffffu) | 1u << 30); }
 				}
-				const int32_t sc = q > 0? max_s : 0;
-				if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt)
-					u[n_u++] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)(n_v - n_v0);
-				else n_v = n_v0;
 			}
-			s_nu = n_u; s_nv = n_v;
+			skip = __builtin_amdgcn_readfirstlane(skip);
+			if (skip) continue;
+			nvis = __builtin_amdgcn_readfirstlane(nvis); q = __builtin_amdgcn_readfirstlane(q); over = __builtin_amdgcn_readfirstlane(over);
+			end_i = __builtin_amdgcn_readfirstlane(end_i); max_i = __builtin_amdgcn_readfirstlane(max_i); max_s = __builtin_amdgcn_readfirstlane(max_s);
+			const int n_v0 = n_v;
+			if (!over) {
+				// marks: the first q visited nodes join the chain (1), the others are released (0).  The word of a visited node needs no load:
+				// its p is the next node of the list (the probe followed p), the last one's is the node the probe stopped at -- so this pass is
+				// stores only, 64 nodes at a time (it used to be one load-modify-store round trip per node by lane 0: half of the walk's time)
+				for (int t = lane; t < nvis; t += WAVE) {
+					const uint32_t vn = visited[t];
+					const int nxt = t + 1 < nvis? (int)visited[t + 1] : end_i;
+					const uint32_t keep = t < q? 1u : 0u;
+					pf[vn].x = (int)((uint32_t)(nxt + 1) | keep << 30);
+					if (keep) vi[n_v0 + t] = (int)vn;
+				}
+				n_v = n_v0 + q;
+			} else {       // a probe longer than the LDS list: the reference's two passes, chasing again
+				int nv2 = n_v;
+				if (lane == 0) {
+					int i;
+					for (i = zi; i >= 0 && i != end_i; i = PF_P(pf[i])) pf[i].x = (int)((uint32_t)pf[i].x & 0x3fffffffu);
+					for (i = zi; i != max_i; i = PF_P(pf[i])) { vi[nv2++] = i; pf[i].x = (int)(((uint32_t)pf[i].x & 0x3fffffffu) | 1u << 30); }
+				}
+				n_v = __builtin_amdgcn_readfirstlane(nv2);
+			}
+			const int32_t sc = q > 0? max_s : 0;
+			if (sc >= min_sc && n_v > n_v0 && n_v - n_v0 >= min_cnt) {
+				if (lane == 0) u[n_u] = (uint64_t)(uint32_t)sc << 32 | (uint32_t)(n_v - n_v0);
+				++n_u;
+			} else n_v = n_v0;
 		}
 		__syncthreads();
-		n_u = s_nu; n_v = s_nv;
 	}
 #undef PF_P
 #undef PF_MARK
