@@ -53,11 +53,10 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws);
 	if (lane == 0 && n_z > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
 	__syncthreads();
-	// The walk below is a pointer chase (one lane): every step used to be two dependent HBM/L2 round trips (p[i], then f and the mark of
-	// the node it points to).  All three now sit in ONE 8-byte word per anchor -- pf[i] = { (p + 1) | mark << 30, f } in the u2[] region,
-	// free between the two sorts -- so a step is one load; the nodes a probe visits are remembered in LDS (the sort stage, idle here), so
-	// the reset and collect passes of U:lchain.c::mg_chain_bk_end / mg_chain_backtrack store without chasing again; and the "already used"
-	// test of the n_z candidates is prefetched 64 at a time by the whole wave (a mark is final once it is 1, only zeros are re-read).
+	// The walk below is a pointer chase: p, f and the mark of a node sit in ONE 8-byte word per anchor -- pf[i] = { (p + 1) | mark << 30, f }
+	// in the u2[] region, free between the two sorts; the nodes a probe visits are remembered in LDS (the sort stage, idle here), so the
+	// collect pass of U:lchain.c::mg_chain_backtrack stores without chasing again; and the "already used" test of the n_z candidates is
+	// prefetched 64 at a time by the whole wave (a mark is final once it is 1, only zeros are re-read).
 	int2 *pf = (int2*)u2;
 	for (int base = 0; base < n; base += 4 * WAVE) {
 		int2 w4[4];
@@ -80,55 +79,54 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 		unsigned long long todo = __ballot(cand);
 		if (todo == 0) continue;                                  // wave-uniform
 		const uint32_t zlo = (uint32_t)zk, zhi = (uint32_t)(zk >> 32);
-		while (todo) {                                            // wave-uniform: lane 0 probes, the whole wave marks
+		while (todo) {                                            // wave-uniform: a scalar probe on a register window, the whole wave marks
 			const int l = __builtin_ctzll(todo); todo &= todo - 1;
 			const int zi = (int)(uint32_t)__builtin_amdgcn_readlane((int)zlo, l);
 			const int32_t zx = (int32_t)__builtin_amdgcn_readlane((int)zhi, l);
-			int end_i = -1, max_i = zi, nvis = 0, q = 0;
+			// mg_chain_bk_end as WAVE-UNIFORM code.  p[i] < i and a chain's next anchor is almost always a few entries back in the x-sorted
+			// array, so the wave keeps a window of 64 words pf[wbase - lane] in two registers (one coalesced load) and the probe reads its next
+			// node with v_readlane (tens of cycles) instead of a dependent global load (hundreds); only a hop of more than 63 entries
+			// reloads the window.  The reference's t[i] = 2 marks are dropped: indices strictly decrease along a probe, so it can never meet a
+			// node it marked itself, and every 2 is reset (or becomes 1) before anybody else looks -- the probe stores nothing to HBM, a window
+			// loaded at its start is fresh for its whole length (marks only change in the pass below).
+			int wbase = zi, Wx, Wy;
+			{ const int idx = wbase - lane; const int2 t = idx >= 0? pf[idx] : make_int2(0, 0); Wx = t.x; Wy = t.y; }
+			int2 w = make_int2(__builtin_amdgcn_readlane(Wx, 0), __builtin_amdgcn_readlane(Wy, 0));
+			if (PF_MARK(w) != 0) continue;
+			int i = zi, end_i = -1, max_i = zi, nvis = 0, q = 0, vreg = 0;
 			int32_t max_s = 0;
-			int over = 0, skip = 0;
-			if (lane == 0) {
-				int2 w = pf[zi];
-				if (PF_MARK(w) != 0) skip = 1;
-				else {   // mg_chain_bk_end
-					int i = zi;
-					for (;;) {
-						pf[i].x = w.x | (int)(2u << 30);                      // t[i] = 2
-						if (nvis < VCAP) visited[nvis] = (uint32_t)i; else over = 1;
-						++nvis;
-						end_i = i = PF_P(w);
-						int32_t sv = zx;
-						if (i >= 0) { w = pf[i]; sv = zx - w.y; }
-						if (sv > max_s) { max_s = sv; max_i = i; q = nvis; }
-						else if (max_s - sv > max_drop) break;
-						if (i < 0 || PF_MARK(w) != 0) break;
-					}
+			for (;;) {
+				vreg = lane == (nvis & 63)? i : vreg;                      // visited list: 64 nodes in a register, then one LDS store
+				if ((nvis & 63) == 63) { const int b0 = nvis & ~63; if (b0 < VCAP) visited[b0 + lane] = (uint32_t)vreg; }
+				++nvis;
+				end_i = i = PF_P(w);
+				int32_t sv = zx;
+				if (i >= 0) {
+					if (wbase - i > 63) { wbase = i; const int idx = wbase - lane; const int2 t = idx >= 0? pf[idx] : make_int2(0, 0); Wx = t.x; Wy = t.y; }
+					w = make_int2(__builtin_amdgcn_readlane(Wx, wbase - i), __builtin_amdgcn_readlane(Wy, wbase - i));
+					sv = zx - w.y;
 				}
+				if (sv > max_s) { max_s = sv; max_i = i; q = nvis; }
+				else if (max_s - sv > max_drop) break;
+				if (i < 0 || PF_MARK(w) != 0) break;
 			}
-			skip = __builtin_amdgcn_readfirstlane(skip);
-			if (skip) continue;
-			nvis = __builtin_amdgcn_readfirstlane(nvis); q = __builtin_amdgcn_readfirstlane(q); over = __builtin_amdgcn_readfirstlane(over);
-			end_i = __builtin_amdgcn_readfirstlane(end_i); max_i = __builtin_amdgcn_readfirstlane(max_i); max_s = __builtin_amdgcn_readfirstlane(max_s);
+			if (nvis & 63) { const int b0 = nvis & ~63; if (b0 < VCAP && lane < (nvis & 63)) visited[b0 + lane] = (uint32_t)vreg; }
+			const bool over = nvis > VCAP;
 			const int n_v0 = n_v;
 			if (!over) {
-				// marks: the first q visited nodes join the chain (1), the others are released (0).  The word of a visited node needs no load:
-				// its p is the next node of the list (the probe followed p), the last one's is the node the probe stopped at -- so this pass is
-				// stores only, 64 nodes at a time (it used to be one load-modify-store round trip per node by lane 0: half of the walk's time)
-				for (int t = lane; t < nvis; t += WAVE) {
+				// marks: the first q visited nodes join the chain (1); the others keep their 0.  The word of a node needs no load: its p is the
+				// next node of the list (the probe followed p), the last one's is the node the probe stopped at -- stores only, 64 nodes at a time
+				for (int t = lane; t < q; t += WAVE) {
 					const uint32_t vn = visited[t];
 					const int nxt = t + 1 < nvis? (int)visited[t + 1] : end_i;
-					const uint32_t keep = t < q? 1u : 0u;
-					pf[vn].x = (int)((uint32_t)(nxt + 1) | keep << 30);
-					if (keep) vi[n_v0 + t] = (int)vn;
+					pf[vn].x = (int)((uint32_t)(nxt + 1) | 1u << 30);
+					vi[n_v0 + t] = (int)vn;
 				}
 				n_v = n_v0 + q;
-			} else {       // a probe longer than the LDS list: the reference's two passes, chasing again
+			} else {       // a probe longer than the LDS list: chase again (one lane)
 				int nv2 = n_v;
-				if (lane == 0) {
-					int i;
-					for (i = zi; i >= 0 && i != end_i; i = PF_P(pf[i])) pf[i].x = (int)((uint32_t)pf[i].x & 0x3fffffffu);
-					for (i = zi; i != max_i; i = PF_P(pf[i])) { vi[nv2++] = i; pf[i].x = (int)(((uint32_t)pf[i].x & 0x3fffffffu) | 1u << 30); }
-				}
+				if (lane == 0)
+					for (int k = zi; k != max_i; k = PF_P(pf[k])) { vi[nv2++] = k; pf[k].x = (int)(((uint32_t)pf[k].x & 0x3fffffffu) | 1u << 30); }
 				n_v = __builtin_amdgcn_readfirstlane(nv2);
 			}
 			const int32_t sc = q > 0? max_s : 0;
