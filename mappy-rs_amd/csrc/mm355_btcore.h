@@ -33,6 +33,7 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	KPROF_BEGIN(bt);
 	// z[] = (f, i) for f >= min_sc, in anchor order
 	int n_z = 0;
+	int32_t f_top = 0;                                         // largest score of the list (of this lane; reduced below)
 	for (int base = 0; base < n; base += 4 * WAVE) {   // four independent loads in flight per step (the loop is a chain of round trips otherwise)
 		int32_t fi[4];
 #pragma unroll
@@ -42,7 +43,7 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 			const int i = base + h * WAVE + lane;
 			const bool keep = i < n && fi[h] >= min_sc;
 			const unsigned long long mask = __ballot(keep);
-			if (keep) z[n_z + __popcll(mask & LANE_LT_MASK(lane))] = (uint64_t)(uint32_t)fi[h] << 32 | (uint32_t)i;
+			if (keep) { z[n_z + __popcll(mask & LANE_LT_MASK(lane))] = (uint64_t)(uint32_t)fi[h] << 32 | (uint32_t)i; f_top = fi[h] > f_top? fi[h] : f_top; }
 			n_z += __popcll(mask);
 		}
 	}
@@ -50,7 +51,10 @@ __device__ inline void wave_backtrack_read(const DevParams &pr, const DevBatch &
 	KPROF(kp_base + 0);
 	if (n_z == 0) return;
 	WalkScratch ws; ws.out = u2; ws.fpos = (uint32_t*)vi; ws.rank = (uint32_t*)(an.v + o); ws.flab = t8; ws.tcnt = 0;   // v[] is dead after the DP fill
-	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws);
+	// (the scores are small positive numbers: the levels above their highest byte would be six histogram passes over the list for nothing)
+	f_top = wave_reduce_max(f_top);
+	const int z_s0 = min_sc < 0? 24 : f_top > 0? ((31 - __builtin_clz((unsigned)f_top)) >> 3) << 3 : 0;   // (a negative threshold lets negative scores in: all four bytes)
+	wave_radix_sort(z, (uint32_t)n_z, key_hi32(), &L, zstage, (uint32_t)Z_STAGE, &ws, z_s0);
 	if (lane == 0 && n_z > MM355_RS_MIN_SIZE && L.overflow) *err = 1;
 	__syncthreads();
 	// The walk below is a pointer chase: p, f and the mark of a node sit in ONE 8-byte word per anchor -- pf[i] = { (p + 1) | mark << 30, f }

@@ -148,6 +148,7 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 	__shared__ uint32_t tw[RQ_TW];
 	__shared__ uint64_t rx[RQ_RING], ryy[RQ_RING];
 	__shared__ int32_t rf[RQ_RING], rpp[RQ_RING];
+	__shared__ int32_t rbad[RQ_RING];                        // number of anchors k' <= k with y[k'] < y[k' - 1] (a ring like rx / ryy)
 	__shared__ double wpri[RQ_WRING];
 	__shared__ int32_t wy[RQ_WRING];
 	__shared__ double bpri[RQ_NB];
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 	RQ_SYNC();
 	KPROF(17);
 	int i0 = 0, st = 0, st_in = 0;
+	int32_t bad_tot = 0, y_before = INT32_MIN;               // descents so far; y of the anchor in front of the current chunk
 	uint64_t x_i0 = 0, cx = 0, cy = 0;
 	int32_t clb = 0, clbi = 0;
 	unsigned long long n_scan = 0;
@@ -205,6 +207,18 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 				const mm128 t = a[i + lane]; cx = t.x; cy = t.y;
 				clb = rq_ld32(lb_out + i + lane); clbi = rq_ld32(lbi_out + i + lane);
 				rx[(i + lane) & RQ_RMASK] = cx; ryy[(i + lane) & RQ_RMASK] = cy;
+			}
+			{   // ... with the running count of descents of y in index order: a window without one is ascending in y, and the inner walk over
+				// it needs neither the order check nor the candidates behind its stopping point
+				const int32_t y32 = (int32_t)cy;
+				int32_t yp = __builtin_amdgcn_update_dpp(0, y32, 0x138, 0xf, 0xf, false);   // wave_shr:1
+				if (lane == 0) yp = y_before;
+				const int32_t bad = (i + lane < n && y32 < yp)? 1 : 0;
+				const int32_t incl = bad_tot + wave_incl_scan_add(bad);
+				if (i + lane < n) rbad[(i + lane) & RQ_RMASK] = incl;
+				bad_tot = __builtin_amdgcn_readlane(incl, 63);
+				const int last = n - i < WAVE? n - i - 1 : WAVE - 1;
+				y_before = __builtin_amdgcn_readlane(y32, last);
 			}
 			if (i > 0) {   // ... and the block of 64 anchors that has just been finished gets its summary
 				const int jb = i - WAVE + lane;
@@ -312,19 +326,22 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 					// larger y would have been met earlier by the reference)
 					const RqWalk w_saved = w;
 					int32_t carry = INT32_MAX; bool sortit = false, stopped = false;
+					const bool ascending = rbad[(i0 - 1) & RQ_RMASK] == rbad[st_in & RQ_RMASK];   // no k in (st_in, i0) with y[k] < y[k - 1]: the proof below in O(1)
 					for (int jb = i0 - 1; jb >= st_in; jb -= WAVE) {
 						const int jj = jb - lane;
 						bool in = false, valid = false; int32_t sc2 = 0, pj = -1, y2 = 0;
 						uint64_t yj = 0;
 						if (jj >= st_in) { yj = ryy[jj & RQ_RMASK]; y2 = (int32_t)yj; in = y2 >= y_lo && y2 < yi32; }
-						const int32_t neg = in? -y2 : INT32_MIN;                      // prefix minimum of y = - prefix maximum of -y
-						int32_t pmn = wave_excl_prefix_max(neg, lane);
-						pmn = pmn == INT32_MIN? INT32_MAX : -pmn;
-						pmn = pmn < carry? pmn : carry;
-						if (__ballot(in && y2 > pmn)) { sortit = true; break; }
-						const int32_t cm = wave_reduce_max(neg);
-						if (cm != INT32_MIN && -cm < carry) carry = -cm;
-						if (stopped) continue;
+						if (!ascending) {
+							const int32_t neg = in? -y2 : INT32_MIN;                      // prefix minimum of y = - prefix maximum of -y
+							int32_t pmn = wave_excl_prefix_max(neg, lane);
+							pmn = pmn == INT32_MIN? INT32_MAX : -pmn;
+							pmn = pmn < carry? pmn : carry;
+							if (__ballot(in && y2 > pmn)) { sortit = true; break; }
+							const int32_t cm = wave_reduce_max(neg);
+							if (cm != INT32_MIN && -cm < carry) carry = -cm;
+						}
+						if (stopped) { if (ascending) break; continue; }
 						if (in) {
 							bool ex2; int32_t width2;
 							sc2 = rf[jj & RQ_RMASK] + rq_comput_sc(xi, yi, rx[jj & RQ_RMASK], yj, pen_gap, pen_skip, &ex2, &width2);

@@ -217,13 +217,16 @@ __device__ void wave_rs_core(T *a, uint32_t n0, int s0, Key key, SortLds *L, T *
 }
 
 template <typename T, typename Key>
-__device__ void wave_radix_sort(T *a, uint32_t n, Key key, SortLds *L, T *stage, uint32_t stage_cap, const WalkScratch *ws = 0)
+__device__ void wave_radix_sort(T *a, uint32_t n, Key key, SortLds *L, T *stage, uint32_t stage_cap, const WalkScratch *ws = 0, int s0 = 56)
 {
+	// s0 < 56: the caller knows that no key has a bit at or above s0 + 8.  A level on which every key has the same digit is the identity
+	// (one bucket holds everything, rs_sort's cycle-leader pass moves nothing and recurses into that bucket), so starting below such
+	// levels gives the same array -- and saves a histogram pass over all n keys per level (chain scores: six of eight levels).
 	if (n <= 1) return;
 	if (n <= MM355_RS_MIN_SIZE) { wave_rank_sort_small(a, n, key); return; }
 	if ((threadIdx.x & 63) == 0) { L->stk_n = 0; L->overflow = 0; }
 	__syncthreads();
-	wave_rs_core<true>(a, n, 56, key, L, stage, stage_cap, ws);
+	wave_rs_core<true>(a, n, s0, key, L, stage, stage_cap, ws);
 }
 
 // Cross-lane scans and reductions by DPP register moves (row_shr / row_bcast): ~12 VALU operations, no LDS crossbar round trips
