@@ -995,6 +995,7 @@ int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob 
 		sc.q = (int8_t)mo->q; sc.e = (int8_t)mo->e;
 	}
 	Mm355ExtraJob *d_segs = c->x_jobs.as<Mm355ExtraJob>();
+	const double tx0 = mm355_now_ms();
 	int64_t *d_first = (int64_t*)((char*)c->x_jobs.p + seg_b);
 	Mm355ExtraSegOut *d_so = c->x_out.as<Mm355ExtraSegOut>();
 	Mm355ExtraOut *d_ro = (Mm355ExtraOut*)(d_so + n_segs + 1);
@@ -1010,6 +1011,8 @@ int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob 
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(c->h_xout.p, d_ro, n_regions * sizeof(Mm355ExtraOut), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
+	const double tx1 = mm355_now_ms();
+	mm355_trace_add(c, "x:walk", tx0, tx1);
 	const Mm355ExtraOut *ho = (const Mm355ExtraOut*)c->h_xout.p;
 	if (want) {
 		size_t tot = 0;
@@ -1019,6 +1022,7 @@ int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob 
 		HIPCHK(hipGetLastError());
 		if (tot) HIPCHK(hipMemcpyAsync(c->h_xcs.p, c->x_dense.p, tot, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(mm355_wait_stream(c->st));
+		mm355_trace_add(c, "x:strings", tx1, mm355_now_ms());
 		*cs = (const char*)c->h_xcs.p;
 	}
 	*out = ho;

@@ -431,11 +431,11 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 			});
 			const Mm355ExtraOut *xo = 0; const char *xcs = 0;
 			const int want_cs = flags & (MM355_OUT_CS | MM355_OUT_MD);
-			ms_host += now_ms() - tx0;
+			ms_host += now_ms() - tx0; trace_add(c, "x:fill", tx0, now_ms());
 			if ((rc = mm355_extra_run(c, mo, xsegs, (size_t)tg, xfirst, (size_t)tr, xcig, (size_t)tc, (size_t)ts, want_cs, &xo, &xcs))) return rc;
 			const double tx1 = now_ms();
 			parallel_for(n_reads, nt, [&](int64_t i, int) { if (xr[i + 1] > xr[i]) mm355_glue_extra_apply(rs[i], xo + xr[i], xcs, want_cs); });
-			ms_host += now_ms() - tx1;
+			ms_host += now_ms() - tx1; trace_add(c, "x:apply", tx1, now_ms());
 		}
 		tv_extra = now_ms() - tx0; trace_add(c, "extra", tx0, now_ms());
 	}
