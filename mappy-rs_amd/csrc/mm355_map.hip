@@ -168,6 +168,25 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 static int host_threads() { return HostPool::get().size(); }
 
 static int host_threads();
+// Deferred destruction of a batch's host state: one background thread frees what the mapping threads are done with (the process never joins
+// it: it only ever frees memory).  At most a few batches are pending; bury() frees synchronously when the queue is long (memory bound).
+struct Reaper {
+	struct Item { virtual ~Item() {} };
+	std::mutex m; std::condition_variable cv; std::vector<Item*> q;
+	static Reaper &get() { static Reaper *r = [] { Reaper *x = new Reaper(); std::thread([x] { x->loop(); }).detach(); return x; }(); return *r; }
+	void bury(Item *it) {
+		{ std::unique_lock<std::mutex> lk(m); if (q.size() < 16) { q.push_back(it); it = 0; } }
+		if (it) delete it; else cv.notify_one();
+	}
+	void loop() {
+		for (;;) {
+			std::vector<Item*> mine;
+			{ std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return !q.empty(); }); mine.swap(q); }
+			for (Item *it : mine) delete it;
+		}
+	}
+};
+
 static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<ReadState> &rs, const std::vector<DpReq> &reqs, std::vector<std::vector<uint32_t>> &arenas)
 {
 	// chunk the requests so that the direction matrices of one launch fit the HBM budget
@@ -315,6 +334,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	const bool verbose = getenv("MM355_VERBOSE") != 0;
 	const bool rmq_chain = (mo->flag & MMF_RMQ) != 0;
 	double tv0 = now_ms(), tv_front, tv_pack, tv_pre, tv_steps = 0, tv_dp = 0, tv_fin, tv_asm, tv_extra = 0;
+	trace_add(c, "prolog", t_start, tv0);
 	{
 		double ts = now_ms();
 #define FRONT_STAGE(name, call) do { if ((rc = (call))) return rc; if (g_trace_path) { const double te = now_ms(); trace_add(c, name, ts, te); ts = te; } } while (0)
@@ -481,6 +501,15 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	if (verbose) mm355_prof_dump(n_reads);
 	if (verbose) mm355_kprof_dump(c);
 	*out = H;
+	{   // the per-read host state (a dozen heap blocks per read: 20 ms of free() per 6144-read sub-batch, MM355_TRACE "teardown") is handed to the
+		// reaper thread instead of being destroyed behind the return on this thread's critical path
+		const double td = now_ms();
+		struct Grave : Reaper::Item { std::vector<ReadState> rs; std::vector<std::vector<mm355_hit_t>> rh; std::vector<std::vector<uint32_t>> rc, ar; std::vector<std::string> st; };
+		Grave *g = new Grave();
+		g->rs.swap(rs); g->rh.swap(rh); g->rc.swap(rc_); g->st.swap(rstr); g->ar.swap(arenas);
+		Reaper::get().bury(g);
+		trace_add(c, "teardown", td, now_ms());
+	}
 	return 0;
 }
 
