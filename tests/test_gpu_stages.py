@@ -91,6 +91,27 @@ def test_chains_parity(world):
     assert n_multi > 0
 
 
+def test_chains_parity_long_probes(world):
+    """mg_chain_backtrack on chains of more than 4096 anchors: the probe outruns the LDS list of visited nodes (the chase-again path of
+    k_backtrack), its register window is reloaded many times, compact_a copies tens of thousands of anchors of one chain"""
+    g = world["genome"]
+    rng = np.random.default_rng(17)
+    comp = lambda c: np.where(c < 4, 3 - c, 4).astype(np.uint8)[::-1]
+    reads = [S.codes_to_str(S.mutate(g[0][1000:121000], rng, 0.01, 0.005, 0.005)),
+             S.codes_to_str(S.mutate(comp(g[0][150000:215000]), rng, 0.02, 0.01, 0.01)),
+             S.codes_to_str(S.mutate(g[1][20000:70000], rng, 0.03, 0.015, 0.015))]
+    got = world["sr"].chains(reads)
+    longest = 0
+    for i, rd in enumerate(reads):
+        u, a = got[i]
+        ea, _, _, _ = world["orc"].anchors(rd, sorted_=True)
+        eu, eb = world["orc"].chains(ea, len(rd))
+        assert np.array_equal(u, eu), i
+        assert np.array_equal(a, eb), i
+        longest = max(longest, max(int(x) & 0xffffffff for x in eu))
+    assert longest > 4096, longest
+
+
 def _sv_reads(g, rng, n_each=10):
     """reads whose chains mg_lchain_dp (bw 500) cannot join: a 1.5 - 6 kb deletion, an inserted block, a chimera of two loci"""
     comp = lambda c: np.where(c < 4, 3 - c, 4).astype(np.uint8)[::-1]
