@@ -272,35 +272,35 @@ __device__ __forceinline__ void rowl_panel(const DpConst &dc, const RowK &K, con
 	uint8_t *ptile = p + 4 * tb + 8 * lane;            // (tb >> 1) * 8: the panel's first cell pair
 	for (int q0 = 0; q0 < qlen; q0 += ROW_TILE_ROWS) {
 #pragma unroll
-	for (int u = 0; u < ROW_TILE_ROWS; ++u) {
-		const int q = q0 + u;
-		if (q >= qlen) break;
-		if ((q & 63) == 0) {
-			qv = q + lane < qlen? query[q + lane] : 0;
-			if (pw > 0) {
-				const int need = q + 64 < qlen? q + 64 : qlen;
-				while (__hip_atomic_load(&done[pw - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
-				if (q + lane < qlen) { vC1 = colC1[q + lane]; vC2 = colC2[q + lane]; vH = colH[q + lane]; }
+		for (int u = 0; u < ROW_TILE_ROWS; ++u) {
+			const int q = q0 + u;
+			if (q >= qlen) break;
+			if ((q & 63) == 0) {
+				qv = q + lane < qlen? query[q + lane] : 0;
+				if (pw > 0) {
+					const int need = q + 64 < qlen? q + 64 : qlen;
+					while (__hip_atomic_load(&done[pw - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+					if (q + lane < qlen) { vC1 = colC1[q + lane]; vC2 = colC2[q + lane]; vH = colH[q + lane]; }
+				}
 			}
-		}
-		const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
-		const uint32_t qc2 = qc | qc << 16;
-		int32_t C1, C2, hl_cur;
-		if (pw == 0) { hl_cur = row_hb(q, dc); C1 = row_dbl(hl_cur - dc.e); C2 = row_dbl(hl_cur - dc.e2); }      // the k = -1 term: a gap opened at the left border (carries travel doubled, also through LDS)
-		else { C1 = __builtin_amdgcn_readlane(vC1, q & 63); C2 = __builtin_amdgcn_readlane(vC2, q & 63); hl_cur = __builtin_amdgcn_readlane(vH, q & 63); }
-		uint32_t carry_h = pk2(0, hl_prev);
+			const uint32_t qc = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 63);
+			const uint32_t qc2 = qc | qc << 16;
+			int32_t C1, C2, hl_cur;
+			if (pw == 0) { hl_cur = row_hb(q, dc); C1 = row_dbl(hl_cur - dc.e); C2 = row_dbl(hl_cur - dc.e2); }      // the k = -1 term: a gap opened at the left border (carries travel doubled, also through LDS)
+			else { C1 = __builtin_amdgcn_readlane(vC1, q & 63); C2 = __builtin_amdgcn_readlane(vC2, q & 63); hl_cur = __builtin_amdgcn_readlane(vH, q & 63); }
+			uint32_t carry_h = pk2(0, hl_prev);
 #pragma unroll
-		for (int k = 0; k < ROWL_NS; ++k) {
-			if (tb + 128 * k >= tlen) break;            // (wave-uniform) sets beyond the target
-			row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], KQ1[k], KQ2[k], carry_h, C1, C2, (u & 1) != 0, u < 2? A0[k] : A1[k]);
+			for (int k = 0; k < ROWL_NS; ++k) {
+				if (tb + 128 * k >= tlen) break;            // (wave-uniform) sets beyond the target
+				row_set<RIGHT>(K, dmis, any_n, qc2, Hp[k], Fp[k], F2p[k], TQ[k], KE1[k], KE2[k], KQ1[k], KQ2[k], carry_h, C1, C2, (u & 1) != 0, u < 2? A0[k] : A1[k]);
+			}
+			if (!last) {
+				const int32_t he = (int32_t)__builtin_amdgcn_readlane((int)Hp[ROWL_NS - 1], 63) >> 16;     // H(tb + 511, q)
+				if (lane == 0) { colC1[q] = C1; colC2[q] = C2; colH[q] = he; }
+				if ((q & 63) == 63 || q == qlen - 1) __hip_atomic_store(&done[pw], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+			hl_prev = hl_cur;
 		}
-		if (!last) {
-			const int32_t he = (int32_t)__builtin_amdgcn_readlane((int)Hp[ROWL_NS - 1], 63) >> 16;     // H(tb + 511, q)
-			if (lane == 0) { colC1[q] = C1; colC2[q] = C2; colH[q] = he; }
-			if ((q & 63) == 63 || q == qlen - 1) __hip_atomic_store(&done[pw], q + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
-		hl_prev = hl_cur;
-	}
 #pragma unroll
 		for (int k = 0; k < ROWL_NS; ++k)
 			if (tb + 128 * k + 2 * lane < tlen) *(uint2*)(ptile + 512 * k) = make_uint2(A0[k], A1[k]);
