@@ -154,20 +154,24 @@ typedef struct {
 	double ms_dp_group[24];
 	int64_t dp_cells_group[24], n_launch_group[24];
 	int64_t n_ext_rounds;                        /* extension rounds of the last call (the reference has no bound on them) */
-	int64_t n_sort_fast_reads, n_sort_tie_reads; /* anchor sort: reads sorted by the segmented radix sort / of those, reads with equal keys
-	                                                whose equal-key runs went through the literal radix_sort_128x emulation */
+	int64_t n_sort_fast_reads, n_sort_tie_reads; /* anchor sort: reads of anchor-rich batches (cull + per-read LDS sort) / of those, reads whose surviving
+	                                                anchors contain equal keys and went through the literal radix_sort_128x emulation */
 	/* mg_lchain_rmq on the device (row a9): kernel time, reads re-chained there, reads handed to the literal host implementation because the
 	 * device could not prove its range-minimum answer unique (or ran out of LDS capacity), window elements looked at */
 	double ms_rmq;
 	int64_t n_rmq_reads, n_rmq_host, rmq_scanned;
 	double host_cpu_ms;                          /* CPU time (not wall) the host tail of the last call spent, summed over the pool threads */
+	int64_t n_a_kept;                            /* anchors left after the cull of the anchor-rich sort path (x-components too small to chain dropped);
+	                                                0 when the batch took the literal path for every read */
 } mm355_stats_t;
 
 /* sketch: minimizers of each read (mm_sketch). mz_off[n_reads+1] host array is filled; mz = (x,y) pairs */
 int mm355_stage_sketch(mm355_ctx_t *ctx, int64_t n_reads, const char *const *seqs, const int32_t *lens,
                        int64_t *mz_off, uint64_t *mz, int64_t mz_cap);
 /* seeds: sketch + mm_seed_mz_flt + mm_collect_matches + collect_seed_hits; anchors in generation order
- * (sorted = 0) or after the radix_sort_128x emulation (sorted = 1). */
+ * (sorted = 0), after the radix_sort_128x emulation (sorted = 1: the reference's whole sorted array) or as the mapping path hands them
+ * to the chainer (sorted = 2: anchor-rich batches drop the x-components that are too small to chain, see mm355_cullsort.hip; a_off
+ * then describes the shorter arrays). */
 int mm355_stage_anchors(mm355_ctx_t *ctx, const mm355_mapopt_t *mo, int64_t n_reads, const char *const *seqs,
                         const int32_t *lens, int sorted, int64_t *a_off, uint64_t *a, int64_t a_cap,
                         int32_t *rep_len, int32_t *n_mini_pos);

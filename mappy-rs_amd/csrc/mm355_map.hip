@@ -341,7 +341,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		FRONT_STAGE("f:sketch", mm355_run_sketch(c));      // (asynchronous: its time shows up in the next stage's wait)
 		FRONT_STAGE("f:seeds", mm355_run_seeds(c, pr));
 		FRONT_STAGE("f:expand", mm355_run_expand(c, pr));
-		FRONT_STAGE("f:sort", mm355_run_sort(c));
+		FRONT_STAGE("f:sort", mm355_run_sort(c, pr));
 		if (rmq_chain) FRONT_STAGE("f:chain", mm355_run_chain_skip(c));   // asm presets: mg_lchain_rmq is the primary chainer (next stage)
 		else {
 			FRONT_STAGE("f:chain", mm355_run_chain(c, pr));

@@ -291,13 +291,13 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 {
 	if (c == 0) return;
 	(void)hipSetDevice(c->dev);
-	DBuf *bufs[] = { &c->sort_tasks, &c->sort_tmp, &c->sort_flag, &c->tie_list, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
+	DBuf *bufs[] = { &c->sort_tasks, &c->sort_flag, &c->tie_list, &c->n_keep, &c->aoff2, &c->cs_list, &c->tie_a, &c->tie_b, &c->tie_f, &c->tie_p, &c->tie_t8, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
 		&c->kprof, &c->d_chunks, &c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack, &c->rmq_list, &c->rmq_flag, &c->x_jobs, &c->x_cig, &c->x_cs, &c->x_out, &c->x_dense };
 	for (DBuf *b : bufs) b->release();
 	for (ResidentBatch &r : c->slots) { r.seq.release(); r.roff.release(); r.rlen.release(); r.order.release(); r.ck_read.release(); r.ck_start.release(); r.ck_r0.release(); }
-	c->h_rmq.release(); c->h_xjobs.release(); c->h_xcig.release(); c->h_xout.release(); c->h_xcs.release(); c->h_tasks.release(); c->h_chunks.release(); c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
+	c->h_cs.release(); c->h_rmq.release(); c->h_xjobs.release(); c->h_xcig.release(); c->h_xout.release(); c->h_xcs.release(); c->h_tasks.release(); c->h_chunks.release(); c->h_res.release(); c->h_jobs.release(); c->h_gather.release(); c->h_ids.release(); for (int i = 0; i < 8; ++i) c->h_arena[i].release(); c->h_cig.release(); c->h_pu.release(); c->h_pa.release(); c->h_pm.release(); c->h_seq.release();
 	for (int i = 0; i < 16; ++i) if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]);
 	for (int i = 0; i < 24; ++i) { if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); if (c->dp_ev0[i]) (void)hipEventDestroy(c->dp_ev0[i]); if (c->dp_ev1[i]) (void)hipEventDestroy(c->dp_ev1[i]); }
 	if (c->dp_up_ev) (void)hipEventDestroy(c->dp_up_ev);
@@ -396,6 +396,7 @@ int mm355_run_sketch(mm355_ctx *c)
 	return 0;
 }
 
+static int upload_heavy_order(mm355_ctx *c);
 int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c);
@@ -429,17 +430,7 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 	    c->z.ensure(na * 8) || c->t8.ensure(na) || c->vi.ensure(na * 4) || c->b.ensure(na * 16) || c->wk.ensure(na * 16) ||
 	    c->u.ensure(na * 8) || c->u2.ensure(na * 8)) return MM355_ENOMEM;
 	HIPCHK(hipMemcpyAsync(c->aoff.p, hb.aoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->st));
-	{   // per-read kernels take the reads with the most anchors first: the slowest block starts at t=0 instead of last
-		std::vector<int32_t> hv(n);
-		std::iota(hv.begin(), hv.end(), 0);
-		std::stable_sort(hv.begin(), hv.end(), [&](int32_t x, int32_t y) { return hb.n_a[x] > hb.n_a[y]; });
-		c->n_heavy = 0;
-		for (int64_t i = 0; i < n && hb.n_a[hv[i]] > mm355_sort_heavy_threshold(); ++i) ++c->n_heavy;
-		if (c->heavy.ensure((size_t)(n + 1) * 4)) return MM355_ENOMEM;
-		if (n) HIPCHK(hipMemcpyAsync(c->heavy.p, hv.data(), n * 4, hipMemcpyHostToDevice, c->st));
-		HIPCHK(mm355_wait_stream(c->st));
-	}
-	return 0;
+	return upload_heavy_order(c);
 }
 
 int mm355_run_expand(mm355_ctx *c, const DevParams &pr)
@@ -458,53 +449,68 @@ static int check_err(mm355_ctx *c)
 	return e[0]? MM355_ENOMEM : 0;
 }
 
-int mm355_run_sort(mm355_ctx *c)
+static int upload_heavy_order(mm355_ctx *c)   // per-read kernels take the reads with the most anchors first: the slowest block starts at t = 0 instead of last
+{
+	HostBatch &hb = c->hb;
+	const int64_t n = hb.n_reads;
+	std::vector<int32_t> hv(n);
+	std::iota(hv.begin(), hv.end(), 0);
+	std::stable_sort(hv.begin(), hv.end(), [&](int32_t x, int32_t y) { return hb.n_a[x] > hb.n_a[y]; });
+	c->n_heavy = 0;
+	for (int64_t i = 0; i < n && hb.n_a[hv[i]] > mm355_sort_heavy_threshold(); ++i) ++c->n_heavy;
+	if (c->heavy.ensure((size_t)(n + 1) * 4)) return MM355_ENOMEM;
+	if (n) HIPCHK(hipMemcpyAsync(c->heavy.p, hv.data(), n * 4, hipMemcpyHostToDevice, c->st));
+	HIPCHK(mm355_wait_stream(c->st));
+	return 0;
+}
+
+// cull: anchor-rich batches drop the anchors that cannot chain before they sort (mm355_cullsort.hip); 0 = the full sorted array of every
+// read (the stage entry points that hand out row a6's result; MM355_CULL=0 forces it everywhere)
+int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
 	{
-		// every emitted task covers > 64 elements, so tot_a / 64 (+ one whole-array task per read) bounds each list
-		const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->hb.n_reads + 1024;
-		if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 64)) return MM355_ENOMEM;
 		EvTimer t(c, &c->stats.ms_sort);
 		const int n_reads = (int)c->hb.n_reads;
-		// anchor-rich batches (GRCh38-scale): one segmented radix sort for all reads; only the reads with equal keys -- where the tie
-		// order of the reference's unstable sort is observable -- go through the literal emulation (MM355_FAST_SORT=0/1 forces the choice)
+		// anchor-rich batches (GRCh38-scale): cull + per-read LDS sort; only the reads with equal keys among what is left -- where the tie order of
+		// the reference's unstable sort is observable -- go through the literal emulation (MM355_FAST_SORT=0/1 forces the choice)
 		static const int force = [] { const char *e = getenv("MM355_FAST_SORT"); return e? atoi(e) : -1; }();
 		const bool fast = force >= 0? force != 0 : (n_reads > 0 && c->hb.tot_a / n_reads >= 2048);
-		std::vector<uint8_t> flag;
-		const double ts0 = mm355_now_ms();
 		if (fast) {
-			int rc = mm355_fast_sort(c, c->hb.tot_a, n_reads, flag);
+			const bool cull_env = [] { const char *e = getenv("MM355_CULL"); return !(e && atoi(e) == 0); }();   // (read per call: the tests switch it)
+			const bool rmq_primary = (pr.flag & MMF_RMQ) != 0;   // mg_lchain_rmq as the primary chainer sees every anchor (its windows are not mg_lchain_dp's)
+			int rc = mm355_cull_sort(c, pr, cull && cull_env && !rmq_primary? 1 : 0);
 			if (rc) return rc;
-			mm355_trace_add(c, "s:fast", ts0, mm355_now_ms());
-			a.tcnt = c->v.as<int32_t>();   // the literal recursion skips buckets without equal keys (restored by mm355_fast_sort_fix)
-		}
-		// whole-array tasks of the reads that are sorted literally, by size class: 1024-thread levels, 256-thread levels, one wave
-		const int big_min = mm355_sort_heavy_threshold(), med_min = mm355_sort_medium_threshold();
-		int nb = 0, nm = 0, ns = 0;
-		for (int i = 0; i < n_reads; ++i) {
-			const int na = c->hb.n_a[i];
-			if (na < 2 || (fast && !flag[i])) continue;
-			if (na > big_min) ++nb; else if (na > med_min) ++nm; else ++ns;
-		}
-		const int n_list = nb + nm + ns;
-		if (fast) { c->stats.n_sort_fast_reads += n_reads; c->stats.n_sort_tie_reads += n_list; }
-		if (n_list) {
-			if (c->h_tasks.ensure((size_t)n_list * sizeof(SortTask))) return MM355_ENOMEM;   // pinned: consumed by asynchronous copies
-			SortTask *ht = (SortTask*)c->h_tasks.p;
-			int ib = 0, im = nb, is = nb + nm;
+			if ((rc = upload_heavy_order(c))) return rc;
+		} else {
+			// every emitted task covers > 64 elements, so tot_a / 64 (+ one whole-array task per read) bounds each list
+			const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->hb.n_reads + 1024;
+			if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 64)) return MM355_ENOMEM;
+			// whole-array tasks of the reads, by size class: 1024-thread levels, 256-thread levels, one wave
+			const int big_min = mm355_sort_heavy_threshold(), med_min = mm355_sort_medium_threshold();
+			int nb = 0, nm = 0, ns = 0;
 			for (int i = 0; i < n_reads; ++i) {
 				const int na = c->hb.n_a[i];
-				if (na < 2 || (fast && !flag[i])) continue;
-				SortTask tk; tk.read = i; tk.beg = 0; tk.end = (uint32_t)na; tk.s = 56;
-				if (na > big_min) ht[ib++] = tk; else if (na > med_min) ht[im++] = tk; else ht[is++] = tk;
+				if (na < 2) continue;
+				if (na > big_min) ++nb; else if (na > med_min) ++nm; else ++ns;
 			}
-			// big tasks first in their list: the longest level walks start at t = 0
-			std::stable_sort(ht, ht + nb, [](const SortTask &x, const SortTask &y) { return x.end > y.end; });
-			const double ts1 = mm355_now_ms();
-			if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
-			mm355_trace_add(c, "s:levels", ts1, mm355_now_ms());
-			if (fast) { int rc = mm355_fast_sort_fix(c, n_reads); if (rc) return rc; }
+			const int n_list = nb + nm + ns;
+			if (n_list) {
+				if (c->h_tasks.ensure((size_t)n_list * sizeof(SortTask))) return MM355_ENOMEM;   // pinned: consumed by asynchronous copies
+				SortTask *ht = (SortTask*)c->h_tasks.p;
+				int ib = 0, im = nb, is = nb + nm;
+				for (int i = 0; i < n_reads; ++i) {
+					const int na = c->hb.n_a[i];
+					if (na < 2) continue;
+					SortTask tk; tk.read = i; tk.beg = 0; tk.end = (uint32_t)na; tk.s = 56;
+					if (na > big_min) ht[ib++] = tk; else if (na > med_min) ht[im++] = tk; else ht[is++] = tk;
+				}
+				// big tasks first in their list: the longest level walks start at t = 0
+				std::stable_sort(ht, ht + nb, [](const SortTask &x, const SortTask &y) { return x.end > y.end; });
+				const double ts1 = mm355_now_ms();
+				if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
+				mm355_trace_add(c, "s:levels", ts1, mm355_now_ms());
+			}
 		}
 	}
 	HIPCHK(hipGetLastError());
@@ -672,7 +678,7 @@ extern "C" int mm355_stage_anchors(mm355_ctx_t *c, const mm355_mapopt_t *mo, int
 	if ((rc = mm355_run_sketch(c))) return rc;
 	if ((rc = mm355_run_seeds(c, pr))) return rc;
 	if ((rc = mm355_run_expand(c, pr))) return rc;
-	if (sorted && (rc = mm355_run_sort(c))) return rc;
+	if (sorted && (rc = mm355_run_sort(c, pr, sorted == 2? 1 : 0))) return rc;
 	HostBatch &hb = c->hb;
 	for (int64_t i = 0; i <= n_reads; ++i) a_off[i] = hb.aoff[i];
 	if (hb.tot_a > a_cap) return MM355_ENOMEM;
@@ -690,7 +696,7 @@ extern "C" int mm355_stage_chain(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64
 	if ((rc = mm355_run_sketch(c))) return rc;
 	if ((rc = mm355_run_seeds(c, pr))) return rc;
 	if ((rc = mm355_run_expand(c, pr))) return rc;
-	if ((rc = mm355_run_sort(c))) return rc;
+	if ((rc = mm355_run_sort(c, pr, 0))) return rc;   // (f / p / v are compared anchor by anchor with the oracle: the whole sorted array)
 	if ((rc = mm355_run_chain(c, pr))) return rc;
 	HostBatch &hb = c->hb;
 	for (int64_t i = 0; i <= n_reads; ++i) a_off[i] = hb.aoff[i];
@@ -713,7 +719,7 @@ extern "C" int mm355_stage_chains(mm355_ctx_t *c, const mm355_mapopt_t *mo, int6
 	if ((rc = mm355_run_sketch(c))) return rc;
 	if ((rc = mm355_run_seeds(c, pr))) return rc;
 	if ((rc = mm355_run_expand(c, pr))) return rc;
-	if ((rc = mm355_run_sort(c))) return rc;
+	if ((rc = mm355_run_sort(c, pr))) return rc;
 	if ((rc = mm355_run_chain(c, pr))) return rc;
 	if ((rc = mm355_run_backtrack(c, pr))) return rc;
 	HostBatch &hb = c->hb;
@@ -737,7 +743,7 @@ extern "C" int mm355_stage_rmq(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64_t
 	if ((rc = mm355_run_sketch(c))) return rc;
 	if ((rc = mm355_run_seeds(c, pr))) return rc;
 	if ((rc = mm355_run_expand(c, pr))) return rc;
-	if ((rc = mm355_run_sort(c))) return rc;
+	if ((rc = mm355_run_sort(c, pr))) return rc;
 	if (mo->flag & MMF_RMQ) { if ((rc = mm355_run_chain_skip(c))) return rc; }
 	else {
 		if ((rc = mm355_run_chain(c, pr))) return rc;

@@ -67,7 +67,7 @@ class Stats(C.Structure):
                 ("ms_dp_group", C.c_double * 24), ("dp_cells_group", C.c_int64 * 24), ("n_launch_group", C.c_int64 * 24),
                 ("n_ext_rounds", C.c_int64), ("n_sort_fast_reads", C.c_int64), ("n_sort_tie_reads", C.c_int64),
                 ("ms_rmq", C.c_double), ("n_rmq_reads", C.c_int64), ("n_rmq_host", C.c_int64), ("rmq_scanned", C.c_int64),
-                ("host_cpu_ms", C.c_double)]
+                ("host_cpu_ms", C.c_double), ("n_a_kept", C.c_int64)]
 
 
 class DpJob(C.Structure):
@@ -225,7 +225,7 @@ class StageRunner:
         off = np.zeros(n + 1, np.int64)
         a = np.zeros((cap, 2), np.uint64)
         rep = np.zeros(n, np.int32); nmp = np.zeros(n, np.int32)
-        check(self.L.mm355_stage_anchors(self.ctx, C.byref(self.mo), n, arr, lens, 1 if sorted_ else 0, off.ctypes.data,
+        check(self.L.mm355_stage_anchors(self.ctx, C.byref(self.mo), n, arr, lens, int(sorted_), off.ctypes.data,
                                          a.ctypes.data, cap, rep.ctypes.data, nmp.ctypes.data))
         return [a[off[i]:off[i + 1]].copy() for i in range(n)], rep, nmp
 
