@@ -74,8 +74,8 @@ __device__ __forceinline__ bool cs_keep(const uint32_t *bm, uint32_t rel, uint32
 	return false;
 }
 
-// One block per read.  keys[o + i] = position word << ib | i for every anchor (generation order); surv[o ..] = the words of the anchors
-// that are kept, in no particular order; n_keep[r] = how many.
+// One block per read.  keys[o + i] = kept << 63 | position word << ib | i for every anchor (generation order); surv[o ..] = the words
+// (without the top bit) of the anchors that are kept, in no particular order; n_keep[r] = how many.
 __global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff, const mm128 *a, uint64_t *keys, uint64_t *surv, int32_t *n_keep, int n_reads, CullPar cp)
 {
 	extern __shared__ uint32_t bm[];   // 3 * CS_WPL
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff
 		for (uint32_t i = tid; i < n; i += CS_NT) {
 			uint64_t k;
 			if (p == 0) { k = cs_pos(ix, a[o + i].x, cp.tot_len); keys[o + i] = k << cp.ib | i; }
-			else k = keys[o + i] >> cp.ib;
+			else k = (keys[o + i] & ~(1ULL << 63)) >> cp.ib;
 			const int64_t rel = (int64_t)(k >> cp.sh) - lo;
 			if (rel >= 0 && rel < CS_BPP + 2 * CS_GUARD) cs_add(bm, (uint32_t)rel);
 		}
@@ -102,9 +102,10 @@ __global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff
 			const uint32_t i = base + tid;
 			bool keep = false; uint64_t kw = 0;
 			if (i < n) {
-				kw = keys[o + i];                                       // (written by this very thread in pass 0)
+				kw = keys[o + i] & ~(1ULL << 63);                       // (written by this very thread in pass 0)
 				const int64_t rel = (int64_t)((kw >> cp.ib) >> cp.sh) - lo;
 				if (rel >= CS_GUARD && rel < CS_BPP + CS_GUARD) keep = cs_keep(bm, (uint32_t)rel, (uint32_t)cp.T);
+				if (keep) keys[o + i] = kw | 1ULL << 63;                // the decision, for the reads that are sorted literally (k_tie_copy)
 			}
 			const unsigned long long mk = __ballot(keep);
 			if (mk) {
@@ -233,43 +234,36 @@ __global__ __launch_bounds__(NT) void k_asort(const int32_t *list, int n_list, c
 }
 
 // ------------------------------------------------------------------ reads with equal keys among their survivors
-// the generation-order anchors of the listed reads, copied to the dense arrays the literal emulation works on
-__global__ __launch_bounds__(256) void k_tie_copy(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const mm128 *a, mm128 *ta)
+// the generation-order anchors of the listed reads, copied to the dense arrays the literal emulation works on; bit 63 of y (unused: y is
+// flags | span << 32 | query position) carries k_cull's decision through the sort
+__global__ __launch_bounds__(256) void k_tie_copy(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const mm128 *a, const uint64_t *keys, mm128 *ta, int keep_all)
 {
 	const int t = blockIdx.x;
 	if (t >= n_list) return;
 	const int r = list[t];
 	const int64_t o = aoff[r], d = toff[t];
 	const uint32_t n = (uint32_t)(aoff[r + 1] - o);
-	for (uint32_t i = threadIdx.x; i < n; i += 256) ta[d + i] = a[o + i];
+	for (uint32_t i = threadIdx.x; i < n; i += 256) {
+		mm128 el = a[o + i];
+		if (keep_all || keys[o + i] >> 63) el.y |= 1ULL << 63;
+		ta[d + i] = el;
+	}
 }
-// ... and after it: the kept anchors of the literally sorted array, in order.  An anchor is kept iff its position is among the sorted
-// survivors (all anchors of one position share a bin, hence the decision).
-__global__ __launch_bounds__(256) void k_tie_emit(DevIndex ix, const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const int64_t *aoff2, const int32_t *n_keep,
-                                                  const mm128 *ta, const uint64_t *surv, mm128 *out, CullPar cp, int keep_all)
+// ... and after it: the kept anchors of the literally sorted array, in order
+__global__ __launch_bounds__(256) void k_tie_emit(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const int64_t *aoff2, const mm128 *ta, mm128 *out)
 {
 	__shared__ uint32_t s_w[4];
 	const int t = blockIdx.x;
 	if (t >= n_list) return;
 	const int r = list[t];
-	const int64_t o = aoff[r], d = toff[t];
-	const uint32_t n = (uint32_t)(aoff[r + 1] - o), nk = (uint32_t)n_keep[r], tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const uint64_t *sv = surv + o;
+	const int64_t d = toff[t];
+	const uint32_t n = (uint32_t)(aoff[r + 1] - aoff[r]), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	mm128 *dst = out + aoff2[r];
 	uint32_t base_out = 0;
 	for (uint32_t base = 0; base < n; base += 256) {
 		const uint32_t i = base + tid;
 		bool keep = false; mm128 el; el.x = el.y = 0;
-		if (i < n) {
-			el = ta[d + i];
-			if (keep_all) keep = true;
-			else {
-				const uint64_t k = cs_pos(ix, el.x, cp.tot_len);
-				uint32_t lo = 0, hi = nk;
-				while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((sv[mid] >> cp.ib) < k) lo = mid + 1; else hi = mid; }
-				keep = lo < nk && (sv[lo] >> cp.ib) == k;
-			}
-		}
+		if (i < n) { el = ta[d + i]; keep = el.y >> 63 != 0; el.y &= ~(1ULL << 63); }
 		const unsigned long long mk = __ballot(keep);
 		if (lane == 0) s_w[wv] = (uint32_t)__popcll(mk);
 		__syncthreads();
@@ -301,7 +295,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	int32_t max_na = 1;
 	for (int i = 0; i < n_reads; ++i) if (hb.n_a[i] > max_na) max_na = hb.n_a[i];
 	cp.ib = bits_for((uint64_t)max_na - 1);
-	if (bits_for(2 * cp.tot_len - 1) + cp.ib > 64) return MM355_EUNSUP;   // (a 2^40-base reference with 2^23 anchors on one read)
+	if (bits_for(2 * cp.tot_len - 1) + cp.ib > 63) return MM355_EUNSUP;   // (a 2^40-base reference with 2^22 anchors on one read; bit 63 is k_cull's mark)
 	// T: the fewest anchors a chain that survives mg_chain_backtrack can have; D: the largest max_dist_x of any read (chain_dist)
 	const int T = std::max<int>(pr.min_cnt, (pr.min_chain_score + mi->k - 1) / mi->k);
 	int64_t D = pr.max_gap_ref > 0? pr.max_gap_ref : pr.max_frag_len > 0? std::max(pr.max_frag_len, pr.max_gap) : pr.max_gap;
@@ -396,20 +390,21 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		int64_t *d_toff = c->tie_list.as<int64_t>(); int32_t *d_tl = (int32_t*)(d_toff + n_tie + 1);
 		HIPCHK(hipMemcpyAsync(d_toff, h_toff, ((size_t)n_tie + 1) * 8, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipMemcpyAsync(d_tl, h_tl, (size_t)n_tie * 4, hipMemcpyHostToDevice, c->st));
-		hipLaunchKernelGGL(k_tie_copy, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, c->a.as<mm128>(), c->tie_a.as<mm128>());
+		hipLaunchKernelGGL(k_tie_copy, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, c->a.as<mm128>(), keys, c->tie_a.as<mm128>(), do_cull? 0 : 1);
 		DevAnchors at; memset(&at, 0, sizeof(at));
 		at.aoff = d_toff; at.a = c->tie_a.as<mm128>(); at.b = c->tie_b.as<mm128>(); at.f = c->tie_f.as<int32_t>(); at.p = c->tie_p.as<int32_t>(); at.t8 = c->tie_t8.as<uint8_t>(); at.tcnt = 0;
 		const size_t task_cap = (size_t)tt / 64 + (size_t)n_tie + 1024;
-		if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 64)) return MM355_ENOMEM;
+		if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 512)) return MM355_ENOMEM;
 		DevBatch bt; memset(&bt, 0, sizeof(bt));
-		if (mm355_launch_sort(bt, at, c->err.as<int>(), ht, nb, nm, ns, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
-		hipLaunchKernelGGL(k_tie_emit, dim3((unsigned)n_tie), dim3(256), 0, c->st, c->dix, d_tl, n_tie, aoff, d_toff, d_off2, d_nk, c->tie_a.as<mm128>(), surv, c->b.as<mm128>(), cp, do_cull? 0 : 1);
+		if (mm355_launch_sort(bt, at, c->err.as<int>(), ht, nb, nm, ns, (size_t)tt, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
+		hipLaunchKernelGGL(k_tie_emit, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, d_off2, c->tie_a.as<mm128>(), c->b.as<mm128>());
 		HIPCHK(hipGetLastError());
 		HIPCHK(mm355_wait_stream(c->st));   // (the pinned lists above are reused by the next call)
 		mm355_trace_add(c, "s:levels", t2, mm355_now_ms());
 	}
 	// ---- the culled, sorted array becomes the batch's anchor array
-	std::swap(c->a, c->b); std::swap(c->aoff, c->aoff2); std::swap(c->n_a, c->n_keep);
+	std::swap(c->a, c->b); std::swap(c->aoff, c->aoff2);   // (both pairs are sized anew by every call; n_a is sized per resident batch: copied, not swapped)
+	HIPCHK(hipMemcpyAsync(c->n_a.p, d_nk, nr * 4, hipMemcpyDeviceToDevice, c->st));
 	for (int i = 0; i < n_reads; ++i) { hb.n_a[i] = h_nk[i]; hb.aoff[i] = h_off2[i]; }
 	hb.aoff[n_reads] = tk; hb.tot_a = tk;
 	return 0;

@@ -625,12 +625,12 @@ __device__ inline uint32_t block_ordered_prefix(bool flag, uint32_t &base, MwLds
 // than MW_BIG elements, <256, MW_BIG + 64 B> for the medium ones (six blocks per CU instead of one).  Children go to the list of their
 // own size class; ctr = { next-level big, next-level medium, wave tasks (running total) }.
 template <typename T, typename Key, int NT, int LABCAP>
-__global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortTask *tasks, int n_tasks, SortTask *out_big, SortTask *out_med, SortTask *out_small,
-                                                      unsigned int *ctr, uint32_t big_min, uint32_t med_min, int *err)
+__global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortTask *tasks, const unsigned int *n_tasks_p, SortTask *out_big, SortTask *out_med, SortTask *out_small,
+                                                      unsigned int *ctr, unsigned int *ctr_small, uint32_t big_min, uint32_t med_min, int *err)
 {
 	__shared__ MwLds<NT> L;
 	extern __shared__ uint8_t lds_lab[];   // LABCAP labels
-	if ((int)blockIdx.x >= n_tasks) return;
+	if (blockIdx.x >= *n_tasks_p) return;   // (the grid is an upper bound: the list lengths stay on the device, no host round trip per level)
 	const SortTask tk = tasks[blockIdx.x];
 	const int64_t o = an.aoff[tk.read];
 	T *a = SortArr<T>::arr(an, o);
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortT
 			SortTask c; c.read = tk.read; c.beg = beg + b0; c.end = beg + b0 + sz; c.s = s - 8;
 			if (sz > big_min) out_big[atomicAdd(&ctr[0], 1u)] = c;
 			else if (sz > med_min) out_med[atomicAdd(&ctr[1], 1u)] = c;
-			else out_small[atomicAdd(&ctr[2], 1u)] = c;
+			else out_small[atomicAdd(ctr_small, 1u)] = c;
 		} else if (sz > 1) mm_rs_insertsort(a + beg + b0, a + beg + b0 + sz, key);
 	}
 	(void)err;
@@ -736,11 +736,11 @@ __global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortT
 
 // one wave per task: finishes a bucket exactly as rs_sort(beg, end, 8, s) would
 template <typename T, typename Key>
-__global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTask *tasks, int n_tasks, int *err)
+__global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTask *tasks, const unsigned int *n_tasks_p, int *err)
 {
 	__shared__ SortLds L;
 	__shared__ mm128 stage[2048];
-	if ((int)blockIdx.x >= n_tasks) return;
+	if (blockIdx.x >= *n_tasks_p) return;
 	const SortTask tk = tasks[blockIdx.x];
 	const int64_t o = an.aoff[tk.read];
 	if (tk.end - tk.beg <= MM355_RS_MIN_SIZE) {   // only a whole array can be this short (children are larger): radix_sort = insertion sort
@@ -755,28 +755,36 @@ __global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTa
 	if (threadIdx.x == 0 && L.overflow) *err = 1;
 }
 
-// host side: the initial tasks (whole arrays of the reads to sort, at byte 56) are already in the three size-class lists on the device;
-// a level = one launch per non-empty block-level class, then the counters come back and the lists swap.  ctr = { big, medium, small }.
+// host side: the initial tasks (whole arrays of the reads to sort, at byte 56) are already in the three size-class lists on the device.
+// A level = one launch per block-level class; the lengths of the lists a level leaves behind stay ON THE DEVICE (ctr[level + 1][big, medium],
+// one running total for the wave tasks) and the next level's grids are upper bounds -- disjoint buckets of more than big_min / med_min
+// elements out of n_elems -- whose surplus blocks leave at once: the whole emulation is one asynchronous chain of launches (round 3 read the
+// counters back after every level: up to nine host round trips per sub-batch, each a few ms under the bench load).
 #define MW_MED_LAB (MW_BIG + 64)
+#define MW_LEVELS 9
 template <typename T, typename Key>
-static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, int *err, hipStream_t st)
+static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, size_t n_elems, size_t task_cap, int *err, hipStream_t st)
 {
 	(void)hipFuncSetAttribute((const void*)k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, MW_LAB_CAP);
 	const uint32_t big_min = (uint32_t)mm355_sort_heavy_threshold(), med_min = (uint32_t)mm355_sort_medium_threshold();
+	// d_ctr: [level][2] list lengths, then the wave-task total
+	unsigned int h[2 * (MW_LEVELS + 1) + 1];
+	memset(h, 0, sizeof(h));
+	h[0] = (unsigned int)n_big; h[1] = (unsigned int)n_med; h[2 * (MW_LEVELS + 1)] = (unsigned int)n_small;
+	if (hipMemcpyAsync(d_ctr, h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess) return -1;   // (pageable source: the copy is staged before the call returns)
+	unsigned int *d_small_ctr = d_ctr + 2 * (MW_LEVELS + 1);
+	const size_t cap_big = std::min(task_cap, n_elems / big_min + 1), cap_med = std::min(task_cap, n_elems / med_min + 1);
 	int cur = 0;
-	unsigned int h[3] = { 0, 0, (unsigned int)n_small };
-	if (hipMemcpyAsync(d_ctr, h, 12, hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-	for (int level = 0; level < 9 && n_big + n_med > 0; ++level) {
-		if (n_big) hipLaunchKernelGGL((k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>), dim3(n_big), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], n_big, d_big[cur ^ 1], d_med[cur ^ 1], d_small, d_ctr, big_min, med_min, err);
-		if (n_med) hipLaunchKernelGGL((k_sort_level_mw<T, Key, 256, MW_MED_LAB>), dim3(n_med), dim3(256), MW_MED_LAB, st, an, d_med[cur], n_med, d_big[cur ^ 1], d_med[cur ^ 1], d_small, d_ctr, big_min, med_min, err);
-		unsigned int hh[3];
-		if (hipMemcpyAsync(hh, d_ctr, 12, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
-		if (mm355_wait_stream(st) != hipSuccess) return -1;
-		n_big = (int)hh[0]; n_med = (int)hh[1]; h[2] = hh[2];
-		if (hipMemsetAsync(d_ctr, 0, 8, st) != hipSuccess) return -1;   // the small-task total keeps running
+	for (int level = 0; level < MW_LEVELS; ++level) {
+		const size_t gb = level == 0? (size_t)n_big : cap_big, gm = level == 0? (size_t)n_med : cap_med;
+		if (level == 0 && n_big + n_med == 0) break;
+		unsigned int *c_in = d_ctr + 2 * level, *c_out = d_ctr + 2 * (level + 1);
+		if (gb) hipLaunchKernelGGL((k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>), dim3((unsigned)gb), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], c_in, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err);
+		if (gm) hipLaunchKernelGGL((k_sort_level_mw<T, Key, 256, MW_MED_LAB>), dim3((unsigned)gm), dim3(256), MW_MED_LAB, st, an, d_med[cur], c_in + 1, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err);
 		cur ^= 1;
 	}
-	if (h[2]) hipLaunchKernelGGL((k_sort_tasks<T, Key>), dim3(h[2]), dim3(WAVE), 0, st, an, d_small, (int)h[2], err);
+	const size_t gs = n_big + n_med == 0? (size_t)n_small : task_cap;
+	if (gs) hipLaunchKernelGGL((k_sort_tasks<T, Key>), dim3((unsigned)gs), dim3(WAVE), 0, st, an, d_small, d_small_ctr, err);
 	return 0;
 }
 
@@ -1167,8 +1175,9 @@ void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const Dev
 }
 // Literal radix_sort_128x of the listed reads.  h_tasks: the initial whole-read tasks (byte 56) grouped by size class -- n_big entries
 // (> MW_BIG anchors: 1024-thread levels), then n_med (> MW_MED: 256-thread levels), then n_small (one wave each) -- in pinned or otherwise
-// stable host memory until the stream has consumed it.  task_buf: device scratch for 5 task lists of `task_cap` entries + counters.
-int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, void *task_buf, size_t task_cap, hipStream_t st)
+// stable host memory until the stream has consumed it.  n_elems: elements of all listed arrays together.  task_buf: device scratch for 5 task
+// lists of `task_cap` entries + 64 counters.
+int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st)
 {
 	(void)bt;
 	const int n = n_big + n_med + n_small;
@@ -1181,7 +1190,7 @@ int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *
 	if (n_big && hipMemcpyAsync(big[0], ht, (size_t)n_big * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 	if (n_med && hipMemcpyAsync(med[0], ht + n_big, (size_t)n_med * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 	if (n_small && hipMemcpyAsync(small, ht + n_big + n_med, (size_t)n_small * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, err, st);
+	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, n_elems, task_cap, err, st);
 }
 int mm355_sort_task_bytes(void) { return (int)sizeof(SortTask); }
 int mm355_sort_heavy_threshold(void)   // MM355_SORT_HEAVY_MIN: test hook that pushes ordinary reads through the 1024-thread path

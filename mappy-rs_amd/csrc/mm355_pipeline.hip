@@ -485,7 +485,7 @@ int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		} else {
 			// every emitted task covers > 64 elements, so tot_a / 64 (+ one whole-array task per read) bounds each list
 			const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->hb.n_reads + 1024;
-			if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 64)) return MM355_ENOMEM;
+			if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 512)) return MM355_ENOMEM;
 			// whole-array tasks of the reads, by size class: 1024-thread levels, 256-thread levels, one wave
 			const int big_min = mm355_sort_heavy_threshold(), med_min = mm355_sort_medium_threshold();
 			int nb = 0, nm = 0, ns = 0;
@@ -508,7 +508,7 @@ int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 				// big tasks first in their list: the longest level walks start at t = 0
 				std::stable_sort(ht, ht + nb, [](const SortTask &x, const SortTask &y) { return x.end > y.end; });
 				const double ts1 = mm355_now_ms();
-				if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
+				if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, (size_t)c->hb.tot_a, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
 				mm355_trace_add(c, "s:levels", ts1, mm355_now_ms());
 			}
 		}

@@ -137,3 +137,62 @@ def test_mid_scale_human_parity(human_mid, preset, seed, kw, extra):
     finally:
         L.mm355_ctx_destroy(ctx)
         L.mm355_index_free(idx)
+
+
+def _check_culled(full, got, max_dist_x, t_min):
+    """`got` (stage sorted = 2) must be `full` (the reference's sorted array) minus whole x-components, in the same order, and must still
+    hold every anchor of every x-component (same strand | contig, consecutive gaps <= max_dist_x) of at least t_min anchors"""
+    pos = {(int(x), int(y)): i for i, (x, y) in enumerate(full)}
+    assert len(pos) == len(full)
+    idx = np.array([pos[(int(x), int(y))] for x, y in got], np.int64)         # KeyError: an anchor that is not in the reference's array
+    assert np.all(idx[1:] > idx[:-1]), "order differs from the reference's sorted array"
+    if len(full) == 0:
+        return 0
+    x = full[:, 0]
+    brk = np.concatenate(([True], (x[1:] >> np.uint64(32) != x[:-1] >> np.uint64(32)) | ((x[1:] - x[:-1]) > np.uint64(max_dist_x))))
+    cid = np.cumsum(brk) - 1
+    need = np.bincount(cid)[cid] >= t_min
+    have = np.zeros(len(full), bool); have[idx] = True
+    assert np.all(have[need]), "an x-component that can chain lost anchors"
+    return int(len(full) - len(got))
+
+
+def test_anchor_cull_and_sort_mid_scale(human_mid):
+    """row a6 on an anchor-rich batch: the hand-written path (mm355_cullsort.hip).  sorted = 1: the reference's whole sorted array, ties in
+    the order of the unstable radix_sort_128x (the cull switched off: every anchor goes through the LDS sort / the literal emulation);
+    sorted = 2: what the chainer is given -- whole x-components dropped, nothing else touched; chains: identical to the oracle's chains
+    of the WHOLE array (the cull is invisible downstream)."""
+    from mappy_rs import _ffi
+    L = _ffi.lib()
+    g, names = human_mid
+    reads, _ = S.make_read_block(4, 2, g, **ONT)
+    reads = reads[:64]
+    idx, mo = build_device_index(L, _ffi, g, names, "map-ont")
+    orc = O.OracleAligner(codes=g, names=names, preset="map-ont", n_threads=16)
+    sr = _ffi.StageRunner(idx, mo, 0)
+    try:
+        full_g, _, _ = sr.anchors(reads, sorted_=1, cap=40_000_000)
+        st = sr.stats()
+        assert st.n_sort_fast_reads == len(reads) and st.n_a_kept == st.n_a, (st.n_sort_fast_reads, st.n_a_kept, st.n_a)
+        cul_g, _, _ = sr.anchors(reads, sorted_=2, cap=40_000_000)
+        st = sr.stats()
+        assert st.n_sort_fast_reads == len(reads) and 0 < st.n_a_kept < 0.9 * st.n_a, (st.n_a_kept, st.n_a)   # (155 Mbp: a third is dropped; 3.1 Gbp: nine tenths)
+        n_ties = n_tie_reads = n_culled = 0
+        exp_all = []
+        for i, rd in enumerate(reads):
+            exp, _, _, _ = orc.anchors(rd, sorted_=True)
+            exp_all.append(exp)
+            assert np.array_equal(full_g[i], exp), i
+            t = int((exp[1:, 0] == exp[:-1, 0]).sum()) if len(exp) > 1 else 0
+            n_ties += t; n_tie_reads += t > 0
+            n_culled += _check_culled(exp, cul_g[i], mo.max_gap, 3)
+        assert n_tie_reads >= 2 and n_culled == st.n_a - st.n_a_kept, (n_tie_reads, n_culled, st.n_a - st.n_a_kept)
+        assert st.n_sort_tie_reads >= 1
+        ch = sr.chains(reads, cap=40_000_000)
+        for i, rd in enumerate(reads):
+            eu, eb = orc.chains(exp_all[i], len(rd))
+            assert np.array_equal(ch[i][0], eu), i
+            assert np.array_equal(ch[i][1], eb), i
+    finally:
+        sr.close()
+        L.mm355_index_free(idx)
