@@ -426,9 +426,10 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 	hb.aoff[n] = tot; hb.tot_a = tot;
 	c->stats.n_mz += tmz; c->stats.n_hit += (int64_t)ctr[0]; c->stats.n_a_multi += (int64_t)ctr[1]; c->stats.n_a += tot;
 	size_t na = (size_t)tot + 64;
-	if (c->aoff.ensure((n + 1) * 8) || c->a.ensure(na * 16) || c->f.ensure(na * 4) || c->p.ensure(na * 4) || c->v.ensure(na * 4) ||
-	    c->z.ensure(na * 8) || c->t8.ensure(na) || c->vi.ensure(na * 4) || c->b.ensure(na * 16) || c->wk.ensure(na * 16) ||
-	    c->u.ensure(na * 8) || c->u2.ensure(na * 8)) return MM355_ENOMEM;
+	if (c->b.cap > c->a.cap) std::swap(c->a, c->b);   // (the sort of the previous batch left its short, culled array in `a`: the long buffer takes the new anchors)
+	// a[] and two 8-byte words per anchor (the cull's position words, then chaining scratch) for every anchor; the arrays of the stages behind
+	// the sort are sized there, for what the cull leaves (mm355_run_sort: a tenth of the anchors on a GRCh38-scale batch)
+	if (c->aoff.ensure((n + 1) * 8) || c->a.ensure(na * 16) || c->z.ensure(na * 8) || c->u.ensure(na * 8)) return MM355_ENOMEM;
 	HIPCHK(hipMemcpyAsync(c->aoff.p, hb.aoff.data(), (n + 1) * 8, hipMemcpyHostToDevice, c->st));
 	return upload_heavy_order(c);
 }
@@ -466,9 +467,17 @@ static int upload_heavy_order(mm355_ctx *c)   // per-read kernels take the reads
 
 // cull: anchor-rich batches drop the anchors that cannot chain before they sort (mm355_cullsort.hip); 0 = the full sorted array of every
 // read (the stage entry points that hand out row a6's result; MM355_CULL=0 forces it everywhere)
+static int ensure_chain_arrays(mm355_ctx *c, int64_t tot)   // everything the stages behind the sort index by anchor
+{
+	const size_t na = (size_t)tot + 64;
+	if (c->f.ensure(na * 4) || c->p.ensure(na * 4) || c->v.ensure(na * 4) || c->z.ensure(na * 8) || c->t8.ensure(na) || c->vi.ensure(na * 4) ||
+	    c->b.ensure(na * 16) || c->wk.ensure(na * 16) || c->u.ensure(na * 8) || c->u2.ensure(na * 8)) return MM355_ENOMEM;
+	return 0;
+}
+
 int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 {
-	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
+	DevBatch b = dev_batch(c);
 	{
 		EvTimer t(c, &c->stats.ms_sort);
 		const int n_reads = (int)c->hb.n_reads;
@@ -481,8 +490,11 @@ int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 			const bool rmq_primary = (pr.flag & MMF_RMQ) != 0;   // mg_lchain_rmq as the primary chainer sees every anchor (its windows are not mg_lchain_dp's)
 			int rc = mm355_cull_sort(c, pr, cull && cull_env && !rmq_primary? 1 : 0);
 			if (rc) return rc;
+			if ((rc = ensure_chain_arrays(c, c->hb.tot_a))) return rc;
 			if ((rc = upload_heavy_order(c))) return rc;
 		} else {
+			if (ensure_chain_arrays(c, c->hb.tot_a)) return MM355_ENOMEM;   // (the literal emulation's scratch: b, f, p, t8)
+			DevAnchors a = dev_anchors(c);
 			// every emitted task covers > 64 elements, so tot_a / 64 (+ one whole-array task per read) bounds each list
 			const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->hb.n_reads + 1024;
 			if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 512)) return MM355_ENOMEM;
