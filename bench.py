@@ -4,9 +4,10 @@
 A "step" is one pass of the hot path (sketch -> seed lookup -> chain -> extension -> hits) over one block of synthetic ONT reads.
 Default workload = BASELINE.json configs[2]: synthetic GRCh38-scale genome (3.09 Gbp, index built on the device), map-ont, 1 M reads
 N50 ~10 kb: the read set is cut into steps + warmup DISTINCT blocks of 73 728 reads (14 + 1 by default: 1 032 192 reads in the timed
-region, no read mapped twice in it; the warm-up block is a block of its own).  `value` is the rate with the reads already resident in
-HBM when the timed region starts (every block is uploaded before it); the PCIe-inclusive rate (host buffers in, hit records out:
-mm355_map_batch, the drop-in call) is timed afterwards on a few of the same blocks and reported beside it (`pcie_inclusive_mbases_per_s`).
+region, no read mapped twice in it; the warm-up block is a block of its own).  `value` is the PCIe-inclusive rate of the drop-in call
+over ALL timed blocks (H2D of the reads and D2H of the hit records inside the timed region): every sub-batch is handed to
+mm355_map_batch as host buffers, in input order (contiguous chunks, the way mappy_rs.map_batch cuts them).  The rate with the reads
+already resident in HBM (mm355_map_resident) is timed afterwards on a few of the same blocks: `resident_mbases_per_s`.
 
 Multi-GPU (--gpus N): ONE read set of N x --reads reads is cut into N contiguous shards balanced by cumulative bases (SURVEY 8e);
 rank r maps shard r against its own replica of the index; no data-path collective.  The driver launches the ranks with
@@ -44,10 +45,12 @@ def _parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="genome scale of the human workloads")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-pcie", "--no-resident", dest="no_pcie", action="store_true", help="skip the second timed region (PCIe-inclusive: mm355_map_batch on host buffers)")
-    ap.add_argument("--pcie-steps", type=int, default=3, help="blocks of the second (PCIe-inclusive) timed region")
+    ap.add_argument("--no-pcie", "--no-resident", dest="no_resident", action="store_true", help="skip the second timed region (reads resident in HBM: mm355_map_resident)")
+    ap.add_argument("--resident-steps", "--pcie-steps", dest="resident_steps", type=int, default=3, help="blocks of the second (HBM-resident) timed region")
+    ap.add_argument("--resident-value", action="store_true", help="experiment: time the whole region with the reads resident in HBM (then `value` is NOT the metric of SURVEY 8d; flagged in value_basis)")
     ap.add_argument("--synth-procs", type=int, default=0, help="worker processes that synthesise the reads (0 = automatic; 1 under a profiler)")
-    ap.add_argument("--no-bin", action="store_true", help="deal the reads of a step to its sub-batches round-robin instead of by length")
+    ap.add_argument("--oversubscribe", action="store_true", help="test hook: more ranks than GPUs on the node -- rank r uses GPU r mod (GPUs visible); the JSON line is flagged `oversubscribed`")
+    ap.add_argument("--bin", action="store_true", help="experiment: sort the reads of a step by length before cutting the sub-batches (untimed preprocessing the drop-in path does not do)")
     return ap.parse_args()
 
 
@@ -276,7 +279,7 @@ def main():
     depth = max(1, args.depth or wl["depth"])
     K, W = max(1, args.steps), max(0, args.warmup)
     # every step maps a block of its own; the library keeps at most 64 resident batches per context (depth of them per block)
-    max_blocks = 64 // depth
+    max_blocks = 63 // depth if args.resident_value else 1 << 30   # (resident batches: 64 slots per context, slot 0 is the drop-in call's)
     n_blocks = min(K + W, max_blocks)
     n_timed_blocks = min(K, n_blocks - min(W, 1)) if n_blocks > 1 else 1
 
@@ -297,8 +300,12 @@ def main():
         import torch
         import torch.distributed as dist_
         dist = dist_
+        n_dev = torch.cuda.device_count()
+        if args.oversubscribe and n_dev > 0:
+            local_rank = local_rank % n_dev
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+        # (MM355_BENCH_DIST_BACKEND=gloo: the oversubscribed test's fallback when RCCL refuses two ranks on one device)
+        dist.init_process_group(backend=os.environ.get("MM355_BENCH_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
     if rank == 0:
         ge.build()
     if dist is not None:
@@ -339,40 +346,41 @@ def main():
     per_block = len(reads) // n_blocks
     t0 = time.time()
     packed, rlens_np, block_bases = {}, {}, []
-    pcie_blocks = 0 if args.no_pcie else min(args.pcie_steps, n_timed_blocks)
+    resident_value = bool(args.resident_value)
+    n_res_blocks = n_timed_blocks if resident_value else (0 if args.no_resident else min(args.resident_steps, n_timed_blocks))
     from mappy_rs import shard_by_bases, order_by_length
     for b in range(n_blocks):
         blk = reads[b * per_block:(b + 1) * per_block]
         block_bases.append(sum(len(r) for r in blk))
-        # sub-batches of a step: reads of similar length together (the per-read kernels of a sub-batch cost the latency of its longest read),
-        # cut at equal cumulative bases -- mappy_rs.map_batch cuts its sub-batches the same way (order_by_length)
-        if args.no_bin:
-            subs = [blk[si::n_str] for si in range(n_str)]
-        else:
+        # sub-batches of a step: contiguous chunks of the block IN INPUT ORDER, the way mappy_rs.map_batch cuts an iterable (SUB_BATCH_READS
+        # reads each).  --bin: reads of similar length together (experiment; a preprocessing step the drop-in path does not perform)
+        if args.bin:
             blk = [blk[i] for i in order_by_length([len(r) for r in blk])]
             cut = shard_by_bases([len(r) for r in blk], n_str)
-            subs = [blk[cut[si]:cut[si + 1]] for si in range(n_str)]
+        else:
+            cut = [(len(blk) * si) // n_str for si in range(n_str + 1)]
         for si in range(n_str):
-            pk = _ffi.pack_reads(subs[si])
+            pk = _ffi.pack_reads(blk[cut[si]:cut[si + 1]])
             rlens_np[(b, si)] = np.asarray(pk[1], dtype=np.int64)
-            _ffi.check(L.mm355_batch_select(ctxs[si % n_thr], b * depth + si // n_thr))
-            _ffi.check(L.mm355_batch_upload(ctxs[si % n_thr], len(pk[2]), pk[0], pk[1]))
-            if b < pcie_blocks:
-                packed[(b, si)] = pk          # host buffers of the blocks the PCIe-inclusive region maps again
+            packed[(b, si)] = pk              # host buffers: what the drop-in call is handed
+            if b < n_res_blocks or (resident_value and b >= n_timed_blocks):   # blocks of the HBM-resident region: uploaded before it (slot 0 is the drop-in call's)
+                _ffi.check(L.mm355_batch_select(ctxs[si % n_thr], 1 + (b % (63 // depth)) * depth + si // n_thr))
+                _ffi.check(L.mm355_batch_upload(ctxs[si % n_thr], len(pk[2]), pk[0], pk[1]))
     cpu_sample = reads[:min(len(reads), per_block)]   # the CPU leg samples the first block
     n_reads_rank = len(reads)
     del reads
-    log("[bench] %d blocks of %d reads uploaded (%d resident sub-batches of ~%d reads) in %.1fs" %
-        (n_blocks, per_block, n_blocks * n_str, per_block // n_str, time.time() - t0))
+    log("[bench] %d blocks of %d reads packed (%d sub-batches of ~%d reads; %d blocks also resident in HBM for the second region) in %.1fs" %
+        (n_blocks, per_block, n_blocks * n_str, per_block // n_str, n_res_blocks, time.time() - t0))
     reads_per_sub_nominal = per_block // n_str
 
     def step_one(b, si, resident):
         ctx = ctxs[si % n_thr]
-        _ffi.check(L.mm355_batch_select(ctx, b * depth + si // n_thr))
         hp = C.POINTER(_ffi.Hits)()
-        if resident:   # the timed call of `value`: inputs already in HBM
+        if resident:   # inputs already in HBM
+            _ffi.check(L.mm355_batch_select(ctx, 1 + (b % (63 // depth)) * depth + si // n_thr))
             _ffi.check(L.mm355_map_resident(ctx, C.byref(mo), _ffi.OUT_CS, C.byref(hp)))
-        else:          # the drop-in call: host buffers in (H2D), hit records out (D2H)
+        else:          # the drop-in call, the timed call of `value`: host buffers in (H2D), hit records out (D2H)
+            _ffi.check(L.mm355_batch_select(ctx, 0))
             rarr, rl, keep = packed[(b, si)]
             _ffi.check(L.mm355_map_batch(ctx, C.byref(mo), len(keep), rarr, rl, _ffi.OUT_CS, C.byref(hp)))
         h = hp.contents
@@ -433,13 +441,13 @@ def main():
     timed_blocks = [k % n_timed_blocks for k in range(K)]
     warm_blocks = [(n_timed_blocks + k) % n_blocks for k in range(W)]
     if warm_blocks:
-        run_blocks(True, warm_blocks)
-    dt, aligned_all, bases_all, agg, n_mapped = timed(True, timed_blocks)             # `value`: reads resident in HBM
+        run_blocks(resident_value, warm_blocks)
+    dt, aligned_all, bases_all, agg, n_mapped = timed(resident_value, timed_blocks)   # `value`: the drop-in call, H2D / D2H inside
     step_ms = timed.step_ms
-    if pcie_blocks:
-        dt_p, aligned_p, _b, _agg, _n = timed(False, list(range(pcie_blocks)))      # host buffers in, records out (same reads again)
+    if n_res_blocks and not resident_value:
+        dt_r, aligned_r, _b, _agg, _n = timed(True, list(range(n_res_blocks)))      # the same reads again, resident in HBM
     else:
-        dt_p, aligned_p = None, None
+        dt_r, aligned_r = None, None
 
     if rank == 0:
         kern_ms = {"sketch": agg["ms_sketch"] / K, "seed_lookup": agg["ms_seed_lookup"] / K, "seed_expand": agg["ms_seed_expand"] / K,
@@ -486,37 +494,82 @@ def main():
         add_valu("k_chain", pairs, kern_ms["chain"], n_lfront, CHAIN_LANE_OPS_PER_PAIR, "Gpairs/s",
                  "predecessor evaluations of mg_lchain_dp per second against the VALU issue peak (%g lane-ops per pair); hbm_*: 16*n_a read + 20*n_a written" % CHAIN_LANE_OPS_PER_PAIR,
                  36.0 * n_a / max(1.0, pairs))
-        add_hbm("k_seed_lookup", lookup_bytes, kern_ms["seed_lookup"], n_lfront, "16*n_mz + 16*n_hit (minimizer read + one table slot)")
-        add_hbm("k_seed_expand", expand_bytes, kern_ms["seed_expand"], n_lfront, "8*n_a_multi + 16*n_a (pos[] entry read + anchor written)")
-        add_hbm("anchor sort", 32 * n_a, kern_ms["sort"], n_lfront, "2*16*n_a (one read + one write of every anchor; the radix passes actually needed are not counted)")
-        # dominant kernel = the extension kernel with the largest summed duration (each is timed alone with HIP events on the stream it is launched
-        # on; the rocprofv3 kernel statistics of the same command, profiles/, name the same kernel at the top).  The front stages are timed as
-        # event spans on the context's main stream, where kernels of other contexts interleave: they stay in roofline_all.
-        # Among them only the kernels whose launches fill the machine (one wave per alignment, 10^4..10^5 alignments per launch): a roofline
-        # fraction says nothing about the three classes of few, long problems (targets > 1024: k_ksw_regw8, k_ksw_rowl, k_ksw_extd2<512>) -- a
-        # launch of a few hundred blocks whose length is the dependent chain of its longest alignment, beside which the wide grids run.
-        # They are in roofline_all and in `latency_chains` with their own figure of merit (ms per launch).
+        # every kernel outside the extension rounds, each timed alone with a HIP-event pair on its stream (mm355_stats_t::ms_kernel)
+        mk = np.array(agg["ms_kernel"], dtype=np.float64) / K
+        n_keep = agg["n_a_kept"] / K if agg["n_a_kept"] > 0 else n_a
+        n_lit, n_vr, pairs_big = agg["n_a_literal"] / K, agg["n_v_rmq"] / K, agg["chain_pairs_big"] / K
+        bases_step = agg["n_bases"] / K
+        front = [   # (slot, kernel, algorithmic bytes per step or None, formula)
+            (0, "k_sketch", bases_step + 16 * n_mz, "L + 16*n_mz (bases read, minimizers written)"),
+            (1, "k_mzflt", 32 * n_mz, "2*16*n_mz"),
+            (2, "k_seed_lookup", lookup_bytes, "16*n_mz + 16*n_hit (minimizer read + one table slot; k_lookup_tiles + k_seed_lookup)"),
+            (3, "k_seed_select", 16 * n_hit + 8 * n_mz, "16*n_hit + 8*n_mz (hit records read, kept seeds written)"),
+            (4, "k_seed_expand", expand_bytes, "8*n_a_multi + 16*n_a (pos[] entry read + anchor written)"),
+            (5, "k_cull", 16 * n_a + 8 * n_a + 8 * n_keep, "16*n_a read + 8*n_a position words + 8*n_kept survivors written"),
+            (6, "k_asort", 16 * n_keep + 32 * n_keep, "8*n_kept words in + out, 16*n_kept anchors gathered + written"),
+            (7, "radix_sort_128x emulation (k_sort_level_mw, k_sort_tasks, k_tie_copy, k_tie_emit)", 32 * n_lit * 2, "2 passes of 2*16 B over the anchors of the reads with equal keys"),
+            (8, "k_chain_segments", 16 * n_keep, "16*n_kept"),
+            (11, "k_backtrack", 28 * n_keep, "(16 + 12)*n_kept: anchors, f / p / v"),
+            (12, "k_rmq_sort", 32 * n_vr, "2*16*n_v of the re-chained reads"),
+            (13, "k_rmq_dp", 40 * n_vr, "16*n_v read + 24*n_v written"),
+            (14, "k_rmq_backtrack", 28 * n_vr, "(16 + 12)*n_v"),
+            (15, "k_dp_gather", None, None),
+            (16, "k_ksw_backtrack", None, None),
+            (17, "k_extra", None, None),
+            (18, "k_read_codes", 3 * bases_step, "L read, 2*L written"),
+            (19, "k_pack_chains", None, None),
+        ]
+        for slot, name, b_, how in front:
+            if mk[slot] <= 0:
+                continue
+            if b_ is None:
+                roof[name] = dict(bound="hbm", achieved=None, peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=pmc_traffic(args.workload, reads_per_sub, name), kernel=name,
+                                  launches_per_step=n_lfront, ms_per_launch=round(mk[slot] / n_lfront, 4), formula="latency-bound walk: no algorithmic byte count defined")
+            else:
+                add_hbm(name, b_, mk[slot], n_lfront, how)
+        if mk[9] > 0:
+            add_valu("k_chain_big", pairs_big, mk[9], n_lfront, CHAIN_LANE_OPS_PER_PAIR, "Gpairs/s", "predecessor evaluations of the long segments (a wave each) against the VALU issue peak", 36.0 * n_keep / max(1.0, pairs))
+        if mk[10] > 0:
+            add_valu("k_chain_small", pairs - pairs_big, mk[10], n_lfront, CHAIN_LANE_OPS_PER_PAIR, "Gpairs/s", "predecessor evaluations of the short segments (a lane each) against the VALU issue peak", 36.0 * n_keep / max(1.0, pairs))
+        add_hbm("anchor sort stage", 32 * n_a, kern_ms["sort"], n_lfront, "2*16*n_a over the event span of the whole stage (cull + sort + literal emulation + its host round trips)")
+        # RULE: `roofline` = the kernel with the largest summed duration among ALL kernels of the path, each timed alone with HIP events on the
+        # stream it is launched on: the extension kernels (ms_dp_group) and every other kernel (ms_kernel).  No exclusion list; the rocprofv3
+        # kernel statistics of the same command (profiles/) rank the same kernels by the same quantity.
+        ms_all = {gnames[i]: float(agg["ms_dp_group"][i]) / K for i in range(19) if nl_g[i] > 0 and agg["ms_dp_group"][i] > 0}
+        ms_all.update({name: float(mk[slot]) for slot, name, _b, _h in front if mk[slot] > 0})
+        ms_all.update({n_: float(mk[sl]) for n_, sl in (("k_chain_big", 9), ("k_chain_small", 10)) if mk[sl] > 0})
+        dom = max(ms_all, key=ms_all.get)
         LATENCY_GROUPS = (8, 10, 17, 18)
-        ms_wide = [0.0 if i in LATENCY_GROUPS else agg["ms_dp_group"][i] for i in range(len(agg["ms_dp_group"]))]
-        gi = int(np.argmax(ms_wide))
-        dom = gnames[gi]
         latency_chains = {gnames[i]: dict(ms_per_launch=round(agg["ms_dp_group"][i] / max(1.0, nl_g[i]), 3), ms_per_step=round(agg["ms_dp_group"][i] / K, 3),
                                           cells_per_launch=int(cells_g[i] / max(1.0, nl_g[i])))
                           for i in LATENCY_GROUPS if nl_g[i] > 0 and agg["ms_dp_group"][i] > 0}
+        # measured issue roof of the row sweep's instruction mix (profiles/r03_valubench.txt: 4.4 cycles per wave-instruction per SIMD at full
+        # occupancy = 0.558e12 wave-instructions/s on 1024 SIMDs) beside the spec roof: x cells per wave-instruction of the kernel
+        MEASURED_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4.4
+        for nm_, cpi in (("k_ksw_row<2>", 128 / 74.0), ("k_ksw_row<4>", 128 / 74.0), ("k_ksw_row<8>", 128 / 74.0)):
+            if nm_ in roof:
+                roof[nm_]["peak_measured_issue"] = round(MEASURED_WAVE_INSTR_PER_S * cpi / 1e9, 1)
+                roof[nm_]["frac_of_measured_issue"] = round(roof[nm_]["achieved"] / roof[nm_]["peak_measured_issue"], 4)
+        # SURVEY 8(d)'s B_seed has four terms: lookup (16*n_mz + 16*n_hit) and expansion (8*n_a_multi + 16*n_a) -- over both kernels' time
+        seed4 = dict(bound="hbm", achieved=round((lookup_bytes + expand_bytes) / ((mk[2] + mk[4]) * 1e-3) / 1e9, 3) if mk[2] + mk[4] > 0 else 0.0, peak=HBM_PEAK_GBS, unit="GB/s",
+                     kernel="k_seed_lookup + k_seed_expand", algorithmic_bytes=int((lookup_bytes + expand_bytes) / n_lfront), ms_per_launch=round((mk[2] + mk[4]) / n_lfront, 4),
+                     formula="B_seed = 16*n_mz + 16*n_hit + 8*n_a_multi + 16*n_a over the two kernels' HIP-event time")
+        seed4["frac"] = round(seed4["achieved"] / HBM_PEAK_GBS, 5)
         # the kernel the north star names: seed lookup against the HBM roof, and against what the memory system delivers for uniformly random
         # 128-byte lines of a table this size (profiles/r03_random_line_roof.json, measured by tools/linebench on the same chip)
-        rl = dict(roof["k_seed_lookup"])
+        rl = dict(roof.get("k_seed_lookup", {}))
+        rl["four_term_B_seed"] = seed4
         try:
             rr = json.load(open(os.path.join(ROOT, "profiles", "r03_random_line_roof.json")))
             rl["random_line_roof_gbs"] = rr["random_128B_lines_GBs"]
-            if rl["traffic"]:
+            if rl.get("traffic"):
                 rl["traffic_gbs"] = round(rl["traffic"] / (rl["ms_per_launch"] * 1e-3) / 1e9, 1)
                 rl["traffic_frac_of_random_line_roof"] = round(rl["traffic_gbs"] / rr["random_128B_lines_GBs"], 4)
         except (OSError, ValueError, KeyError):
             pass
         pool_threads = int(os.environ.get("MM355_HOST_THREADS", "14"))
         out = {
-            "metric": METRIC,
+            "metric": METRIC, "oversubscribed": bool(args.oversubscribe),
             "value": round(aligned_all / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/int32 (+f32 chaining gap cost, f64 RMQ priority)", "data": "synthetic",
@@ -527,18 +580,22 @@ def main():
                                     % (n_per_step * n_blocks * world, world, n_blocks, n_timed_blocks, n_blocks - n_timed_blocks),
                            streams_per_gpu=n_thr, sub_batches_per_stream=depth, mbases_per_step_per_gpu=round(sum(block_bases[b] for b in timed_blocks) / K / 1e6, 3),
                            preset=wl["preset"], parallelism="reads sharded over %d GPU(s), index replicated, no collective" % world),
-            "value_basis": "reads resident in HBM when the timed region starts (every block uploaded beforehand), hit records returned to the host; "
-                           "the PCIe-inclusive rate of the drop-in call (host buffers in) is pcie_inclusive_mbases_per_s",
+            "value_basis": ("EXPERIMENT (--resident-value): reads resident in HBM when the timed region starts; not the metric of SURVEY 8d" if resident_value else
+                            "PCIe-inclusive (SURVEY 8d): every timed sub-batch is handed to the drop-in call mm355_map_batch as host buffers (H2D of the reads, "
+                            "D2H of the hit records inside the timed region), sub-batches cut in input order; resident_mbases_per_s: the same call sequence "
+                            "with the reads already in HBM, a few of the same blocks") + ("; EXPERIMENT (--bin): blocks sorted by length beforehand" if args.bin else ""),
             "input_mbases_per_s": round(bases_all / dt / 1e6, 3),
             "step_ms": dict(median=float(np.median(step_ms)), min=min(step_ms), max=max(step_ms), all=step_ms,
                             note="completion of the last sub-batch of every step, rank 0 (the threads do not wait for one another between steps)"),
-            "pcie_inclusive_mbases_per_s": None if dt_p is None else round(aligned_p / dt_p / 1e6, 3),
-            "roofline": dict(roof[dom], rule="the extension kernel with the largest summed duration among those whose launches fill the machine; "
-                                                "the classes of few long alignments are latency chains (latency_chains, roofline_all)"),
+            "resident_mbases_per_s": None if dt_r is None else round(aligned_r / dt_r / 1e6, 3),
+            "roofline": dict(roof[dom], ms_per_step=round(ms_all[dom], 3),
+                             rule="the kernel with the largest summed duration among ALL kernels of the path (extension kernels and every other kernel, each timed "
+                                  "alone with HIP events on the stream it is launched on; kernel_ms_per_step_all) -- no exclusion list"),
+            "kernel_ms_per_step_all": {k: round(v, 3) for k, v in sorted(ms_all.items(), key=lambda kv: -kv[1])},
             "roofline_seed_lookup": rl, "roofline_all": roof, "latency_chains": latency_chains, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
             "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(19) if nl_g[i] > 0},
             "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(19) if nl_g[i] > 0},
-            "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
+            "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_kept_by_cull=int(n_keep), n_a_sorted_literally=int(n_lit), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
                                       n_dp_jobs=int(agg["n_dp_jobs"] / K), n_sort_tie_reads=int(agg["n_sort_tie_reads"] / K),
                                       n_rmq_reads=int(agg["n_rmq_reads"] / K), n_rmq_host_fallback=int(agg["n_rmq_host"] / K),
                                       rmq_window_elements=int(agg["rmq_scanned"] / K)),

@@ -163,6 +163,15 @@ typedef struct {
 	double host_cpu_ms;                          /* CPU time (not wall) the host tail of the last call spent, summed over the pool threads */
 	int64_t n_a_kept;                            /* anchors left after the cull of the anchor-rich sort path (x-components too small to chain dropped);
 	                                                0 when the batch took the literal path for every read */
+	/* every kernel outside the extension rounds, timed alone with a HIP-event pair on the stream it is launched on (the extension kernels:
+	 * ms_dp_group).  Slots: 0 sketch, 1 mz_flt, 2 seed lookup (tile list + probes), 3 seed select, 4 seed expand, 5 anchor cull, 6 anchor
+	 * sort (LDS), 7 literal radix_sort_128x emulation (reads with equal keys), 8 chain segments, 9 chain (long segments, a wave each),
+	 * 10 chain (short segments, a lane each), 11 chain backtrack, 12 / 13 / 14 mg_lchain_rmq sort / recurrence / backtrack, 15 extension
+	 * gather, 16 extension backtrack (CIGAR), 17 mm_update_extra + cs walk, 18 read codes, 19 chain / anchor pack */
+	double ms_kernel[24];
+	int64_t chain_pairs_big;                     /* k_chain_big's share of chain_pairs */
+	int64_t n_a_literal;                         /* anchors (all of them, culled ones included) of the reads that were sorted literally */
+	int64_t n_v_rmq;                             /* anchors mg_lchain_rmq chained on the device */
 } mm355_stats_t;
 
 /* sketch: minimizers of each read (mm_sketch). mz_off[n_reads+1] host array is filled; mz = (x,y) pairs */

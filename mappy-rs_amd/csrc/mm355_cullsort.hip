@@ -321,6 +321,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	if (do_cull) {
 		static const bool attr = [] { return hipFuncSetAttribute((const void*)k_cull, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CS_WPL * 4) == hipSuccess; }();
 		if (!attr) return MM355_EHIP;
+		KtScope ks(c, KT_CULL, c->st);
 		hipLaunchKernelGGL(k_cull, dim3((unsigned)n_reads), dim3(CS_NT), 3 * CS_WPL * 4, c->st, c->dix, aoff, c->a.as<mm128>(), keys, surv, d_nk, n_reads, cp);
 	} else hipLaunchKernelGGL(k_keys_all, dim3((unsigned)n_reads), dim3(256), 0, c->st, c->dix, aoff, c->a.as<mm128>(), surv, d_nk, n_reads, cp);
 	// pinned staging: [n_keep: nr x i32][aoff2: (nr + 1) x i64][flags: nr x u8][lists: nr x i32]
@@ -347,6 +348,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	if (n_small + n_big) HIPCHK(hipMemcpyAsync(d_list, h_list, (size_t)(n_small + n_big) * 4, hipMemcpyHostToDevice, c->st));
 	const double t1 = mm355_now_ms();
 	HIPCHK(hipMemsetAsync(c->sort_flag.p, 0, nr, c->st));   // (reads without survivors are not listed: their flag stays 0)
+	mm355_kt(c, KT_ASORT, 0, c->st);
 	if (n_small) hipLaunchKernelGGL((k_asort<256, CS_SMALL_CAP>), dim3((unsigned)n_small), dim3(256), CS_SMALL_CAP * 8, c->st, d_list, n_small, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
 	                                c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
 	if (n_big) {
@@ -355,6 +357,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_big), dim3(1024), CS_BIG_CAP * 8, c->st, d_list + n_small, n_big, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
 		                   c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
 	}
+	mm355_kt(c, KT_ASORT, 1, c->st);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(h_flag, c->sort_flag.p, nr, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
@@ -363,7 +366,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	int n_tie = 0; int64_t tt = 0;
 	for (int i = 0; i < n_reads; ++i) if (h_nk[i] > 0 && h_flag[i]) { ++n_tie; tt += hb.n_a[i]; }
 	c->stats.n_sort_fast_reads += n_reads; c->stats.n_sort_tie_reads += n_tie;
-	c->stats.n_a_kept += tk;
+	c->stats.n_a_kept += tk; c->stats.n_a_literal += tt;
 	if (n_tie) {
 		const double t2 = mm355_now_ms();
 		const size_t na = (size_t)tt + 64;
@@ -396,7 +399,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		const size_t task_cap = (size_t)tt / 64 + (size_t)n_tie + 1024;
 		if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 512)) return MM355_ENOMEM;
 		DevBatch bt; memset(&bt, 0, sizeof(bt));
-		if (mm355_launch_sort(bt, at, c->err.as<int>(), ht, nb, nm, ns, (size_t)tt, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
+		if (mm355_launch_sort(bt, at, c->err.as<int>(), ht, nb, nm, ns, (size_t)tt, c->sort_tasks.p, task_cap, c->st, c)) return MM355_EHIP;
 		hipLaunchKernelGGL(k_tie_emit, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, d_off2, c->tie_a.as<mm128>(), c->b.as<mm128>());
 		HIPCHK(hipGetLastError());
 		HIPCHK(mm355_wait_stream(c->st));   // (the pinned lists above are reused by the next call)

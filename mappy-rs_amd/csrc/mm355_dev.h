@@ -84,22 +84,29 @@ struct DevAnchors {
 	const int32_t *tcnt;       // optional (fast sort): equal-key pair counts of the sorted array, see WalkScratch
 };
 
+// Per-kernel HIP-event timers (mm355_stats_t::ms_kernel): a begin / end pair of events around ONE kernel (or a run of kernels with no host wait
+// between them) on the stream it is launched on.  kt = the context, or null for "not timed".  bench.py's `roofline` is the entry with the
+// largest summed duration among these and the extension kernels' own timers (ms_dp_group) -- no exclusion list.
+enum { KT_SKETCH = 0, KT_MZFLT, KT_LOOKUP, KT_SELECT, KT_EXPAND, KT_CULL, KT_ASORT, KT_LITERAL, KT_CHAIN_SEG, KT_CHAIN_BIG, KT_CHAIN_SMALL, KT_BACKTRACK,
+       KT_RMQ_SORT, KT_RMQ_DP, KT_RMQ_BT, KT_DP_GATHER, KT_DP_BACKTRACK, KT_EXTRA, KT_CODES, KT_PACK, KT_N };
 #ifdef __HIPCC__
+void mm355_kt(void *kt, int slot, int end, hipStream_t st);
+struct KtScope { void *kt; int slot; hipStream_t st; KtScope(void *k, int s, hipStream_t t) : kt(k), slot(s), st(t) { if (kt) mm355_kt(kt, slot, 0, st); } ~KtScope() { if (kt) mm355_kt(kt, slot, 1, st); } };
 int mm355_sketch_chunk_size(void);
 void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
-                         const int64_t *read_chunk0, int32_t *chunk_n, hipStream_t st);
-void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
+                         const int64_t *read_chunk0, int32_t *chunk_n, hipStream_t st, void *kt = 0);
+void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st, void *kt = 0);
 void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
-                              unsigned long long *hit_ctr, unsigned int *tile_ctr, hipStream_t st);
-void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st);
-void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st);
+                              unsigned long long *hit_ctr, unsigned int *tile_ctr, hipStream_t st, void *kt = 0);
+void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st, void *kt = 0);
+void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st, void *kt = 0);
 struct SortTask { int32_t read; uint32_t beg, end; int32_t s; };   // a bucket [beg, end) of one read's array, to be sorted from byte shift s
-int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st);
+int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st, void *kt = 0);
 int mm355_sort_heavy_threshold(void);
 int mm355_sort_medium_threshold(void);
 int mm355_chain_chunk(void);
 int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr,
-                       const void *chunks, int n_chunks, hipStream_t st);
-void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st);
+                       const void *chunks, int n_chunks, hipStream_t st, void *kt = 0);
+void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st, void *kt = 0);
 #endif
 hipError_t mm355_wait_stream(hipStream_t st);   // like hipStreamSynchronize, but the calling thread sleeps

@@ -754,6 +754,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		else { for (int g = 0; g < 2 * DP_N_CLASS; ++g) if (n_grp[g] && classes[g >> 1].kind != 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0)); }
 		for (int g = 1; g < 8; g += 2) if (n_grp[g] && classes[g >> 1].kind == 0) HIPCHK(hipStreamWaitEvent(c->st, c->dp_ev[g], 0));   // the exact register classes
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
+		KtScope ks_bt(c, KT_DP_BACKTRACK, c->st);
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
 		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
 	}
@@ -1002,12 +1003,14 @@ int mm355_extra_run(mm355_ctx *c, const mm355_mapopt_t *mo, const Mm355ExtraJob 
 	if (n_segs) HIPCHK(hipMemcpyAsync(d_segs, segs, n_segs * sizeof(Mm355ExtraJob), hipMemcpyHostToDevice, c->st));
 	HIPCHK(hipMemcpyAsync(d_first, seg_first, first_b, hipMemcpyHostToDevice, c->st));
 	if (n_cig) HIPCHK(hipMemcpyAsync(c->x_cig.p, cig, n_cig * 4, hipMemcpyHostToDevice, c->st));
+	mm355_kt(c, KT_EXTRA, 0, c->st);
 	if (n_segs) {
 		hipLaunchKernelGGL(k_extra, dim3((unsigned)((n_segs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dix, c->rq.as<uint8_t>(), d_segs, (int)n_segs,
 		                   c->x_cig.as<uint32_t>(), sc, c->x_cs.as<char>(), d_so, want);
 	}
 	hipLaunchKernelGGL(k_extra_compose, dim3((unsigned)((n_regions + 255) / 256)), dim3(256), 0, c->st, d_so, d_first, (int)n_regions, d_ro, want);
 	if (want) hipLaunchKernelGGL(k_extra_scan, dim3(1), dim3(256), 0, c->st, d_ro, (int)n_regions);
+	mm355_kt(c, KT_EXTRA, 1, c->st);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpyAsync(c->h_xout.p, d_ro, n_regions * sizeof(Mm355ExtraOut), hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
@@ -1035,6 +1038,7 @@ int mm355_dp_gather(mm355_ctx *c, const DpGather *g, size_t n, size_t q_tot, siz
 	if (n == 0) return 0;
 	if (c->dp_q.ensure(q_tot + 64) || c->dp_t.ensure(t_tot + 64) || c->dp_gather.ensure(n * sizeof(DpGather))) return MM355_ENOMEM;
 	HIPCHK(hipMemcpyAsync(c->dp_gather.p, g, n * sizeof(DpGather), hipMemcpyHostToDevice, c->st));
+	KtScope ks(c, KT_DP_GATHER, c->st);
 	hipLaunchKernelGGL(k_dp_gather, dim3((unsigned)n), dim3(256), 0, c->st, c->dix, c->dp_gather.as<DpGather>(), (int)n,
 	                   c->rq.as<uint8_t>(), c->dp_q.as<uint8_t>(), c->dp_t.as<uint8_t>());
 	HIPCHK(hipGetLastError());
@@ -1046,6 +1050,7 @@ int mm355_run_read_codes(mm355_ctx *c)
 	if (c->hb.n_reads == 0) return 0;
 	if (c->rq.ensure((size_t)c->hb.n_bytes * 2 + 64)) return MM355_ENOMEM;
 	DevBatch b; b.n_reads = (int32_t)c->hb.n_reads; b.seq = c->seq.as<uint8_t>(); b.roff = c->roff.as<int64_t>(); b.rlen = c->rlen.as<int32_t>(); b.order = c->order.as<int32_t>(); b.prof = 0;
+	KtScope ks(c, KT_CODES, c->st);
 	hipLaunchKernelGGL(k_read_codes, dim3((unsigned)c->hb.n_reads), dim3(256), 0, c->st, b, c->rq.as<uint8_t>());
 	HIPCHK(hipGetLastError());
 	return 0;

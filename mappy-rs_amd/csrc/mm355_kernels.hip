@@ -625,13 +625,9 @@ __device__ inline uint32_t block_ordered_prefix(bool flag, uint32_t &base, MwLds
 // than MW_BIG elements, <256, MW_BIG + 64 B> for the medium ones (six blocks per CU instead of one).  Children go to the list of their
 // own size class; ctr = { next-level big, next-level medium, wave tasks (running total) }.
 template <typename T, typename Key, int NT, int LABCAP>
-__global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortTask *tasks, const unsigned int *n_tasks_p, SortTask *out_big, SortTask *out_med, SortTask *out_small,
-                                                      unsigned int *ctr, unsigned int *ctr_small, uint32_t big_min, uint32_t med_min, int *err)
+__device__ inline void mw_level_task(MwLds<NT> &L, uint8_t *lds_lab, const DevAnchors &an, const SortTask tk, SortTask *out_big, SortTask *out_med, SortTask *out_small,
+                                     unsigned int *ctr, unsigned int *ctr_small, uint32_t big_min, uint32_t med_min)
 {
-	__shared__ MwLds<NT> L;
-	extern __shared__ uint8_t lds_lab[];   // LABCAP labels
-	if (blockIdx.x >= *n_tasks_p) return;   // (the grid is an upper bound: the list lengths stay on the device, no host round trip per level)
-	const SortTask tk = tasks[blockIdx.x];
 	const int64_t o = an.aoff[tk.read];
 	T *a = SortArr<T>::arr(an, o);
 	const WalkScratch ws = SortArr<T>::ws(an, o);
@@ -731,6 +727,21 @@ __global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortT
 			else out_small[atomicAdd(ctr_small, 1u)] = c;
 		} else if (sz > 1) mm_rs_insertsort(a + beg + b0, a + beg + b0 + sz, key);
 	}
+}
+// The list length stays on the device (no host round trip per level) and the grid is a bound on it: a block takes the tasks blockIdx.x,
+// blockIdx.x + gridDim.x, ...  A level that turns out empty costs a few dozen blocks that leave at once -- not hundreds of 120-KB-LDS
+// blocks that each wait for a whole free CU beside the other contexts' kernels.
+template <typename T, typename Key, int NT, int LABCAP>
+__global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortTask *tasks, const unsigned int *n_tasks_p, SortTask *out_big, SortTask *out_med, SortTask *out_small,
+                                                      unsigned int *ctr, unsigned int *ctr_small, uint32_t big_min, uint32_t med_min, int *err)
+{
+	__shared__ MwLds<NT> L;
+	extern __shared__ uint8_t lds_lab[];   // LABCAP labels
+	const unsigned int n_tasks = *n_tasks_p;
+	for (unsigned int t = blockIdx.x; t < n_tasks; t += gridDim.x) {
+		mw_level_task<T, Key, NT, LABCAP>(L, lds_lab, an, tasks[t], out_big, out_med, out_small, ctr, ctr_small, big_min, med_min);
+		__syncthreads();
+	}
 	(void)err;
 }
 
@@ -740,19 +751,22 @@ __global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTa
 {
 	__shared__ SortLds L;
 	__shared__ mm128 stage[2048];
-	if (blockIdx.x >= *n_tasks_p) return;
-	const SortTask tk = tasks[blockIdx.x];
-	const int64_t o = an.aoff[tk.read];
-	if (tk.end - tk.beg <= MM355_RS_MIN_SIZE) {   // only a whole array can be this short (children are larger): radix_sort = insertion sort
-		wave_rank_sort_small(SortArr<T>::arr(an, o) + tk.beg, tk.end - tk.beg, Key());
-		return;
+	const unsigned int n_tasks = *n_tasks_p;
+	for (unsigned int t = blockIdx.x; t < n_tasks; t += gridDim.x) {   // (the grid is a bound on the list length, which stays on the device)
+		const SortTask tk = tasks[t];
+		const int64_t o = an.aoff[tk.read];
+		if (tk.end - tk.beg <= MM355_RS_MIN_SIZE) {   // only a whole array can be this short (children are larger): radix_sort = insertion sort
+			wave_rank_sort_small(SortArr<T>::arr(an, o) + tk.beg, tk.end - tk.beg, Key());
+		} else {
+			WalkScratch ws = SortArr<T>::ws(an, o);
+			ws.out = (T*)ws.out + tk.beg; ws.fpos += tk.beg; ws.rank += tk.beg; ws.flab += tk.beg; if (ws.tcnt) ws.tcnt += tk.beg;
+			if (threadIdx.x == 0) { L.stk_n = 0; L.overflow = 0; }
+			__syncthreads();
+			wave_rs_core<true>(SortArr<T>::arr(an, o) + tk.beg, tk.end - tk.beg, tk.s, Key(), &L, (T*)stage, (uint32_t)(sizeof(stage) / sizeof(T)), &ws);
+			if (threadIdx.x == 0 && L.overflow) *err = 1;
+		}
+		__syncthreads();
 	}
-	WalkScratch ws = SortArr<T>::ws(an, o);
-	ws.out = (T*)ws.out + tk.beg; ws.fpos += tk.beg; ws.rank += tk.beg; ws.flab += tk.beg; if (ws.tcnt) ws.tcnt += tk.beg;
-	if (threadIdx.x == 0) { L.stk_n = 0; L.overflow = 0; }
-	__syncthreads();
-	wave_rs_core<true>(SortArr<T>::arr(an, o) + tk.beg, tk.end - tk.beg, tk.s, Key(), &L, (T*)stage, (uint32_t)(sizeof(stage) / sizeof(T)), &ws);
-	if (threadIdx.x == 0 && L.overflow) *err = 1;
 }
 
 // host side: the initial tasks (whole arrays of the reads to sort, at byte 56) are already in the three size-class lists on the device.
@@ -773,7 +787,8 @@ static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2]
 	h[0] = (unsigned int)n_big; h[1] = (unsigned int)n_med; h[2 * (MW_LEVELS + 1)] = (unsigned int)n_small;
 	if (hipMemcpyAsync(d_ctr, h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess) return -1;   // (pageable source: the copy is staged before the call returns)
 	unsigned int *d_small_ctr = d_ctr + 2 * (MW_LEVELS + 1);
-	const size_t cap_big = std::min(task_cap, n_elems / big_min + 1), cap_med = std::min(task_cap, n_elems / med_min + 1);
+	// grids behind level 0: a bound on the list length, capped -- the blocks stride over the list
+	const size_t cap_big = std::min<size_t>(std::min(task_cap, n_elems / big_min + 1), 96), cap_med = std::min<size_t>(std::min(task_cap, n_elems / med_min + 1), 1024);
 	int cur = 0;
 	for (int level = 0; level < MW_LEVELS; ++level) {
 		const size_t gb = level == 0? (size_t)n_big : cap_big, gm = level == 0? (size_t)n_med : cap_med;
@@ -783,7 +798,7 @@ static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2]
 		if (gm) hipLaunchKernelGGL((k_sort_level_mw<T, Key, 256, MW_MED_LAB>), dim3((unsigned)gm), dim3(256), MW_MED_LAB, st, an, d_med[cur], c_in + 1, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err);
 		cur ^= 1;
 	}
-	const size_t gs = n_big + n_med == 0? (size_t)n_small : task_cap;
+	const size_t gs = n_big + n_med == 0? (size_t)n_small : std::min<size_t>(task_cap, 16384);
 	if (gs) hipLaunchKernelGGL((k_sort_tasks<T, Key>), dim3((unsigned)gs), dim3(WAVE), 0, st, an, d_small, d_small_ctr, err);
 	return 0;
 }
@@ -956,7 +971,7 @@ __global__ __launch_bounds__(256) void k_chain_small(DevParams pr, DevBatch bt, 
 		}
 	}
 	for (int o2 = 32; o2 > 0; o2 >>= 1) pairs += __shfl_down(pairs, o2);
-	if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(pairs_ctr + (blockIdx.x & 63), pairs);
+	if ((threadIdx.x & 63) == 0 && pairs) atomicAdd(pairs_ctr + (blockIdx.x & 31), pairs);          // words 0..31: short segments
 }
 
 // one wave per long segment
@@ -1116,7 +1131,7 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 	}
 #undef CH_SYNC
 	KPROF(12);
-	if (lane == 0 && pairs) atomicAdd(pairs_ctr + (blockIdx.x & 63), pairs);
+	if (lane == 0 && pairs) atomicAdd(pairs_ctr + 32 + (blockIdx.x & 31), pairs);                     // words 32..63: long segments
 }
 
 #include "mm355_btcore.h"
@@ -1131,9 +1146,10 @@ __global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, D
 // ------------------------------------------------------------------ launchers
 int mm355_sketch_chunk_size(void) { return SK_CHUNK; }
 void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
-                         const int64_t *read_chunk0, int32_t *chunk_n, hipStream_t st)
+                         const int64_t *read_chunk0, int32_t *chunk_n, hipStream_t st, void *kt)
 {
 	if (bt.n_reads == 0) return;
+	KtScope ks(kt, KT_SKETCH, st);
 	if (n_chunks > 0) {
 		const char *e = getenv("MM355_SKETCH_SPARSE_MAX");   // read per launch: the parity tests force either form
 		const int sparse_max = e? atoi(e) : 2048;             // chunks
@@ -1147,15 +1163,17 @@ void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, c
 	}
 	hipLaunchKernelGGL(k_sketch_compact, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, sd, read_chunk0, chunk_n);
 }
-void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
+void mm355_launch_mzflt(const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st, void *kt)
 {
 	if (bt.n_reads == 0) return;
+	KtScope ks(kt, KT_MZFLT, st);
 	hipLaunchKernelGGL(k_mzflt, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, sd);
 }
 void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
-                              unsigned long long *hit_ctr, unsigned int *tile_ctr, hipStream_t st)
+                              unsigned long long *hit_ctr, unsigned int *tile_ctr, hipStream_t st, void *kt)
 {
 	if (bt.n_reads == 0 || n_chunks == 0) return;
+	KtScope ks(kt, KT_LOOKUP, st);
 	int4 *tiles = (int4*)sd.hl;   // (the hit list of k_seed_select: free until then; 4 bytes per minimizer slot >= 16 per 384-slot table entry)
 	(void)hipMemsetAsync(tile_ctr, 0, 4, st);
 	hipLaunchKernelGGL(k_lookup_tiles, dim3((n_chunks + 1023) / 1024), dim3(1024), 0, st, bt, sd, chunk_read, chunk_start, n_chunks, tiles, tile_ctr);
@@ -1163,23 +1181,26 @@ void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &
 	const int grid = n_chunks < lk_grid? n_chunks : lk_grid;   // resident blocks walk the live tiles
 	hipLaunchKernelGGL(k_seed_lookup, dim3(grid), dim3(256), 0, st, ix, bt, sd, (const int4*)tiles, (const unsigned int*)tile_ctr, hit_ctr);
 }
-void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st)
+void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st, void *kt)
 {
 	if (bt.n_reads == 0) return;
+	KtScope ks(kt, KT_SELECT, st);
 	hipLaunchKernelGGL(k_seed_select, dim3(bt.n_reads), dim3(WAVE), 0, st, ix, pr, bt, sd);
 }
-void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st)
+void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st, void *kt)
 {
 	if (bt.n_reads == 0) return;
+	KtScope ks(kt, KT_EXPAND, st);
 	hipLaunchKernelGGL(k_seed_expand, dim3(bt.n_reads), dim3(256), 0, st, ix, pr, bt, sd, an);
 }
 // Literal radix_sort_128x of the listed reads.  h_tasks: the initial whole-read tasks (byte 56) grouped by size class -- n_big entries
 // (> MW_BIG anchors: 1024-thread levels), then n_med (> MW_MED: 256-thread levels), then n_small (one wave each) -- in pinned or otherwise
 // stable host memory until the stream has consumed it.  n_elems: elements of all listed arrays together.  task_buf: device scratch for 5 task
 // lists of `task_cap` entries + 64 counters.
-int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st)
+int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st, void *kt)
 {
 	(void)bt;
+	KtScope ks(kt, KT_LITERAL, st);
 	const int n = n_big + n_med + n_small;
 	if (n == 0) return 0;
 	SortTask *base = (SortTask*)task_buf;
@@ -1208,20 +1229,23 @@ int mm355_sort_medium_threshold(void)   // buckets above this (and up to the hea
 // of every mm355_chain_chunk()-anchor piece of every read
 int mm355_chain_chunk(void) { return SEG_CHUNK; }
 int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr,
-                       const void *chunks, int n_chunks, hipStream_t st)
+                       const void *chunks, int n_chunks, hipStream_t st, void *kt)
 {
 	if (bt.n_reads == 0 || n_chunks == 0) return 0;
 	if (hipMemsetAsync(ctr, 0, 8, st) != hipSuccess) return -1;
+	if (kt) mm355_kt(kt, KT_CHAIN_SEG, 0, st);
 	hipLaunchKernelGGL(k_chain_segments, dim3(n_chunks), dim3(256), 0, st, pr, bt, an, (const int2*)chunks, n_chunks, (ChainSeg*)seg_small, (ChainSeg*)seg_big, ctr, CHAIN_SMALL);
+	if (kt) mm355_kt(kt, KT_CHAIN_SEG, 1, st);
 	unsigned int h[2] = {0, 0};
 	if (hipMemcpyAsync(h, ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
 	if (mm355_wait_stream(st) != hipSuccess) return -1;
-	if (h[1]) hipLaunchKernelGGL(k_chain_big, dim3(h[1]), dim3(WAVE), 0, st, pr, bt, an, (const ChainSeg*)seg_big, h[1], pairs);
-	if (h[0]) hipLaunchKernelGGL(k_chain_small, dim3((h[0] + 255) / 256), dim3(256), 0, st, pr, bt, an, (const ChainSeg*)seg_small, h[0], pairs);
+	if (h[1]) { KtScope ks(kt, KT_CHAIN_BIG, st); hipLaunchKernelGGL(k_chain_big, dim3(h[1]), dim3(WAVE), 0, st, pr, bt, an, (const ChainSeg*)seg_big, h[1], pairs); }
+	if (h[0]) { KtScope ks(kt, KT_CHAIN_SMALL, st); hipLaunchKernelGGL(k_chain_small, dim3((h[0] + 255) / 256), dim3(256), 0, st, pr, bt, an, (const ChainSeg*)seg_small, h[0], pairs); }
 	return 0;
 }
-void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st)
+void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st, void *kt)
 {
 	if (bt.n_reads == 0) return;
+	KtScope ks(kt, KT_BACKTRACK, st);
 	hipLaunchKernelGGL(k_backtrack, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, an, err, heavy_first);
 }

@@ -371,9 +371,11 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 		HIPCHK(hipMemcpyAsync(d_uo, uo.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipMemcpyAsync(d_vo, vo.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipMemcpyAsync(d_mo, mo_.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, c->st));
+		mm355_kt(c, KT_PACK, 0, c->st);
 		hipLaunchKernelGGL(k_pack_chains, dim3((unsigned)n_reads), dim3(256), 0, c->st, (int)n_reads, c->aoff.as<int64_t>(), c->roff.as<int64_t>(),
 		                   c->n_u.as<int32_t>(), c->n_v.as<int32_t>(), c->n_mini.as<int32_t>(), d_uo, d_vo, d_mo, c->u.as<uint64_t>(), c->a.as<mm128>(),
 		                   c->mini_pos.as<uint64_t>(), d_pu, d_pa, d_pm);
+		mm355_kt(c, KT_PACK, 1, c->st);
 		HIPCHK(hipGetLastError());
 		if (tu) HIPCHK(hipMemcpyAsync(pu, d_pu, (size_t)tu * 8, hipMemcpyDeviceToHost, c->st));
 		if (tv) HIPCHK(hipMemcpyAsync(pa, d_pa, (size_t)tv * 16, hipMemcpyDeviceToHost, c->st));

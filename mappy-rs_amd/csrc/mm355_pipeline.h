@@ -99,7 +99,8 @@ struct mm355_ctx {
 	DBuf x_jobs, x_cig, x_cs, x_out, x_dense; HBuf h_xjobs, h_xcig, h_xout, h_xcs;   // k_extra (mm_update_extra's walk + cs on the device)
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
-	std::vector<hipEvent_t> tev; std::vector<double*> tacc; int n_tpend = 0;   // lazy stage timers (EvTimer)
+	std::vector<hipEvent_t> tev; std::vector<double*> tacc; int n_tpend = 0;   // lazy stage timers (EvTimer, mm355_kt)
+	int kt_open[KT_N] = {};   // open mm355_kt pair of a slot: its event-pair index + 1
 	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[24] = {}, dp_ev0[24] = {}, dp_ev1[24] = {};
 	HostBatch hb;
 };
@@ -137,7 +138,7 @@ struct EvTimer {
 	mm355_ctx *c; int slot;
 	EvTimer(mm355_ctx *c_, double *a) : c(c_)
 	{
-		if (c->n_tpend >= 48) mm355_timers_resolve(c);
+		if (c->n_tpend >= 120) mm355_timers_resolve(c);
 		slot = c->n_tpend++;
 		while ((int)c->tev.size() < 2 * (slot + 1)) { hipEvent_t e = 0; (void)hipEventCreate(&e); c->tev.push_back(e); }
 		if ((int)c->tacc.size() <= slot) c->tacc.resize(slot + 1);

@@ -62,6 +62,25 @@ void mm355_timers_resolve(mm355_ctx *c)
 	c->n_tpend = 0;
 }
 
+// per-kernel timer (mm355_dev.h): the pair shares the lazy event slots of EvTimer
+void mm355_kt(void *kt, int slot, int end, hipStream_t st)
+{
+	mm355_ctx *c = (mm355_ctx*)kt;
+	if (c == 0 || slot < 0 || slot >= KT_N) return;
+	if (!end) {
+		if (c->n_tpend >= 120) mm355_timers_resolve(c);
+		const int k = c->n_tpend++;
+		while ((int)c->tev.size() < 2 * (k + 1)) { hipEvent_t e = 0; (void)hipEventCreate(&e); c->tev.push_back(e); }
+		if ((int)c->tacc.size() <= k) c->tacc.resize(k + 1);
+		c->tacc[k] = &c->stats.ms_kernel[slot];
+		c->kt_open[slot] = k + 1;
+		(void)hipEventRecord(c->tev[2 * k], st);
+	} else if (c->kt_open[slot] > 0) {
+		(void)hipEventRecord(c->tev[2 * (c->kt_open[slot] - 1) + 1], st);
+		c->kt_open[slot] = 0;
+	}
+}
+
 extern "C" int mm355_device_synchronize(int device_id)
 {
 	HIPCHK(hipSetDevice(device_id));
@@ -391,7 +410,7 @@ int mm355_run_sketch(mm355_ctx *c)
 {
 	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c);
 	{ EvTimer t(c, &c->stats.ms_sketch); mm355_launch_sketch(c->dix, b, s, c->ck_read.as<int32_t>(), c->ck_start.as<int32_t>(), (int)c->n_chunks,
-	                                                         c->ck_r0.as<int64_t>(), c->ck_n.as<int32_t>(), c->st); }
+	                                                         c->ck_r0.as<int64_t>(), c->ck_n.as<int32_t>(), c->st, c); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -401,11 +420,11 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c);
 	HostBatch &hb = c->hb;
-	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_mzflt(pr, b, s, c->st); }
+	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_mzflt(pr, b, s, c->st, c); }
 	{ EvTimer t(c, &c->stats.ms_seed_lookup); mm355_launch_seed_lookup(c->dix, b, s, c->ck_read.as<int32_t>(), c->ck_start.as<int32_t>(), (int)c->n_chunks,
-	                                                                   c->counters.as<unsigned long long>() + CTR_HITS_OFF, (unsigned int*)(c->counters.as<unsigned long long>() + 2), c->st); }
+	                                                                   c->counters.as<unsigned long long>() + CTR_HITS_OFF, (unsigned int*)(c->counters.as<unsigned long long>() + 2), c->st, c); }
 	++c->stats.n_launch_seed;
-	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_seed_select(c->dix, pr, b, s, c->st); }
+	{ EvTimer t(c, &c->stats.ms_seed); mm355_launch_seed_select(c->dix, pr, b, s, c->st, c); }
 	HIPCHK(hipGetLastError());
 	int64_t n = hb.n_reads;
 	hb.n_mz.resize(n); hb.n_a.resize(n); hb.rep_len.resize(n); hb.n_mini.resize(n); hb.aoff.resize(n + 1);
@@ -437,7 +456,7 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 int mm355_run_expand(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevSeeds s = dev_seeds(c); DevAnchors a = dev_anchors(c);
-	{ EvTimer t(c, &c->stats.ms_seed_expand); mm355_launch_seed_expand(c->dix, pr, b, s, a, c->st); }
+	{ EvTimer t(c, &c->stats.ms_seed_expand); mm355_launch_seed_expand(c->dix, pr, b, s, a, c->st, c); }
 	HIPCHK(hipGetLastError());
 	return 0;
 }
@@ -520,7 +539,7 @@ int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 				// big tasks first in their list: the longest level walks start at t = 0
 				std::stable_sort(ht, ht + nb, [](const SortTask &x, const SortTask &y) { return x.end > y.end; });
 				const double ts1 = mm355_now_ms();
-				if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, (size_t)c->hb.tot_a, c->sort_tasks.p, task_cap, c->st)) return MM355_EHIP;
+				if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, (size_t)c->hb.tot_a, c->sort_tasks.p, task_cap, c->st, c)) return MM355_EHIP;
 				mm355_trace_add(c, "s:levels", ts1, mm355_now_ms());
 			}
 		}
@@ -546,13 +565,15 @@ int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
 		if (n_chunks) HIPCHK(hipMemcpyAsync(c->d_chunks.p, hc, n_chunks * 8, hipMemcpyHostToDevice, c->st));
 	}
 	// segment lists live in scratch that is free at this point: z (8 B/anchor) and wk (16 B/anchor) hold >= tot_a/2 16-byte entries each
-	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->d_chunks.p, (int)n_chunks, c->st)) return MM355_EHIP; }
+	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->d_chunks.p, (int)n_chunks, c->st, c)) return MM355_EHIP; }
 	HIPCHK(hipGetLastError());
 	unsigned long long pairs[CTR_PAIRS_WORDS];   // spread over 64 words (slot = block & 63): one word takes ~88 atomics per microsecond
 	HIPCHK(hipMemcpyAsync(pairs, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, CTR_PAIRS_WORDS * 8, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
 	c->stats.chain_pairs = 0;
 	for (int k = 0; k < CTR_PAIRS_WORDS; ++k) c->stats.chain_pairs += (int64_t)pairs[k];
+	c->stats.chain_pairs_big = 0;
+	for (int k = 32; k < CTR_PAIRS_WORDS; ++k) c->stats.chain_pairs_big += (int64_t)pairs[k];   // (k_chain_big's share)
 	return 0;
 }
 
@@ -573,7 +594,7 @@ int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
 	HostBatch &hb = c->hb;
-	{ EvTimer t(c, &c->stats.ms_backtrack); mm355_launch_backtrack(pr, b, a, c->err.as<int>(), c->heavy.as<int32_t>(), c->st); }
+	{ EvTimer t(c, &c->stats.ms_backtrack); mm355_launch_backtrack(pr, b, a, c->err.as<int>(), c->heavy.as<int32_t>(), c->st, c); }
 	HIPCHK(hipGetLastError());
 	int64_t n = hb.n_reads;
 	hb.n_u.resize(n); hb.n_v.resize(n);
@@ -598,13 +619,14 @@ static int rmq_pass(mm355_ctx *c, const RmqParams &rp, const DevParams &pr, int 
 	if (nl == 0) return 0;
 	// the reads with the most anchors first: the longest dependence chain starts at t = 0
 	std::stable_sort(hl, hl + nl, [&](int32_t x, int32_t y) { return (rp.primary? hb.n_a[x] > hb.n_a[y] : hb.n_v[x] > hb.n_v[y]); });
+	if (!rp.primary) for (int k = 0; k < nl; ++k) c->stats.n_v_rmq += hb.n_v[hl[k]];   // (before the pass rewrites n_v)
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
 	HIPCHK(hipMemcpyAsync(c->rmq_list.p, hl, (size_t)nl * 4, hipMemcpyHostToDevice, c->st));
 	HIPCHK(hipMemsetAsync(c->rmq_flag.p, rp.primary? MM355_RMQ_DONE : MM355_RMQ_KEEP, (size_t)n, c->st));
 	unsigned long long *ctr = c->counters.as<unsigned long long>() + CTR_RMQ_OFF;
 	HIPCHK(hipMemsetAsync(ctr, 0, CTR_RMQ_WORDS * 8, c->st));
 	{ EvTimer t(c, &c->stats.ms_rmq);
-	  if (mm355_launch_rmq(rp, pr, b, a, c->rmq_list.as<int32_t>(), nl, c->rmq_flag.as<uint8_t>(), c->err.as<int>(), ctr, c->st)) return MM355_EHIP; }
+	  if (mm355_launch_rmq(rp, pr, b, a, c->rmq_list.as<int32_t>(), nl, c->rmq_flag.as<uint8_t>(), c->err.as<int>(), ctr, c->st, c)) return MM355_EHIP; }
 	unsigned long long hc[CTR_RMQ_WORDS];
 	HIPCHK(hipMemcpyAsync(hf, c->rmq_flag.p, (size_t)n, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(hipMemcpyAsync(hb.n_u.data(), c->n_u.p, n * 4, hipMemcpyDeviceToHost, c->st));
@@ -612,6 +634,7 @@ static int rmq_pass(mm355_ctx *c, const RmqParams &rp, const DevParams &pr, int 
 	HIPCHK(hipMemcpyAsync(hc, ctr, CTR_RMQ_WORDS * 8, hipMemcpyDeviceToHost, c->st));
 	int rc = check_err(c);   // (synchronises the stream)
 	if (rc) return rc;
+	for (int k = 0; k < nl; ++k) c->stats.n_v_rmq += rp.primary? hb.n_a[hl[k]] : 0;
 	for (int64_t i = 0; i < n; ++i) {
 		state[i] = hf[i];
 		if (hf[i] == MM355_RMQ_DONE) ++c->stats.n_rmq_reads; else if (hf[i] == MM355_RMQ_HOST) ++c->stats.n_rmq_host;

@@ -413,11 +413,11 @@ __global__ __launch_bounds__(WAVE) void k_rmq_backtrack(RmqParams rp, DevParams 
 }
 
 int mm355_launch_rmq(const RmqParams &rp, const DevParams &pr, const DevBatch &bt, DevAnchors &an, const int32_t *d_list, int n_list, uint8_t *d_flag,
-                     int *err, unsigned long long *ctr, hipStream_t st)
+                     int *err, unsigned long long *ctr, hipStream_t st, void *kt)
 {
 	if (n_list <= 0) return 0;
-	if (!rp.primary) hipLaunchKernelGGL(k_rmq_sort, dim3(n_list), dim3(WAVE), 0, st, rp, bt, an, d_list, d_flag, err);
-	hipLaunchKernelGGL(k_rmq_dp, dim3(n_list), dim3(WAVE), 0, st, rp, bt, an, d_list, d_flag, ctr);
-	hipLaunchKernelGGL(k_rmq_backtrack, dim3(n_list), dim3(WAVE), 0, st, rp, pr, bt, an, d_list, (const uint8_t*)d_flag, err);
+	if (!rp.primary) { KtScope ks(kt, KT_RMQ_SORT, st); hipLaunchKernelGGL(k_rmq_sort, dim3(n_list), dim3(WAVE), 0, st, rp, bt, an, d_list, d_flag, err); }
+	{ KtScope ks(kt, KT_RMQ_DP, st); hipLaunchKernelGGL(k_rmq_dp, dim3(n_list), dim3(WAVE), 0, st, rp, bt, an, d_list, d_flag, ctr); }
+	{ KtScope ks(kt, KT_RMQ_BT, st); hipLaunchKernelGGL(k_rmq_backtrack, dim3(n_list), dim3(WAVE), 0, st, rp, pr, bt, an, d_list, (const uint8_t*)d_flag, err); }
 	return hipGetLastError() == hipSuccess? 0 : -1;
 }

@@ -22,7 +22,7 @@ else
   run regw1 "MM355_DP_REGW8=0" ""
   run shared "MM355_DP_SHARED_STREAMS=1" ""
   run rmqhost "MM355_RMQ_ON_HOST=1" ""
-  run nobin "A=1" "--no-bin"
+  run bin "A=1" "--bin"
   run s8d2 "MM355_BUF_SLACK_DIV=8" "--reads 98304 --streams 8 --depth 2"
   run base2 "A=1" ""
 fi
