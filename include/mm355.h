@@ -150,7 +150,8 @@ typedef struct {
 	int64_t n_launch_dp;                         /* extension launch groups (one per round and HBM-budget chunk) */
 	/* per extension kernel of a launch group, timed with HIP events on the stream it is launched on; group = 2 * size class + exact,
 	 * size classes: targets <= 128, 256, 512, 1024 (k_ksw_reg<1|2|4|8, exact>), <= 4096, <= 12288, larger (k_ksw_extd2<512>; one launch
-	 * for groups 8-9, timed as 8, and one for 10-13, timed as 10); 14 / 15 / 16 = k_ksw_row<2|4|8> (full-band approximate gap fills) */
+	 * for groups 8-9, timed as 8, and one for 10-13, timed as 10); 14 / 15 / 16 = k_ksw_row<2|4|8> (full-band approximate gap fills), 17 k_ksw_rowl,
+	 * 18 k_ksw_regw8, 19 / 20 / 21 = k_ksw_band<1|2|4> (the same fills on a band of 128 / 256 / 512 diagonals), 22 = second run of band problems */
 	double ms_dp_group[24];
 	int64_t dp_cells_group[24], n_launch_group[24];
 	int64_t n_ext_rounds;                        /* extension rounds of the last call (the reference has no bound on them) */
@@ -172,6 +173,7 @@ typedef struct {
 	int64_t chain_pairs_big;                     /* k_chain_big's share of chain_pairs */
 	int64_t n_a_literal;                         /* anchors (all of them, culled ones included) of the reads that were sorted literally */
 	int64_t n_v_rmq;                             /* anchors mg_lchain_rmq chained on the device */
+	int64_t n_dp_band, n_dp_band_redo;           /* gap fills run on a diagonal band with a sufficiency proof / of those, run again on the full matrix */
 } mm355_stats_t;
 
 /* sketch: minimizers of each read (mm_sketch). mz_off[n_reads+1] host array is filled; mz = (x,y) pairs */

@@ -14,8 +14,10 @@ struct DpJobDev {
 	int32_t qlen, tlen;
 	int64_t qoff, toff;      // into the device code buffers
 	int32_t w, zdrop, end_bonus, flag;
-	int32_t skip, pad;
+	int32_t skip, pad;       // pad: layout of the direction matrix -- 0 the reference's anti-diagonal rows, 1 the row sweep's tiles, 2 the band's tiles (mm355_dpband.h), +4: the matrix lives in the redo buffer
 	int64_t p_off, off_off, cig_off, st_off;
+	int32_t dlo, lmin;       // band kernels: first diagonal of the band, least end score that proves the band sufficient
+	int32_t bw, rsv;         // ... and the band's width in diagonals (128, 256, 512)
 };
 
 struct DpGather {           // where the code strings of a job come from

@@ -318,11 +318,12 @@ __global__ __launch_bounds__(NT) void k_ksw_extd2(DpConst dc, const DpJobDev *jo
 #include "mm355_dpreg.h"
 #include "mm355_dpmw.h"
 #include "mm355_dprow.h"
+#include "mm355_dpband.h"
 
 // U:ksw2.h::ksw_backtrack (is_rot = 1).  The walk is a chain of dependent 1-byte loads (one per CIGAR column), i.e. pure
 // latency: with one lane per alignment a wave keeps 64 independent chains in flight instead of one.  off[]/off_end[] of
 // the reference are pure functions of (r, qlen, tlen, w) and are recomputed instead of being stored and re-loaded.
-__global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, const int32_t *job_ids, int n_jobs, const uint8_t *pbase, uint32_t *cigbase,
+__global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, const int32_t *job_ids, int n_jobs, const uint8_t *pbase, const uint8_t *pbase2, uint32_t *cigbase,
                                                         mm355_dpres_t *res, uint32_t *dense, unsigned long long *dense_ctr)
 {
 	const int t = blockIdx.x * WAVE + threadIdx.x;
@@ -340,8 +341,9 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 		int n_col_ = qlen < tlen? qlen : tlen;
 		n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
 		const int n_col = n_col_ * 16;
-		const uint8_t *p = pbase + jb.p_off;
-		const int row_stride = (tlen + 15) / 16 * 16 + 16;
+		const uint8_t *p = (jb.pad & 4? pbase2 : pbase) + jb.p_off;
+		const int lay = jb.pad & 3, dlo = jb.dlo;
+		const int row_stride = lay == 2? jb.bw : (tlen + 15) / 16 * 16 + 16;
 		int i = i0, j = j0, state = 0;
 		// the open CIGAR run lives in registers and is stored once, when the operation changes (it used to be a read-modify-write of the
 		// scratch entry on every column: one more memory round trip per step, and most of the kernel's write traffic)
@@ -358,7 +360,8 @@ __global__ __launch_bounds__(WAVE) void k_ksw_backtrack(const DpJobDev *jobs, co
 			uint32_t tmp;
 			if (i < st) force_state = 2;
 			if (i > en) force_state = 1;
-			tmp = force_state < 0? (jb.pad? p[row_cell_off(j, i, row_stride)] : p[(size_t)rr * n_col + i - st]) : 0;   // pad = 1: the row sweep's tiled matrix (mm355_dprow.h)
+			// lay = 1: the row sweep's tiled matrix (mm355_dprow.h); 2: the band's (mm355_dpband.h; the walk cannot leave the band: the kernel's proof)
+			tmp = force_state < 0? (lay == 1? p[row_cell_off(j, i, row_stride)] : lay == 2? p[row_cell_off(j, min(max(i - j - dlo, 0), row_stride - 1), row_stride)] : p[(size_t)rr * n_col + i - st]) : 0;
 			if (state == 0) state = tmp & 7;
 			else if (!(tmp >> (state + 2) & 1)) state = 0;
 			if (state == 0) state = tmp & 7;
@@ -451,11 +454,15 @@ struct DpClass { int cap, kind, np; };   // kind 0: k_ksw_reg, 1: k_ksw_extd2<64
 static const DpClass DP_CLASSES[] = { {128, 0, 1}, {256, 0, 2}, {512, 0, 4}, {1024, 0, 8}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 static const DpClass DP_CLASSES_LEGACY[] = { {256, 1, 0}, {512, 1, 0}, {1024, 1, 0}, {1024, 1, 0}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 #define DP_N_CLASS 7
-#define DP_N_GROUP 19                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills), 17 = k_ksw_rowl (the same, targets 1025..8192)
+#define DP_N_GROUP 22                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills), 17 = k_ksw_rowl (the same, targets 1025..8192)
 #define DP_G_ROW2 14
 #define DP_G_ROW4 15
 #define DP_G_ROW8 16
 #define DP_G_ROWL 17
+#define DP_G_BAND1 19                   // k_ksw_band<1 | 2 | 4>: the row sweep on a band of 128 / 256 / 512 diagonals with a sufficiency proof (mm355_dpband.h)
+#define DP_G_BAND2 20
+#define DP_G_BAND4 21
+#define DP_G_REDO 22                    // (not a class: the second, full-matrix run of band problems whose proof failed -- timer / counter slot)
 #define DP_G_REGW 18                    // k_ksw_regw: exact, narrow band (w <= DP_WIN_MAX_W), targets > 1024 -- the register kernel with a moving window
 
 // value range of the row sweep on a qlen x tlen problem (int16 halves; ROW_NEG must stay below every real value, differences of two real
@@ -484,6 +491,49 @@ static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc
 	else hipLaunchKernelGGL((k_ksw_reg<NP, false>), dim3(n), dim3(64), pad, st, dc, jobs, ids, (int)n, d_q, d_t, bt, res, cells);
 }
 
+
+__global__ void k_dp_patch(DpJobDev *jobs, const int32_t *ids, const DpJobDev *nj, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) jobs[ids[i]] = nj[i]; }
+
+// ---- band kernels (mm355_dpband.h): which problems take them, with which band
+struct BandPlan { int nsb, dlo, lmin; };   // nsb = 0: the full-matrix kernels
+static int band_ubound(const DpConst &dc, int qlen, int tlen, int d)   // no path through diagonal d (outside [min(0, D0), max(0, D0)]) scores more
+{
+	const int D0 = tlen - qlen, g1 = d < 0? -d : d, g2 = D0 - d < 0? d - D0 : D0 - d;
+	auto cost = [&](int g) { if (g <= 0) return 0; const int c1 = dc.q + g * dc.e, c2 = dc.q2 + g * dc.e2; return c1 < c2? c1 : c2; };
+	int a = dc.sc_mch; if (dc.sc_mis > a) a = dc.sc_mis; if (dc.sc_N > a) a = dc.sc_N; if (a < 0) a = 0;
+	int m = (qlen + tlen - g1 - g2) / 2; if (m < 0) m = 0;
+	return a * m - cost(g1) - cost(g2);
+}
+static BandPlan band_plan(const DpConst &dc, int qlen, int tlen, int full_sets)
+{
+	BandPlan bp; bp.nsb = 0; bp.dlo = 0; bp.lmin = 0;
+	static const bool use_band = [] { const char *e = getenv("MM355_DP_BAND"); return !(e && atoi(e) == 0); }();        // MM355_DP_BAND=0: full-matrix kernels only
+	static const double thr = [] { const char *e = getenv("MM355_DP_BAND_THR"); return e? atof(e) : 0.65; }();          // a band is tried when a score of thr x (all matches) would prove it
+	static const int force = [] { const char *e = getenv("MM355_DP_BAND_FORCE"); return e? atoi(e) : 0; }();            // test hook: this many register sets whenever the geometry allows
+	if (!use_band) return bp;
+	const int D0 = tlen - qlen, lo = D0 < 0? D0 : 0, hi = D0 > 0? D0 : 0, span = hi - lo + 1;
+	const int emax = dc.e > dc.e2? dc.e : dc.e2;
+	auto cost = [&](int g) { const int c1 = dc.q + g * dc.e, c2 = dc.q2 + g * dc.e2; return c1 < c2? c1 : c2; };
+	int a = dc.sc_mch > 0? dc.sc_mch : 0;
+	const int n = qlen < tlen? qlen : tlen;
+	for (int nsb = 1; nsb <= 4; nsb *= 2) {
+		const int W = 128 * nsb;
+		if (force && nsb != force) continue;
+		if (nsb >= full_sets && !force) break;                          // no narrower than the full matrix
+		if (W < span + 2 * BAND_MIN_MARGIN) continue;
+		// int16 range: real values stay above -(cost(qlen + 1) + cost(tlen + 1)) - ..., the cells left of the border column start at ROW_NEG and
+		// drift by at most a per row for W rows; prefix terms G + d e with |d| <= W + span
+		if (cost(qlen + 1) + cost(tlen + 1) + 256 > 7000 || a * (W + 8) > 4000 || (W + span + 8) * emax > 4000 || a * n + (W + span + 8) * emax > 30000) continue;
+		const int dlo = lo - (W - span) / 2;
+		int u1 = band_ubound(dc, qlen, tlen, dlo - 1), u2 = band_ubound(dc, qlen, tlen, dlo + W);
+		const int lmin = (u1 > u2? u1 : u2) + 1;
+		if (!force && (double)lmin > thr * (double)(a * n)) continue;   // not worth a try: only a nearly perfect alignment would prove this band
+		bp.nsb = nsb; bp.dlo = dlo; bp.lmin = lmin;
+		return bp;
+	}
+	return bp;
+}
+
 // runs n jobs whose code strings are already on the device (d_q/d_t).  `jobs` is host memory that stays valid until the call
 // returns (pinned when it comes from the mapping path).  Results: res_out -> c->h_res (pinned, valid until the next call),
 // bytes of direction matrix mm355_dp_run lays out for one extension problem (the caller cuts a round so that a launch fits its HBM budget):
@@ -503,7 +553,11 @@ size_t mm355_dp_matrix_bytes(const mm355_mapopt_t *mo, const DpConst &dc, int ql
 	const bool row_kind = dc.valid && use_row && regular && (flag & EZ_APPROX_MAX) && !(flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= qlen + tlen;
 	const bool row = row_kind && tlen <= ROW_MAX_T && qlen + tlen <= ROW_MAX_QT && rowl_range_ok(dc, qlen, tlen <= 256? 256 : tlen <= 512? 512 : 1024);
 	const bool rowl = row_kind && use_rowl && tlen > ROW_MAX_T && tlen <= ROWL_MAX_T && qlen <= ROWL_MAX_Q && rowl_range_ok(dc, qlen, tlen);
-	if (row || rowl) return row_matrix_bytes(qlen, T) + 64;   // (+ the alignment of its first tile)
+	if (row || rowl) {
+		const BandPlan bp = band_plan(dc, qlen, tlen, rowl? 64 : tlen <= 256? 2 : tlen <= 512? 4 : 8);
+		if (bp.nsb) return band_matrix_bytes(qlen, 128 * bp.nsb) + 64;
+		return row_matrix_bytes(qlen, T) + 64;   // (+ the alignment of its first tile)
+	}
 	return ((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16;
 }
 
@@ -536,7 +590,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		int T = (j.tlen + 15) / 16 * 16;
 		j.p_off = (int64_t)p_tot; j.off_off = (int64_t)off_tot; j.cig_off = (int64_t)cig_tot; j.st_off = 0;
 		int g = 0;
-		j.pad = 0;
+		j.pad = 0; j.dlo = 0; j.lmin = 0; j.bw = 0; j.rsv = 0;
 		if (j.qlen > 0 && j.tlen > 0 && !j.skip) {
 			cig_tot += (size_t)j.qlen + j.tlen + 2;
 			// gap fills whose band never binds, without z-drop on the approximate score: the row sweep (mm355_dprow.h)
@@ -551,11 +605,18 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			const bool row = row_kind && j.tlen <= ROW_MAX_T && j.qlen + j.tlen <= ROW_MAX_QT && rowl_range_ok(dc, j.qlen, j.tlen <= 256? 256 : j.tlen <= 512? 512 : 1024);
 			const bool rowl = row_kind && use_rowl && j.tlen > ROW_MAX_T && j.tlen <= ROWL_MAX_T && j.qlen <= ROWL_MAX_Q && rowl_range_ok(dc, j.qlen, j.tlen);
 			if (row || rowl) {
-				j.pad = 1;
+				const BandPlan bp = band_plan(dc, j.qlen, j.tlen, rowl? 64 : j.tlen <= 256? 2 : j.tlen <= 512? 4 : 8);
 				p_tot = (p_tot + 63) & ~(size_t)63;            // tiles are 64-byte lines
 				j.p_off = (int64_t)p_tot;
-				p_tot += row_matrix_bytes(j.qlen, T);
-				g = rowl? DP_G_ROWL : j.tlen <= 256? DP_G_ROW2 : j.tlen <= 512? DP_G_ROW4 : DP_G_ROW8;
+				if (bp.nsb) {                                  // a band of 128 * nsb diagonals with a sufficiency proof (mm355_dpband.h)
+					j.pad = 2; j.dlo = bp.dlo; j.lmin = bp.lmin; j.bw = 128 * bp.nsb;
+					p_tot += band_matrix_bytes(j.qlen, 128 * bp.nsb);
+					g = bp.nsb == 1? DP_G_BAND1 : bp.nsb == 2? DP_G_BAND2 : DP_G_BAND4;
+				} else {
+					j.pad = 1;
+					p_tot += row_matrix_bytes(j.qlen, T);
+					g = rowl? DP_G_ROWL : j.tlen <= 256? DP_G_ROW2 : j.tlen <= 512? DP_G_ROW4 : DP_G_ROW8;
+				}
 			} else {
 				p_tot += ((size_t)(j.qlen + j.tlen - 1) * n_col_ + 1) * 16;
 				int cls = 0;
@@ -621,10 +682,16 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	int32_t *d_H = (int32_t*)(d_S + st_tot + 8);
 	unsigned long long *d_cells = c->counters.as<unsigned long long>() + 4, *d_dense = c->counters.as<unsigned long long>() + 5;
 	double t_turn0 = 0;
+	bool redo_timed = false;
 	HIPCHK(hipMemsetAsync(d_dense, 0, 8, c->st));
 	unsigned long long *d_gcells = c->counters.as<unsigned long long>() + CTR_GCELLS_OFF;   // cells per group [CTR_GROUPS][DP_CTR_SPREAD]
 	HIPCHK(hipMemsetAsync(d_cells, 0, 8, c->st));
 	HIPCHK(hipMemsetAsync(d_gcells, 0, CTR_GCELLS_WORDS * 8, c->st));
+	// band kernels: [0] = problems whose proof failed, then their ids; behind it the launch lists of their second run
+	const size_t n_band = n_grp[DP_G_BAND1] + n_grp[DP_G_BAND2] + n_grp[DP_G_BAND4];
+	if (c->dp_fail.ensure((2 * n_band + 64) * 4 + (n_band + 8) * sizeof(DpJobDev)) || c->h_fail.ensure((2 * n_band + 64) * 4 + (n_band + 8) * sizeof(DpJobDev))) return MM355_ENOMEM;
+	int32_t *d_fail = c->dp_fail.as<int32_t>();
+	if (n_band) HIPCHK(hipMemsetAsync(d_fail, 0, 4, c->st));
 	// every group gets its own HIP stream: the few long alignments of the big classes run concurrently with the thousands of
 	// short ones instead of holding the GPU alone (same-stream launches would serialise the classes)
 	HIPCHK(hipMemcpyAsync(d_ids, h_ids, (2 * n + 8) * 4, hipMemcpyHostToDevice, c->st));   // launch lists + backtrack order (pinned source)
@@ -712,9 +779,12 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			if (n_grp[g] == 0 || g == DP_G_ROWL || g == DP_G_REGW) continue;
 			if (g >= DP_G_ROW2) {   // the row sweep of the full-band approximate fills: the wide throughput grids of a round
 				hipStream_t gst; int rc2;
-				if ((rc2 = group_stream(g == DP_G_ROW2? 0 : g == DP_G_ROW4? 3 : 2, &gst))) return rc2;
+				if ((rc2 = group_stream(g == DP_G_ROW2 || g == DP_G_BAND1? 0 : g == DP_G_ROW4 || g == DP_G_BAND2? 3 : 2, &gst))) return rc2;
 				if ((rc2 = group_begin(g, gst))) return rc2;
-				if (g == DP_G_ROW2) hipLaunchKernelGGL(k_ksw_row<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g);
+				if (g == DP_G_BAND1) hipLaunchKernelGGL(k_ksw_band<1>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
+				else if (g == DP_G_BAND2) hipLaunchKernelGGL(k_ksw_band<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
+				else if (g == DP_G_BAND4) hipLaunchKernelGGL(k_ksw_band<4>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
+				else if (g == DP_G_ROW2) hipLaunchKernelGGL(k_ksw_row<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g);
 				else if (g == DP_G_ROW4) hipLaunchKernelGGL(k_ksw_row<4>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g);
 				else hipLaunchKernelGGL(k_ksw_row<8>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g);
 				if ((rc2 = group_end(g, gst, true))) return rc2;
@@ -743,6 +813,54 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 				                   c->dp_cig.as<uint32_t>(), d_S, d_H, dres, k.cap, gc, c->dp_dense.as<uint32_t>(), d_dense, -1);
 			if ((rc2 = group_end(g, gst, k.kind == 0 && !(g & 1)))) return rc2;   // in the turn: the approximate register classes; the exact ones are small latency-bound grids
 		}
+		// band kernels whose proof failed (a divergent stretch, a long indel: the optimal path may leave the band): the same problems again, on
+		// the full-matrix row sweep, inside the same turn; their direction matrices go to a buffer of their own
+		bool rowl_redo = false;
+		if (n_band) {
+			int32_t *h_fail = (int32_t*)c->h_fail.p;
+			HIPCHK(hipMemcpyAsync(h_fail, d_fail, (1 + n_band) * 4, hipMemcpyDeviceToHost, c->st));   // (c->st has joined every band group: group_end)
+			HIPCHK(mm355_wait_stream(c->st));
+			const size_t n_fail = (size_t)h_fail[0];
+			c->stats.n_dp_band += (int64_t)n_band; c->stats.n_dp_band_redo += (int64_t)n_fail;
+			if (n_fail) {
+				std::sort(h_fail + 1, h_fail + 1 + n_fail);                  // (the device appended them in no particular order)
+				int32_t *h_rid = h_fail + 1 + n_band;                        // launch lists of the second run: row<8>, row<4>, row<2>, rowl
+				DpJobDev *h_rj = (DpJobDev*)((char*)c->h_fail.p + (2 * n_band + 64) * 4);
+				size_t p2 = 0, cnt[4] = {0, 0, 0, 0}, pos[4];
+				auto cls_of = [&](const DpJobDev &j) { return j.tlen > ROW_MAX_T? 3 : j.tlen <= 256? 2 : j.tlen <= 512? 1 : 0; };
+				for (size_t k = 0; k < n_fail; ++k) ++cnt[cls_of(jobs[h_fail[1 + k]])];
+				pos[0] = 0; pos[1] = cnt[0]; pos[2] = pos[1] + cnt[1]; pos[3] = pos[2] + cnt[2];
+				for (size_t k = 0; k < n_fail; ++k) {
+					DpJobDev &j = jobs[h_fail[1 + k]];
+					j.pad = 1 | 4; j.p_off = (int64_t)p2; j.bw = 0;
+					p2 += (row_matrix_bytes(j.qlen, (j.tlen + 15) / 16 * 16) + 63) & ~(size_t)63;
+					h_rj[k] = j;
+					h_rid[pos[cls_of(j)]++] = h_fail[1 + k];
+				}
+				if (c->dp_bt2.ensure(p2 + 64, 4)) return MM355_ENOMEM;
+				int32_t *d_rid = d_fail + 1 + n_band; DpJobDev *d_rj = (DpJobDev*)((char*)c->dp_fail.p + (2 * n_band + 64) * 4);
+				HIPCHK(hipMemcpyAsync(d_fail + 1, h_fail + 1, n_fail * 4, hipMemcpyHostToDevice, c->st));
+				HIPCHK(hipMemcpyAsync(d_rid, h_rid, n_fail * 4, hipMemcpyHostToDevice, c->st));
+				HIPCHK(hipMemcpyAsync(d_rj, h_rj, n_fail * sizeof(DpJobDev), hipMemcpyHostToDevice, c->st));
+				hipLaunchKernelGGL(k_dp_patch, dim3((unsigned)((n_fail + 255) / 256)), dim3(256), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_fail + 1, d_rj, (int)n_fail);
+				const int g = DP_G_REDO;
+				if (c->dp_ev0[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev0[g]));
+				if (c->dp_ev1[g] == 0) HIPCHK(hipEventCreate(&c->dp_ev1[g]));
+				HIPCHK(hipEventRecord(c->dp_ev0[g], c->st));
+				unsigned long long *gc = d_gcells + DP_CTR_SPREAD * g;
+				size_t o0 = 0;
+				if (cnt[0]) hipLaunchKernelGGL(k_ksw_row<8>, dim3((unsigned)cnt[0]), dim3(64), 0, c->st, dc, dj, d_rid + o0, (int)cnt[0], d_q, d_t, c->dp_bt2.as<uint8_t>(), dres, gc);
+				o0 += cnt[0];
+				if (cnt[1]) hipLaunchKernelGGL(k_ksw_row<4>, dim3((unsigned)cnt[1]), dim3(64), 0, c->st, dc, dj, d_rid + o0, (int)cnt[1], d_q, d_t, c->dp_bt2.as<uint8_t>(), dres, gc);
+				o0 += cnt[1];
+				if (cnt[2]) hipLaunchKernelGGL(k_ksw_row<2>, dim3((unsigned)cnt[2]), dim3(64), 0, c->st, dc, dj, d_rid + o0, (int)cnt[2], d_q, d_t, c->dp_bt2.as<uint8_t>(), dres, gc);
+				o0 += cnt[2];
+				if (cnt[3]) { hipLaunchKernelGGL(k_ksw_rowl, dim3((unsigned)cnt[3]), dim3(64 * ROWL_WAVES), 0, c->st, dc, dj, d_rid + o0, (int)cnt[3], d_q, d_t, c->dp_bt2.as<uint8_t>(), dres, gc); rowl_redo = true; }
+				HIPCHK(hipEventRecord(c->dp_ev1[g], c->st));
+				redo_timed = true;
+			}
+		}
+		(void)rowl_redo;
 		// the turn ends when the extension kernels are done: the backtrack below is a latency-bound pointer walk and, like the result
 		// copies, overlaps the next context's round
 		// (only the wide register-kernel grids count: the few long alignments of the eight-wave classes are latency chains that
@@ -756,7 +874,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// backtrack: all jobs, longest first so that the lanes of a wave walk paths of similar length
 		KtScope ks_bt(c, KT_DP_BACKTRACK, c->st);
 		hipLaunchKernelGGL(k_ksw_backtrack, dim3((unsigned)((n + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->st, c->dp_jobs.as<DpJobDev>(), d_ids + n + 8, (int)n,
-		                   c->dp_bt.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
+		                   c->dp_bt.as<uint8_t>(), c->dp_bt2.as<uint8_t>(), c->dp_cig.as<uint32_t>(), c->dp_res.as<mm355_dpres_t>(), c->dp_dense.as<uint32_t>(), d_dense);
 	}
 	HIPCHK(hipGetLastError());
 	if (c->h_res.ensure(n * sizeof(mm355_dpres_t) + 64 + CTR_GCELLS_WORDS * 8)) return MM355_ENOMEM;
@@ -786,6 +904,13 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			for (int k = 0; k < DP_CTR_SPREAD; ++k) gc += (int64_t)ctr[2 + DP_CTR_SPREAD * g + k];
 			c->stats.dp_cells_group[g] += gc; ++c->stats.n_launch_group[g];
 			tot += gc;
+		}
+		if (redo_timed) {   // the second run of the band problems whose proof failed (its cells are counted again: they were computed twice)
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, c->dp_ev0[DP_G_REDO], c->dp_ev1[DP_G_REDO]) == hipSuccess) c->stats.ms_dp_group[DP_G_REDO] += ms;
+			int64_t gc = 0;
+			for (int k = 0; k < DP_CTR_SPREAD; ++k) gc += (int64_t)ctr[2 + DP_CTR_SPREAD * DP_G_REDO + k];
+			c->stats.dp_cells_group[DP_G_REDO] += gc; ++c->stats.n_launch_group[DP_G_REDO];
 		}
 		c->stats.dp_cells += tot; c->stats.n_dp_jobs += (int64_t)n; ++c->stats.n_launch_dp;
 	}

@@ -87,6 +87,7 @@ struct mm355_ctx {
 	DBuf aoff, a, f, p, v, z, t8, vi, b, wk, u, u2, n_u, n_v;
 	// dp buffers
 	DBuf dp_jobs, dp_res, dp_q, dp_t, dp_bt, dp_cig, dp_work, dp_H, dp_dense, dp_gather, pack;
+	DBuf dp_bt2, dp_fail; HBuf h_fail;      // band kernels: direction matrices of the problems that are run again on the full matrix, their list
 	HBuf h_res, h_cig, h_pu, h_pa, h_pm, h_seq;
 	HBuf h_tasks;                          // whole-array tasks of the literal anchor sort (pinned)
 	HBuf h_chunks; DBuf d_chunks;          // chunk table of k_chain_segments

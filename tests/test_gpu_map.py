@@ -412,7 +412,8 @@ def test_dp_kernel_parity(ont):
     sr = al._stage_runner()
     _ffi.check(L.mm355_stage_dp(sr.ctx, C.byref(al._mo), len(jobs), ja, qcat.ctypes.data, qcat.size, tcat.ctypes.data, tcat.size, res, cig.ctypes.data, cap))
     st = sr.stats()
-    assert st.n_launch_group[17] == 1 and st.dp_cells_group[17] >= sum(j[0] * j[1] for j in jobs[n_short:n_rowl]), "long full-band fills must run on k_ksw_rowl"
+    if not os.environ.get("MM355_DP_BAND_FORCE"):
+        assert st.n_launch_group[17] == 1 and st.dp_cells_group[17] + st.dp_cells_group[21] + st.dp_cells_group[20] >= sum(j[0] * j[1] for j in jobs[n_short:n_rowl]), "long full-band fills must run on k_ksw_rowl (or a band)"
     assert st.n_launch_group[18] == 1 and st.dp_cells_group[18] > 0, "long narrow-band exact sweeps must run on k_ksw_regw"
     mat = np.zeros(25, np.int8)
     mo = al._mo
@@ -431,8 +432,30 @@ def test_dp_kernel_parity(ont):
         if ez.n_cigar: OL.free(ez.cigar)
     assert n_zd > 0
     groups = list(sr.stats().n_launch_group)
-    assert groups[14] > 0 and groups[15] > 0 and groups[16] > 0, groups      # k_ksw_row<2>, <4> and <8> ran
+    st = sr.stats()
+    forced = os.environ.get("MM355_DP_BAND_FORCE") or os.environ.get("MM355_DP_BAND") == "0"
+    if not forced:
+        assert groups[14] > 0 and groups[15] > 0 and groups[16] > 0, groups      # k_ksw_row<2>, <4> and <8> ran ...
+        assert groups[19] > 0 and st.n_dp_band > 50, (groups, st.n_dp_band)          # ... and the band kernel with its sufficiency proof (mm355_dpband.h)
+        assert 0 < st.n_dp_band_redo < st.n_dp_band and groups[22] == 1, (st.n_dp_band_redo, st.n_dp_band, groups)   # some proofs fail (long indels): run again on the full matrix
+    elif os.environ.get("MM355_DP_BAND") == "0":
+        assert groups[19] + groups[20] + groups[21] == 0 and st.n_dp_band == 0
+    else:
+        k = {"1": 19, "2": 20, "4": 21}[os.environ["MM355_DP_BAND_FORCE"]]
+        assert groups[k] > 0 and st.n_dp_band > 300 and st.n_dp_band_redo > 20, (groups, st.n_dp_band, st.n_dp_band_redo)   # forced: every problem whose end cell fits the band tries it
     sr.close()
+
+
+@pytest.mark.parametrize("env", [{"MM355_DP_BAND_FORCE": "1"}, {"MM355_DP_BAND_FORCE": "2"}, {"MM355_DP_BAND_FORCE": "4"}, {"MM355_DP_BAND": "0"}])
+def test_dp_band_kernels_forced(built, env):
+    """the 1000 problems of test_dp_kernel_parity once more (a child process: the switches are read once) with every full-band fill pushed onto a
+    band of 128 / 256 / 512 diagonals whenever its end cell fits -- unrelated sequences, 700-base insertions and all: the proof must fail for
+    those and the second run on the full matrix must deliver the oracle's result -- and with the band kernels switched off"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_map.py", "-x", "-q", "-k", "test_dp_kernel_parity or test_dp_row_kernel_with_reordered_gap_costs"],
+                       cwd=root, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_dp_row_kernel_with_reordered_gap_costs(ont):
@@ -467,7 +490,7 @@ def test_dp_row_kernel_with_reordered_gap_costs(ont):
         sr = al._stage_runner()
         _ffi.check(L.mm355_stage_dp(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, tcat.ctypes.data, tcat.size, res, cig.ctypes.data, cap))
         groups = list(sr.stats().n_launch_group)
-        assert (groups[14] + groups[15] + groups[16] > 0) == expect_row, (groups, (q, e, q2, e2))
+        assert (groups[14] + groups[15] + groups[16] + groups[19] + groups[20] + groups[21] > 0) == expect_row, (groups, (q, e, q2, e2))
         # k_ksw_rowl takes a long problem only where its int16 range allows (mm355_dp.hip::rowl_range_ok, restated here): with
         # (4, 6, 1, 10, 1, 3, 4) -- match 4, e = 4 after ksw2's ordering -- 4096 columns do not fit, nor with the single piece (5, 2)
         def range_ok(ql, tl):
@@ -479,7 +502,10 @@ def test_dp_row_kernel_with_reordered_gap_costs(ont):
             return hi + emax * (tlr + 1) <= 32000 and lo <= 16384 - 64 and hi + lo <= 32000
         cells17 = sr.stats().dp_cells_group[17]
         want17 = sum(j[0] * j[1] for j in jobs[-3:] if range_ok(j[0], j[1])) if expect_row else 0
-        assert cells17 == want17 and (not expect_row or 0 < want17 < sum(j[0] * j[1] for j in jobs[-3:])), (cells17, want17, (q, e, q2, e2))
+        if os.environ.get("MM355_DP_BAND") == "0":        # (a band kernel takes a long problem whose proof looks within reach; without them: exactly these)
+            assert cells17 == want17 and (not expect_row or 0 < want17 < sum(j[0] * j[1] for j in jobs[-3:])), (cells17, want17, (q, e, q2, e2))
+        else:
+            assert cells17 <= want17, (cells17, want17, (q, e, q2, e2))
         mat = np.zeros(25, np.int8); OL.mmo_ksw_gen_simple_mat(5, mat.ctypes.data, a, b, amb)
         for i, (ql, tl, w, fl) in enumerate(jobs):
             ez = O.Extz()
