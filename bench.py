@@ -137,7 +137,7 @@ def pmc_traffic(workload, reads_per_sub, kernel):
 WORKLOADS = {
     # name: (genome, preset, read-set seed, read model, default reads/step/GPU, streams, depth, BASELINE config text)
     "human": dict(genome="human", preset="map-ont", seed=4, reads=dict(n50=10000, sigma=0.75, lo=500, hi=100000),
-                  n_reads=73728, streams=6, depth=2, cfg="configs[2]", what="synthetic ONT reads N50~10kb 6% error (read set seed 4)"),
+                  n_reads=73728, streams=8, depth=1, cfg="configs[2]", what="synthetic ONT reads N50~10kb 6% error (read set seed 4)"),
     "human-hifi": dict(genome="human", preset="map-hifi", seed=6, reads=dict(n50=18000, sigma=0.14, lo=5000, hi=60000, sub=0.0005, ins=0.00075, dele=0.00075),
                        n_reads=24576, streams=6, depth=2, cfg="configs[4]", what="synthetic HiFi reads ~N(18kb, 2.5kb) 0.2% error (read set seed 6)"),
     "ecoli": dict(genome="ecoli", preset="map-ont", seed=2, reads=dict(n50=8000, sigma=0.75, lo=500, hi=100000),
@@ -212,6 +212,61 @@ def aggregate(dist, dt, aligned, bases):
 
 
 SIG_FIELDS = ("target_name", "target_start", "target_end", "query_start", "query_end", "strand", "mapq", "is_primary", "NM", "match_len", "block_len", "cigar_str", "cs")
+
+
+def reference_on_box(g, names, preset, reads, gpu_recs, threads, budget_s=600.0):
+    """SURVEY 8d / BASELINE.md: if the real thing is on the GPU box -- the `minimap2` binary or the `mappy` module -- time it on the CPU sample and
+    diff its records with the HIP path's (/root/reference/tests/benchmark.py:53-90 times mappy beside mappy_rs the same way).  None when
+    neither exists (the case on every box this was run on: no network, nothing to install); the check itself is always made."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("minimap2")
+    try:
+        import mappy as _mappy          # noqa: F401  (the reference's own baseline module)
+    except Exception:
+        _mappy = None
+    if exe is None and _mappy is None:
+        return None
+    import synthdata as S
+    out = {"minimap2": exe, "mappy": getattr(_mappy, "__version__", None) if _mappy else None}
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "ref.fa")
+        S.write_fasta(fa, g, names)
+        n = len(reads)
+        try:
+            if exe is not None:
+                fq = os.path.join(td, "reads.fa")
+                with open(fq, "w") as f:
+                    for i, r in enumerate(reads):
+                        f.write(">r%d\n%s\n" % (i, r if isinstance(r, str) else S.codes_to_str(np.frombuffer(r, np.uint8))))
+                ver = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=30).stdout.strip()
+                t0 = time.time()
+                p = subprocess.run([exe, "-x", preset, "-c", "--cs", "-t", str(threads), fa, fq], capture_output=True, text=True, timeout=budget_s)
+                dt = time.time() - t0
+                got = {}
+                for line in p.stdout.splitlines():
+                    c = line.split("\t")
+                    tags = {t[:2]: t[5:] for t in c[12:]}
+                    got.setdefault(int(c[0][1:]), []).append((c[5], int(c[7]), int(c[8]), int(c[2]), int(c[3]), c[4], int(c[11]), tags.get("cg"), tags.get("cs")))
+                out.update(version=ver, seconds=round(dt, 1), note="index construction included in the time (minimap2 CLI)")
+            else:
+                al = _mappy.Aligner(fa, preset=preset, n_threads=threads)
+                t0 = time.time()
+                got = {}
+                for i, r in enumerate(reads):
+                    s_ = r if isinstance(r, str) else S.codes_to_str(np.frombuffer(r, np.uint8))
+                    got[i] = [(h.ctg, h.r_st, h.r_en, h.q_st, h.q_en, "+" if h.strand > 0 else "-", h.mapq, h.cigar_str, h.cs) for h in al.map(s_, cs=True)]
+                dt = time.time() - t0
+                out.update(version=out["mappy"], seconds=round(dt, 1), note="mappy.Aligner.map loop, one thread")
+            aligned = sum(len(reads[i]) for i in range(n) if got.get(i))
+            out["value"] = round(aligned / dt / 1e6, 4); out["unit"] = "aligned Mbases/s"
+            if gpu_recs is not None:
+                bad = sum(1 for i in range(min(n, len(gpu_recs))) if sorted(got.get(i, [])) != sorted(gpu_recs[i]))
+                out["parity"] = dict(reads=min(n, len(gpu_recs)), mismatching_reads=bad)
+        except Exception as e:      # a broken install must not take the bench line down
+            out["error"] = repr(e)[:300]
+    return out
 
 
 def cpu_baseline(g, names, preset, reads, budget_s, threads, gpu_sigs=None):
@@ -597,7 +652,7 @@ def main():
             "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(23) if nl_g[i] > 0},
             "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(23) if nl_g[i] > 0},
             "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_kept_by_cull=int(n_keep), n_a_sorted_literally=int(n_lit), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
-                                      n_dp_jobs=int(agg["n_dp_jobs"] / K), n_dp_band=int(agg["n_dp_band"] / K), n_dp_band_redo=int(agg["n_dp_band_redo"] / K), n_sort_tie_reads=int(agg["n_sort_tie_reads"] / K),
+                                      n_dp_jobs=int(agg["n_dp_jobs"] / K), n_dp_band=int(agg["n_dp_band"] / K), n_dp_band_redo=int(agg["n_dp_band_redo"] / K), n_rounds_split=int(agg["n_rounds_split"]), n_sort_tie_reads=int(agg["n_sort_tie_reads"] / K),
                                       n_rmq_reads=int(agg["n_rmq_reads"] / K), n_rmq_host_fallback=int(agg["n_rmq_host"] / K),
                                       rmq_window_elements=int(agg["rmq_scanned"] / K)),
             "host": dict(cpu_us_per_read=round(agg["host_cpu_ms"] * 1e3 / max(1, n_mapped), 2), pool_threads=pool_threads, context_threads=n_thr,
@@ -607,9 +662,14 @@ def main():
         }
     barrier()
     gpu_sigs = None
+    gpu_recs = None
     if rank == 0 and not args.no_cpu and world == 1:   # (outside the timed region) the records of the reads the CPU sample will cover
         import mappy_rs
         gpu_sigs = []
+        import shutil as _sh
+        import importlib.util as _iu
+        ref_wanted = _sh.which("minimap2") is not None or _iu.find_spec("mappy") is not None
+        gpu_recs = []
         n_chk = len(cpu_sample) if args.cpu_seconds >= 60 else min(len(cpu_sample), 4 * 6144)   # a long CPU leg compares the whole block
         _ffi.check(L.mm355_batch_select(ctxs[0], 63))   # a slot of its own: the resident blocks stay as they are
         for lo in range(0, n_chk, 6144):
@@ -619,6 +679,9 @@ def main():
             _ffi.check(L.mm355_map_batch(ctxs[0], C.byref(mo), len(sub), rarr, rl_, _ffi.OUT_CS, C.byref(hp)))
             for ms in mappy_rs._batch_to_mappings(hp, len(sub), names):
                 gpu_sigs.append(None if isinstance(ms, Exception) else hash(tuple(tuple(getattr(m, k) for k in SIG_FIELDS) for m in ms)))
+                if ref_wanted:
+                    gpu_recs.append([] if isinstance(ms, Exception) else [(m.target_name, m.target_start, m.target_end, m.query_start, m.query_end, "+" if m.strand > 0 else "-",
+                                                                             m.mapq, m.cigar_str, m.cs) for m in ms])
             L.mm355_free_hits(hp)
             if lo == 0:   # this sub-batch had the GPU to itself: the seed-lookup kernel without other contexts' kernels in front of it on its queue
                 st1 = _ffi.Stats()
@@ -638,6 +701,9 @@ def main():
     if rank == 0:
         if not args.no_cpu and world == 1:   # after the GPU side has released its memory; rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(g, names, wl["preset"], cpu_sample, args.cpu_seconds, min(16, os.cpu_count() or 1), gpu_sigs)
+            # the real minimap2 / mappy, if the box has one (it never did): timed on the same sample, records diffed -- null otherwise
+            n_ref = len(gpu_recs) if gpu_recs else min(len(cpu_sample), 6144)
+            out["reference_on_box"] = reference_on_box(g, names, wl["preset"], cpu_sample[:n_ref], gpu_recs or None, min(16, os.cpu_count() or 1))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -174,6 +174,7 @@ typedef struct {
 	int64_t n_a_literal;                         /* anchors (all of them, culled ones included) of the reads that were sorted literally */
 	int64_t n_v_rmq;                             /* anchors mg_lchain_rmq chained on the device */
 	int64_t n_dp_band, n_dp_band_redo;           /* gap fills run on a diagonal band with a sufficiency proof / of those, run again on the full matrix */
+	int64_t n_rounds_split;                      /* extension rounds whose direction matrices did not fit the HBM budget and were cut into several launches */
 } mm355_stats_t;
 
 /* sketch: minimizers of each read (mm_sketch). mz_off[n_reads+1] host array is filled; mz = (x,y) pairs */

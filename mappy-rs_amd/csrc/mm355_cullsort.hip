@@ -33,7 +33,7 @@
 
 struct CullPar {
 	uint64_t tot_len;                  // bases of all contigs; position word = strand * tot_len + seq_off[rid] + rpos < 2 * tot_len
-	int32_t ib, sh, n_pass, T;
+	int32_t ib, sh, n_pass, T;         // ib: bits of (index in generation order << 1 | kept) below the position
 };
 
 __device__ __forceinline__ uint64_t cs_pos(const DevIndex &ix, uint64_t x, uint64_t tot_len)
@@ -74,14 +74,14 @@ __device__ __forceinline__ bool cs_keep(const uint32_t *bm, uint32_t rel, uint32
 	return false;
 }
 
-// One block per read.  keys[o + i] = kept << 63 | position word << ib | i for every anchor (generation order); surv[o ..] = the words
-// (without the top bit) of the anchors that are kept, in no particular order; n_keep[r] = how many.
-__global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff, const mm128 *a, uint64_t *keys, uint64_t *surv, int32_t *n_keep, int n_reads, CullPar cp)
+// One block per read.  keys[o + i] = position word << ib | i << 1 | kept for every anchor (generation order); surv[o ..] = the words of the
+// anchors that are kept, in no particular order; n_keep[r] = how many.
+__global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff, const mm128 *a, uint64_t *keys, uint64_t *surv, int32_t *n_keep, int n_reads, CullPar cp, const int32_t *heavy_first)
 {
 	extern __shared__ uint32_t bm[];   // 3 * CS_WPL
 	__shared__ uint32_t s_cur;
-	const int r = blockIdx.x;
-	if (r >= n_reads) return;
+	if ((int)blockIdx.x >= n_reads) return;
+	const int r = heavy_first[blockIdx.x];   // the reads with the most anchors first: the longest block starts at t = 0
 	const int64_t o = aoff[r];
 	const uint32_t n = (uint32_t)(aoff[r + 1] - o), tid = threadIdx.x, lane = tid & 63;
 	if (tid == 0) s_cur = 0;
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff
 		__syncthreads();
 		for (uint32_t i = tid; i < n; i += CS_NT) {
 			uint64_t k;
-			if (p == 0) { k = cs_pos(ix, a[o + i].x, cp.tot_len); keys[o + i] = k << cp.ib | i; }
-			else k = (keys[o + i] & ~(1ULL << 63)) >> cp.ib;
+			if (p == 0) { k = cs_pos(ix, a[o + i].x, cp.tot_len); keys[o + i] = k << cp.ib | (uint64_t)i << 1; }
+			else k = keys[o + i] >> cp.ib;
 			const int64_t rel = (int64_t)(k >> cp.sh) - lo;
 			if (rel >= 0 && rel < CS_BPP + 2 * CS_GUARD) cs_add(bm, (uint32_t)rel);
 		}
@@ -102,10 +102,10 @@ __global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff
 			const uint32_t i = base + tid;
 			bool keep = false; uint64_t kw = 0;
 			if (i < n) {
-				kw = keys[o + i] & ~(1ULL << 63);                       // (written by this very thread in pass 0)
+				kw = keys[o + i] | 1ULL;                                // (written by this very thread in pass 0)
 				const int64_t rel = (int64_t)((kw >> cp.ib) >> cp.sh) - lo;
 				if (rel >= CS_GUARD && rel < CS_BPP + CS_GUARD) keep = cs_keep(bm, (uint32_t)rel, (uint32_t)cp.T);
-				if (keep) keys[o + i] = kw | 1ULL << 63;                // the decision, for the reads that are sorted literally (k_tie_copy)
+				if (keep) keys[o + i] = kw;                             // the decision in bit 0, for the reads that are sorted literally
 			}
 			const unsigned long long mk = __ballot(keep);
 			if (mk) {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_keys_all(DevIndex ix, const int64_t *ao
 	if (r >= n_reads) return;
 	const int64_t o = aoff[r];
 	const uint32_t n = (uint32_t)(aoff[r + 1] - o);
-	for (uint32_t i = threadIdx.x; i < n; i += 256) surv[o + i] = cs_pos(ix, a[o + i].x, cp.tot_len) << cp.ib | i;
+	for (uint32_t i = threadIdx.x; i < n; i += 256) surv[o + i] = cs_pos(ix, a[o + i].x, cp.tot_len) << cp.ib | (uint64_t)i << 1 | 1ULL;
 	if (threadIdx.x == 0) n_keep[r] = (int32_t)n;
 }
 
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT) void k_asort(const int32_t *list, int n_list, c
 	if ((int)blockIdx.x >= n_list) return;
 	const int r = list[blockIdx.x];
 	const int64_t o = aoff[r];
-	const uint32_t n_all = (uint32_t)(aoff[r + 1] - o), n = (uint32_t)n_keep[r], tid = threadIdx.x;
+	const uint32_t n_all = (uint32_t)(aoff[r + 1] - o), n = n_keep? (uint32_t)n_keep[r] : n_all, tid = threadIdx.x;   // (n_keep = null: the whole array, sort only)
 	uint64_t *g = surv + o;
 	bool tie = false;
 	if (n <= (uint32_t)CAP) {
@@ -222,15 +222,16 @@ __global__ __launch_bounds__(NT) void k_asort(const int32_t *list, int n_list, c
 		__syncthreads();
 		for (uint32_t i = tid; i < n; i += NT) if (i > 0 && (g[i] >> ib) == (g[i - 1] >> ib)) tie = true;
 	}
+	if (out == 0) return;                                   // sort only
 	const int any = __syncthreads_or(tie);
 	const bool literal = any && n_all > MM355_RS_MIN_SIZE;
 	if (tid == 0) flag[r] = literal? 1 : 0;
 	if (literal) return;
-	const uint64_t im = (1ULL << ib) - 1;
+	const uint64_t im = (1ULL << (ib - 1)) - 1;
 	mm128 *dst = out + aoff2[r];
 	const mm128 *src = a + o;
-	if (n <= (uint32_t)CAP) { for (uint32_t i = tid; i < n; i += NT) dst[i] = src[s[i] & im]; }
-	else for (uint32_t i = tid; i < n; i += NT) dst[i] = src[g[i] & im];
+	if (n <= (uint32_t)CAP) { for (uint32_t i = tid; i < n; i += NT) dst[i] = src[s[i] >> 1 & im]; }
+	else for (uint32_t i = tid; i < n; i += NT) dst[i] = src[g[i] >> 1 & im];
 }
 
 // ------------------------------------------------------------------ reads with equal keys among their survivors
@@ -245,25 +246,57 @@ __global__ __launch_bounds__(256) void k_tie_copy(const int32_t *list, int n_lis
 	const uint32_t n = (uint32_t)(aoff[r + 1] - o);
 	for (uint32_t i = threadIdx.x; i < n; i += 256) {
 		mm128 el = a[o + i];
-		if (keep_all || keys[o + i] >> 63) el.y |= 1ULL << 63;
+		if (keep_all || (keys[o + i] & 1ULL)) el.y |= 1ULL << 63;
 		ta[d + i] = el;
 	}
 }
-// ... and after it: the kept anchors of the literally sorted array, in order
-__global__ __launch_bounds__(256) void k_tie_emit(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const int64_t *aoff2, const mm128 *ta, mm128 *out)
+// tcnt[d + i] = equal-position neighbour pairs among the first i + 1 elements of the read's plainly sorted array (sorted[o ..]): the literal
+// emulation skips every bucket without such a pair -- its content is unique and comes from the plain sort (WalkScratch::tcnt)
+__global__ __launch_bounds__(256) void k_tie_tcnt(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const uint64_t *sorted, int32_t *tcnt, int ib)
 {
 	__shared__ uint32_t s_w[4];
 	const int t = blockIdx.x;
 	if (t >= n_list) return;
 	const int r = list[t];
-	const int64_t d = toff[t];
-	const uint32_t n = (uint32_t)(aoff[r + 1] - aoff[r]), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int64_t o = aoff[r], d = toff[t];
+	const uint32_t n = (uint32_t)(aoff[r + 1] - o), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	uint32_t base = 0;
+	for (uint32_t b0 = 0; b0 < n; b0 += 256) {
+		const uint32_t i = b0 + tid;
+		const bool tie = i > 0 && i < n && (sorted[o + i] >> ib) == (sorted[o + i - 1] >> ib);
+		const unsigned long long mk = __ballot(tie);
+		if (lane == 0) s_w[wv] = (uint32_t)__popcll(mk);
+		__syncthreads();
+		uint32_t before = 0, tot = 0;
+		for (uint32_t w2 = 0; w2 < 4; ++w2) { const uint32_t c = s_w[w2]; if (w2 < wv) before += c; tot += c; }
+		if (i < n) tcnt[d + i] = (int32_t)(base + before + (uint32_t)__popcll(mk & (LANE_LT_MASK(lane) | 1ULL << lane)));
+		base += tot;
+		__syncthreads();
+	}
+}
+// ... and after the emulation: the kept anchors of the read's sorted array, in order.  Inside a run of equal positions the emulation's
+// result (and the decision it carried); everywhere else the plain sort's element
+__global__ __launch_bounds__(256) void k_tie_emit(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const int64_t *aoff2, const mm128 *a, const mm128 *ta,
+                                                  const uint64_t *sorted, mm128 *out, int ib)
+{
+	__shared__ uint32_t s_w[4];
+	const int t = blockIdx.x;
+	if (t >= n_list) return;
+	const int r = list[t];
+	const int64_t o = aoff[r], d = toff[t];
+	const uint32_t n = (uint32_t)(aoff[r + 1] - o), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const uint64_t im = (1ULL << (ib - 1)) - 1;
 	mm128 *dst = out + aoff2[r];
 	uint32_t base_out = 0;
 	for (uint32_t base = 0; base < n; base += 256) {
 		const uint32_t i = base + tid;
 		bool keep = false; mm128 el; el.x = el.y = 0;
-		if (i < n) { el = ta[d + i]; keep = el.y >> 63 != 0; el.y &= ~(1ULL << 63); }
+		if (i < n) {
+			const uint64_t w = sorted[o + i], k = w >> ib;
+			const bool run = (i > 0 && (sorted[o + i - 1] >> ib) == k) || (i + 1 < n && (sorted[o + i + 1] >> ib) == k);
+			if (run) { el = ta[d + i]; keep = el.y >> 63 != 0; el.y &= ~(1ULL << 63); }
+			else { el = a[o + (w >> 1 & im)]; keep = (w & 1ULL) != 0; }
+		}
 		const unsigned long long mk = __ballot(keep);
 		if (lane == 0) s_w[wv] = (uint32_t)__popcll(mk);
 		__syncthreads();
@@ -294,8 +327,8 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	cp.tot_len = mi->n_seq? mi->seq_off[mi->n_seq - 1] + mi->seq_len[mi->n_seq - 1] : 1;
 	int32_t max_na = 1;
 	for (int i = 0; i < n_reads; ++i) if (hb.n_a[i] > max_na) max_na = hb.n_a[i];
-	cp.ib = bits_for((uint64_t)max_na - 1);
-	if (bits_for(2 * cp.tot_len - 1) + cp.ib > 63) return MM355_EUNSUP;   // (a 2^40-base reference with 2^22 anchors on one read; bit 63 is k_cull's mark)
+	cp.ib = bits_for((uint64_t)max_na - 1) + 1;   // index in generation order, and the cull's decision in bit 0
+	if (bits_for(2 * cp.tot_len - 1) + cp.ib > 64) return MM355_EUNSUP;   // (a 2^40-base reference with 2^22 anchors on one read)
 	// T: the fewest anchors a chain that survives mg_chain_backtrack can have; D: the largest max_dist_x of any read (chain_dist)
 	const int T = std::max<int>(pr.min_cnt, (pr.min_chain_score + mi->k - 1) / mi->k);
 	int64_t D = pr.max_gap_ref > 0? pr.max_gap_ref : pr.max_frag_len > 0? std::max(pr.max_frag_len, pr.max_gap) : pr.max_gap;
@@ -319,10 +352,9 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	int32_t *d_nk = c->n_keep.as<int32_t>();
 	const double t0 = mm355_now_ms();
 	if (do_cull) {
-		static const bool attr = [] { return hipFuncSetAttribute((const void*)k_cull, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CS_WPL * 4) == hipSuccess; }();
-		if (!attr) return MM355_EHIP;
+		if (hipFuncSetAttribute((const void*)k_cull, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CS_WPL * 4) != hipSuccess) return MM355_EHIP;
 		KtScope ks(c, KT_CULL, c->st);
-		hipLaunchKernelGGL(k_cull, dim3((unsigned)n_reads), dim3(CS_NT), 3 * CS_WPL * 4, c->st, c->dix, aoff, c->a.as<mm128>(), keys, surv, d_nk, n_reads, cp);
+		hipLaunchKernelGGL(k_cull, dim3((unsigned)n_reads), dim3(CS_NT), 3 * CS_WPL * 4, c->st, c->dix, aoff, c->a.as<mm128>(), keys, surv, d_nk, n_reads, cp, c->heavy.as<int32_t>());
 	} else hipLaunchKernelGGL(k_keys_all, dim3((unsigned)n_reads), dim3(256), 0, c->st, c->dix, aoff, c->a.as<mm128>(), surv, d_nk, n_reads, cp);
 	// pinned staging: [n_keep: nr x i32][aoff2: (nr + 1) x i64][flags: nr x u8][lists: nr x i32]
 	int32_t *h_nk = (int32_t*)c->h_cs.p;
@@ -351,9 +383,9 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	mm355_kt(c, KT_ASORT, 0, c->st);
 	if (n_small) hipLaunchKernelGGL((k_asort<256, CS_SMALL_CAP>), dim3((unsigned)n_small), dim3(256), CS_SMALL_CAP * 8, c->st, d_list, n_small, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
 	                                c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
+	// (per call, not once per process: the attribute belongs to the function on the CURRENT device, and one process may drive several)
+	if (hipFuncSetAttribute((const void*)k_asort<1024, CS_BIG_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_BIG_CAP * 8) != hipSuccess) return MM355_EHIP;
 	if (n_big) {
-		static const bool attr = [] { return hipFuncSetAttribute((const void*)k_asort<1024, CS_BIG_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_BIG_CAP * 8) == hipSuccess; }();
-		if (!attr) return MM355_EHIP;
 		hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_big), dim3(1024), CS_BIG_CAP * 8, c->st, d_list + n_small, n_big, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
 		                   c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
 	}
@@ -370,7 +402,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	if (n_tie) {
 		const double t2 = mm355_now_ms();
 		const size_t na = (size_t)tt + 64;
-		if (c->tie_a.ensure(na * 16) || c->tie_b.ensure(na * 16) || c->tie_f.ensure(na * 4) || c->tie_p.ensure(na * 4) || c->tie_t8.ensure(na) ||
+		if (c->tie_a.ensure(na * 16) || c->tie_b.ensure(na * 16) || c->tie_f.ensure(na * 4) || c->tie_p.ensure(na * 4) || c->tie_t8.ensure(na) || c->tie_tcnt.ensure(na * 4) ||
 		    c->tie_list.ensure((size_t)n_tie * 4 + ((size_t)n_tie + 1) * 8 + 64)) return MM355_ENOMEM;
 		if (c->h_tasks.ensure((size_t)n_tie * sizeof(SortTask) + (size_t)n_tie * 4 + ((size_t)n_tie + 1) * 8 + 256)) return MM355_ENOMEM;
 		// pinned: [tasks][toff: (n_tie + 1) x i64][list: n_tie x i32]
@@ -394,13 +426,20 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		HIPCHK(hipMemcpyAsync(d_toff, h_toff, ((size_t)n_tie + 1) * 8, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipMemcpyAsync(d_tl, h_tl, (size_t)n_tie * 4, hipMemcpyHostToDevice, c->st));
 		hipLaunchKernelGGL(k_tie_copy, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, c->a.as<mm128>(), keys, c->tie_a.as<mm128>(), do_cull? 0 : 1);
+		// the plain sort of the WHOLE array of these reads (with the cull off the survivors are the whole array, sorted already): where its equal
+		// positions are, so that the emulation only descends into the buckets that hold some (MM355_TIE_SKIP=0: it sorts everything)
+		static const bool tie_skip = [] { const char *e = getenv("MM355_TIE_SKIP"); return !(e && atoi(e) == 0); }();
+		const uint64_t *full_sorted = do_cull? keys : surv;
+		if (do_cull) hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_tie), dim3(1024), CS_BIG_CAP * 8, c->st, d_tl, n_tie, aoff, d_off2, (const int32_t*)0, c->a.as<mm128>(), keys,
+		                                (mm128*)0, (uint8_t*)0, cp.ib);
+		if (tie_skip) hipLaunchKernelGGL(k_tie_tcnt, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, full_sorted, c->tie_tcnt.as<int32_t>(), cp.ib);
 		DevAnchors at; memset(&at, 0, sizeof(at));
-		at.aoff = d_toff; at.a = c->tie_a.as<mm128>(); at.b = c->tie_b.as<mm128>(); at.f = c->tie_f.as<int32_t>(); at.p = c->tie_p.as<int32_t>(); at.t8 = c->tie_t8.as<uint8_t>(); at.tcnt = 0;
+		at.aoff = d_toff; at.a = c->tie_a.as<mm128>(); at.b = c->tie_b.as<mm128>(); at.f = c->tie_f.as<int32_t>(); at.p = c->tie_p.as<int32_t>(); at.t8 = c->tie_t8.as<uint8_t>(); at.tcnt = tie_skip? c->tie_tcnt.as<int32_t>() : 0;
 		const size_t task_cap = (size_t)tt / 64 + (size_t)n_tie + 1024;
 		if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 512)) return MM355_ENOMEM;
 		DevBatch bt; memset(&bt, 0, sizeof(bt));
-		if (mm355_launch_sort(bt, at, c->err.as<int>(), ht, nb, nm, ns, (size_t)tt, c->sort_tasks.p, task_cap, c->st, c)) return MM355_EHIP;
-		hipLaunchKernelGGL(k_tie_emit, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, d_off2, c->tie_a.as<mm128>(), c->b.as<mm128>());
+		if (mm355_launch_sort(bt, at, c->err.as<int>(), ht, nb, nm, ns, (size_t)tt, c->sort_tasks.p, task_cap, c->st, c, mm355_sort_levels(c->mi))) return MM355_EHIP;
+		hipLaunchKernelGGL(k_tie_emit, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, d_off2, c->a.as<mm128>(), c->tie_a.as<mm128>(), full_sorted, c->b.as<mm128>(), cp.ib);
 		HIPCHK(hipGetLastError());
 		HIPCHK(mm355_wait_stream(c->st));   // (the pinned lists above are reused by the next call)
 		mm355_trace_add(c, "s:levels", t2, mm355_now_ms());

@@ -101,7 +101,7 @@ void mm355_launch_seed_lookup(const DevIndex &ix, const DevBatch &bt, DevSeeds &
 void mm355_launch_seed_select(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, hipStream_t st, void *kt = 0);
 void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const DevBatch &bt, DevSeeds &sd, DevAnchors &an, hipStream_t st, void *kt = 0);
 struct SortTask { int32_t read; uint32_t beg, end; int32_t s; };   // a bucket [beg, end) of one read's array, to be sorted from byte shift s
-int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st, void *kt = 0);
+int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st, void *kt = 0, int n_levels = 0);
 int mm355_sort_heavy_threshold(void);
 int mm355_sort_medium_threshold(void);
 int mm355_chain_chunk(void);

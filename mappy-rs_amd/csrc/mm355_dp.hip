@@ -492,6 +492,26 @@ static void launch_reg(bool exact, unsigned n, hipStream_t st, const DpConst &dc
 }
 
 
+// which full-matrix row-sweep kernel takes a problem: 0 none (the anti-diagonal kernels), 1 k_ksw_row, 2 k_ksw_rowl -- ONE definition for the
+// launch layout (mm355_dp_run) and for the HBM budget of a round (mm355_dp_matrix_bytes)
+static int row_class(const DpConst &dc, int qlen, int tlen, int w_in, int flag)
+{
+	static const bool legacy = [] { const char *e = getenv("MM355_DP_LEGACY"); return e && atoi(e) != 0; }();
+	static const bool use_row = [] { const char *e = getenv("MM355_DP_ROW"); return !legacy && !(e && atoi(e) == 0); }();   // MM355_DP_ROW=0: anti-diagonal kernels only
+	static const bool use_rowl = [] { const char *e = getenv("MM355_DP_ROWL"); return !(e && atoi(e) == 0); }();                           // MM355_DP_ROWL=0: no eight-wave row sweep
+	const int w = w_in < 0? std::max(qlen, tlen) : w_in;
+	// ... only for a regular two-piece cost (after ksw2's ordering: e > e2, or two identical pieces).  Otherwise the boundary row and
+	// column of U:ksw2_extd2_sse.c follow the dearer piece (long_thres <= 1), H(t,q) - H(t-1,q-1) can exceed the match score next to
+	// them, the kernel's clamp `z = min(z, sc_mch)` becomes active and the result is no longer the plain recurrence the row sweep
+	// computes (found by the option fuzzer: scoring=(4,10,3,3,12,3)); those options keep the literal anti-diagonal kernels.
+	const bool regular = dc.e > dc.e2 || (dc.e == dc.e2 && dc.q == dc.q2);
+	const bool row_kind = dc.valid && use_row && regular && (flag & EZ_APPROX_MAX) && !(flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= qlen + tlen;
+	if (!row_kind) return 0;
+	// (the int16 value range is checked per problem: a user scoring such as e2 >= 7 or a large match score would wrap the packed halves)
+	if (tlen <= ROW_MAX_T) return qlen + tlen <= ROW_MAX_QT && rowl_range_ok(dc, qlen, tlen <= 256? 256 : tlen <= 512? 512 : 1024)? 1 : 0;
+	return use_rowl && tlen <= ROWL_MAX_T && qlen <= ROWL_MAX_Q && rowl_range_ok(dc, qlen, tlen)? 2 : 0;
+}
+
 __global__ void k_dp_patch(DpJobDev *jobs, const int32_t *ids, const DpJobDev *nj, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) jobs[ids[i]] = nj[i]; }
 
 // ---- band kernels (mm355_dpband.h): which problems take them, with which band
@@ -542,17 +562,12 @@ size_t mm355_dp_matrix_bytes(const mm355_mapopt_t *mo, const DpConst &dc, int ql
 {
 	if (qlen <= 0 || tlen <= 0) return 0;
 	if (mo->max_sw_mat > 0 && (int64_t)tlen * qlen > mo->max_sw_mat) return 0;
-	static const bool legacy = [] { const char *e = getenv("MM355_DP_LEGACY"); return e && atoi(e) != 0; }();
-	static const bool use_row = [] { const char *e = getenv("MM355_DP_ROW"); return !legacy && !(e && atoi(e) == 0); }();
-	static const bool use_rowl = [] { const char *e = getenv("MM355_DP_ROWL"); return !(e && atoi(e) == 0); }();
 	const int w = w_in < 0? std::max(qlen, tlen) : w_in;
 	int n_col_ = std::min(qlen, tlen);
 	n_col_ = ((n_col_ < w + 1? n_col_ : w + 1) + 15) / 16 + 1;
 	const int T = (tlen + 15) / 16 * 16;
-	const bool regular = dc.e > dc.e2 || (dc.e == dc.e2 && dc.q == dc.q2);
-	const bool row_kind = dc.valid && use_row && regular && (flag & EZ_APPROX_MAX) && !(flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= qlen + tlen;
-	const bool row = row_kind && tlen <= ROW_MAX_T && qlen + tlen <= ROW_MAX_QT && rowl_range_ok(dc, qlen, tlen <= 256? 256 : tlen <= 512? 512 : 1024);
-	const bool rowl = row_kind && use_rowl && tlen > ROW_MAX_T && tlen <= ROWL_MAX_T && qlen <= ROWL_MAX_Q && rowl_range_ok(dc, qlen, tlen);
+	const int rk = row_class(dc, qlen, tlen, w_in, flag);
+	const bool row = rk == 1, rowl = rk == 2;
 	if (row || rowl) {
 		const BandPlan bp = band_plan(dc, qlen, tlen, rowl? 64 : tlen <= 256? 2 : tlen <= 512? 4 : 8);
 		if (bp.nsb) return band_matrix_bytes(qlen, 128 * bp.nsb) + 64;
@@ -569,8 +584,6 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	if (n == 0) return 0;
 	DpConst dc = mm355_dp_const(mo);
 	static const bool legacy = [] { const char *e = getenv("MM355_DP_LEGACY"); return e && atoi(e) != 0; }();
-	static const bool use_row = [] { const char *e = getenv("MM355_DP_ROW"); return !legacy && !(e && atoi(e) == 0); }();   // MM355_DP_ROW=0: anti-diagonal kernels only
-	static const bool use_rowl = [] { const char *e = getenv("MM355_DP_ROWL"); return !(e && atoi(e) == 0); }();                           // MM355_DP_ROWL=0: no eight-wave row sweep
 	static const bool use_regw = [] { const char *e = getenv("MM355_DP_REGW"); return !legacy && !(e && atoi(e) == 0); }();               // MM355_DP_REGW=0: no windowed register kernel
 	static const bool regw8 = [] { const char *e = getenv("MM355_DP_REGW8"); return !(e && atoi(e) == 0); }();                             // MM355_DP_REGW8=0: the single-wave kernel of round 2 (same results)
 	size_t regw_seq = 0;                       // LDS bytes of the longest (query, target) pair of the eight-wave kernel in this round
@@ -593,17 +606,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		j.pad = 0; j.dlo = 0; j.lmin = 0; j.bw = 0; j.rsv = 0;
 		if (j.qlen > 0 && j.tlen > 0 && !j.skip) {
 			cig_tot += (size_t)j.qlen + j.tlen + 2;
-			// gap fills whose band never binds, without z-drop on the approximate score: the row sweep (mm355_dprow.h)
-			// ... and only for a regular two-piece cost (after ksw2's ordering: e > e2, or two identical pieces).  Otherwise the boundary row and
-			// column of U:ksw2_extd2_sse.c follow the dearer piece (long_thres <= 1), H(t,q) - H(t-1,q-1) can exceed the match score next to
-			// them, the kernel's clamp `z = min(z, sc_mch)` becomes active and the result is no longer the plain recurrence the row sweep
-			// computes (found by the option fuzzer: scoring=(4,10,3,3,12,3)); those options keep the literal anti-diagonal kernels.
-			const bool regular = dc.e > dc.e2 || (dc.e == dc.e2 && dc.q == dc.q2);
-			const bool row_kind = use_row && regular && (j.flag & EZ_APPROX_MAX) && !(j.flag & (EZ_APPROX_DROP | EZ_EXTZ_ONLY | EZ_SCORE_ONLY)) && w >= j.qlen + j.tlen;
-			// (the int16 value range is checked for the row sweep's register sets as for the long variant: a user scoring such as e2 >= 7 or a
-			// large match score would wrap the packed halves; such problems keep the anti-diagonal kernels)
-			const bool row = row_kind && j.tlen <= ROW_MAX_T && j.qlen + j.tlen <= ROW_MAX_QT && rowl_range_ok(dc, j.qlen, j.tlen <= 256? 256 : j.tlen <= 512? 512 : 1024);
-			const bool rowl = row_kind && use_rowl && j.tlen > ROW_MAX_T && j.tlen <= ROWL_MAX_T && j.qlen <= ROWL_MAX_Q && rowl_range_ok(dc, j.qlen, j.tlen);
+			// gap fills whose band never binds, without z-drop on the approximate score: the row sweep (mm355_dprow.h; row_class above)
+			const int rk = row_class(dc, j.qlen, j.tlen, j.w, j.flag);
+			const bool row = rk == 1, rowl = rk == 2;
 			if (row || rowl) {
 				const BandPlan bp = band_plan(dc, j.qlen, j.tlen, rowl? 64 : j.tlen <= 256? 2 : j.tlen <= 512? 4 : 8);
 				p_tot = (p_tot + 63) & ~(size_t)63;            // tiles are 64-byte lines
@@ -1225,6 +1230,9 @@ extern "C" int mm355_stage_extra(mm355_ctx_t *c, const mm355_mapopt_t *mo, int64
 	size_t n_segs = 0;
 	for (int64_t k = 0; k < n_regions; ++k) {
 		if (jobs[k].n_cigar < 0 || jobs[k].cigar_off < 0 || jobs[k].cigar_off + jobs[k].n_cigar > n_cigar || (uint32_t)jobs[k].rid >= c->mi->n_seq) return MM355_EINVAL;
+		// '=' / 'X' CIGARs never reach the device walk in the mapping path (MM_F_EQX keeps the host walk, which rewrites the CIGAR): U:align.c::mm_update_extra
+		// counts match columns on op 0 only, so a stage call with ops 7 / 8 would disagree with its own oracle -- refused
+		for (int32_t x = 0; x < jobs[k].n_cigar; ++x) { const uint32_t op = cigar[jobs[k].cigar_off + x] & 0xf; if (op == 7 || op == 8) return MM355_EINVAL; }
 		n_segs += (size_t)mm355_extra_split(cigar + jobs[k].cigar_off, jobs[k].n_cigar, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0);
 	}
 	const size_t seg_b = (n_segs * sizeof(Mm355ExtraJob) + 63) & ~(size_t)63;

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTa
 #define MW_MED_LAB (MW_BIG + 64)
 #define MW_LEVELS 9
 template <typename T, typename Key>
-static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, size_t n_elems, size_t task_cap, int *err, hipStream_t st)
+static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, size_t n_elems, size_t task_cap, int n_levels, int *err, hipStream_t st)
 {
 	(void)hipFuncSetAttribute((const void*)k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, MW_LAB_CAP);
 	const uint32_t big_min = (uint32_t)mm355_sort_heavy_threshold(), med_min = (uint32_t)mm355_sort_medium_threshold();
@@ -787,10 +787,13 @@ static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2]
 	h[0] = (unsigned int)n_big; h[1] = (unsigned int)n_med; h[2 * (MW_LEVELS + 1)] = (unsigned int)n_small;
 	if (hipMemcpyAsync(d_ctr, h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess) return -1;   // (pageable source: the copy is staged before the call returns)
 	unsigned int *d_small_ctr = d_ctr + 2 * (MW_LEVELS + 1);
-	// grids behind level 0: a bound on the list length, capped -- the blocks stride over the list
-	const size_t cap_big = std::min<size_t>(std::min(task_cap, n_elems / big_min + 1), 96), cap_med = std::min<size_t>(std::min(task_cap, n_elems / med_min + 1), 1024);
+	// grids behind level 0: a bound on the list length, capped -- the blocks stride over the list (under the bench load: 48 big-class blocks 435 ms per
+	// step in the emulation, 96: 392, 192: 366, 400: 359 -- a block per task beats a short grid although every block wants a whole CU)
+	static const size_t lim_big = [] { const char *e = getenv("MM355_SORT_CAP_BIG"); return (size_t)(e && atoi(e) > 0? atoi(e) : 512); }();
+	static const size_t lim_med = [] { const char *e = getenv("MM355_SORT_CAP_MED"); return (size_t)(e && atoi(e) > 0? atoi(e) : 1024); }();
+	const size_t cap_big = std::min<size_t>(std::min(task_cap, n_elems / big_min + 1), lim_big), cap_med = std::min<size_t>(std::min(task_cap, n_elems / med_min + 1), lim_med);
 	int cur = 0;
-	for (int level = 0; level < MW_LEVELS; ++level) {
+	for (int level = 0; level < MW_LEVELS && level < n_levels; ++level) {
 		const size_t gb = level == 0? (size_t)n_big : cap_big, gm = level == 0? (size_t)n_med : cap_med;
 		if (level == 0 && n_big + n_med == 0) break;
 		unsigned int *c_in = d_ctr + 2 * level, *c_out = d_ctr + 2 * (level + 1);
@@ -1196,8 +1199,9 @@ void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const Dev
 // Literal radix_sort_128x of the listed reads.  h_tasks: the initial whole-read tasks (byte 56) grouped by size class -- n_big entries
 // (> MW_BIG anchors: 1024-thread levels), then n_med (> MW_MED: 256-thread levels), then n_small (one wave each) -- in pinned or otherwise
 // stable host memory until the stream has consumed it.  n_elems: elements of all listed arrays together.  task_buf: device scratch for 5 task
-// lists of `task_cap` entries + 64 counters.
-int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st, void *kt)
+// lists of `task_cap` entries + 64 counters.  n_levels (0 = all nine): a bound on the number of list levels -- one per byte of the key that is not the
+// same for every element the index can produce (a level whose byte is constant is skipped inside the kernel and opens no new list).
+int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st, void *kt, int n_levels)
 {
 	(void)bt;
 	KtScope ks(kt, KT_LITERAL, st);
@@ -1211,7 +1215,7 @@ int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *
 	if (n_big && hipMemcpyAsync(big[0], ht, (size_t)n_big * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 	if (n_med && hipMemcpyAsync(med[0], ht + n_big, (size_t)n_med * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 	if (n_small && hipMemcpyAsync(small, ht + n_big + n_med, (size_t)n_small * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, n_elems, task_cap, err, st);
+	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, n_elems, task_cap, n_levels > 0? n_levels : MW_LEVELS, err, st);
 }
 int mm355_sort_task_bytes(void) { return (int)sizeof(SortTask); }
 int mm355_sort_heavy_threshold(void)   // MM355_SORT_HEAVY_MIN: test hook that pushes ordinary reads through the 1024-thread path

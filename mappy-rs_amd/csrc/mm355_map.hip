@@ -197,6 +197,7 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 	// what this context already holds for direction matrices costs nothing to use again: with six contexts' buffers resident the free
 	// third alone is below one round's matrices, and a round cut in two is two launch cycles (two turns, twice the tails)
 	if (c->dp_bt.cap > 64 && budget < c->dp_bt.cap - 64) budget = c->dp_bt.cap - 64;
+	if (const char *e = getenv("MM355_DP_BUDGET_MB")) { if (atoll(e) > 0) budget = (size_t)atoll(e) << 20; }   // test hook (read per call): forces rounds to be cut
 	const bool verbose = getenv("MM355_VERBOSE") != 0;
 	const int nt = host_threads();
 	std::vector<int64_t> qo, to;
@@ -215,6 +216,9 @@ static int run_dp_round(mm355_ctx *c, const mm355_mapopt_t *mo, std::vector<Read
 			q_tot += (size_t)(q.qlen > 0? q.qlen : 0) + 16; t_tot += (size_t)(q.tlen > 0? q.tlen : 0) + 16; p_tot += pb;
 		}
 		const size_t n = j - i;
+		// a round whose direction matrices do not fit the budget is cut into several launch cycles (several turns, several tails): it costs
+		// rate, silently -- so it is counted (mm355_stats_t::n_rounds_split; bench.py prints it, 0 on the GRCh38-scale workload)
+		if (j < reqs.size() && i == 0) ++c->stats.n_rounds_split;
 		if (c->h_gather.ensure(n * sizeof(DpGather)) || c->h_jobs.ensure(n * sizeof(DpJobDev))) return MM355_ENOMEM;
 		DpGather *g = (DpGather*)c->h_gather.p; DpJobDev *jobs = (DpJobDev*)c->h_jobs.p;
 		parallel_for(nt, nt, [&](int64_t part, int) {

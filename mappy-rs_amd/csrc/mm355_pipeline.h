@@ -81,7 +81,7 @@ struct mm355_ctx {
 	DBuf heavy, seq, roff, rlen, order, ck_read, ck_start, ck_n, ck_r0;
 	int64_t n_chunks = 0;
 	int prio_low = 0, prio_high = 0; bool use_prio = false; int ord = 0;   // ord: creation ordinal of the context
-	DBuf sort_flag, tie_list, n_keep, aoff2, cs_list, tie_a, tie_b, tie_f, tie_p, tie_t8; HBuf h_cs;   // cull + sort of anchor-rich batches (mm355_cullsort.hip)
+	DBuf sort_flag, tie_list, n_keep, aoff2, cs_list, tie_a, tie_b, tie_f, tie_p, tie_t8, tie_tcnt; HBuf h_cs;   // cull + sort of anchor-rich batches (mm355_cullsort.hip)
 	int n_heavy = 0; hipStream_t aux_st = 0; hipEvent_t aux_ev = 0, aux_ev2 = 0; DBuf sort_tasks;
 	DBuf mz, mz_tmp, n_mz, sn, sv, sflt, hl, soff, n_a, rep_len, n_mini, mini_pos, counters, err;
 	DBuf aoff, a, f, p, v, z, t8, vi, b, wk, u, u2, n_u, n_v;
@@ -151,6 +151,7 @@ struct EvTimer {
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)
 
+int mm355_sort_levels(const mm355_index *mi);
 int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull);   // mm355_cullsort.hip: anchors that cannot chain dropped, the rest sorted per read in LDS
 hipError_t mm355_wait_stream(hipStream_t st);   // polls hipStreamQuery with short naps (MM355_BLOCKING_WAIT=0: hipStreamSynchronize, =1: blocking-sync event)
 void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1);   // MM355_TRACE timeline (no-op when unset)

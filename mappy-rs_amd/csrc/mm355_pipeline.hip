@@ -310,7 +310,7 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 {
 	if (c == 0) return;
 	(void)hipSetDevice(c->dev);
-	DBuf *bufs[] = { &c->sort_tasks, &c->sort_flag, &c->tie_list, &c->n_keep, &c->aoff2, &c->cs_list, &c->tie_a, &c->tie_b, &c->tie_f, &c->tie_p, &c->tie_t8, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
+	DBuf *bufs[] = { &c->sort_tasks, &c->sort_flag, &c->tie_list, &c->n_keep, &c->aoff2, &c->cs_list, &c->tie_a, &c->tie_b, &c->tie_f, &c->tie_p, &c->tie_t8, &c->tie_tcnt, &c->heavy, &c->seq, &c->roff, &c->rlen, &c->order, &c->ck_read, &c->ck_start, &c->ck_n, &c->ck_r0,
 		&c->mz, &c->mz_tmp, &c->n_mz, &c->sn, &c->sv, &c->sflt, &c->hl, &c->soff, &c->n_a, &c->rep_len, &c->n_mini, &c->mini_pos, &c->counters, &c->err,
 		&c->aoff, &c->a, &c->f, &c->p, &c->v, &c->z, &c->t8, &c->vi, &c->b, &c->wk, &c->u, &c->u2, &c->n_u, &c->n_v,
 		&c->kprof, &c->d_chunks, &c->dp_jobs, &c->dp_res, &c->dp_q, &c->dp_t, &c->dp_bt, &c->dp_bt2, &c->dp_fail, &c->dp_cig, &c->dp_work, &c->dp_H, &c->rq, &c->dp_dense, &c->dp_gather, &c->pack, &c->rmq_list, &c->rmq_flag, &c->x_jobs, &c->x_cig, &c->x_cs, &c->x_out, &c->x_dense };
@@ -434,10 +434,11 @@ int mm355_run_seeds(mm355_ctx *c, const DevParams &pr)
 		HIPCHK(hipMemcpyAsync(hb.rep_len.data(), c->rep_len.p, n * 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipMemcpyAsync(hb.n_mini.data(), c->n_mini.p, n * 4, hipMemcpyDeviceToHost, c->st));
 	}
-	unsigned long long ctr[8], hits[CTR_HITS_WORDS];
-	HIPCHK(hipMemcpyAsync(ctr, c->counters.p, 64, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(hits, c->counters.as<unsigned long long>() + CTR_HITS_OFF, CTR_HITS_WORDS * 8, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(mm355_wait_stream(c->st));
+	unsigned long long ctr[8], hits[CTR_HITS_WORDS];   // (stack targets of asynchronous copies: the stream is synchronised before any return)
+	hipError_t ce = hipMemcpyAsync(ctr, c->counters.p, 64, hipMemcpyDeviceToHost, c->st);
+	if (ce == hipSuccess) ce = hipMemcpyAsync(hits, c->counters.as<unsigned long long>() + CTR_HITS_OFF, CTR_HITS_WORDS * 8, hipMemcpyDeviceToHost, c->st);
+	const hipError_t we = mm355_wait_stream(c->st);
+	if (ce != hipSuccess || we != hipSuccess) return MM355_EHIP;
 	ctr[0] = 0;
 	for (int k = 0; k < CTR_HITS_WORDS; ++k) ctr[0] += hits[k];
 	int64_t tot = 0, tmz = 0;
@@ -467,6 +468,17 @@ static int check_err(mm355_ctx *c)
 	HIPCHK(hipMemcpyAsync(e, c->err.p, 16, hipMemcpyDeviceToHost, c->st));
 	HIPCHK(mm355_wait_stream(c->st));
 	return e[0]? MM355_ENOMEM : 0;
+}
+
+// list levels the literal radix_sort_128x emulation can need for the anchors of this index: the bytes of x = strand << 63 | rid << 32 | rpos that vary
+int mm355_sort_levels(const mm355_index *mi)
+{
+	uint32_t max_len = 1;
+	for (uint32_t l : mi->seq_len) if (l > max_len) max_len = l;
+	int n = 1;                                            // byte 7: the strand (and rid >> 24)
+	for (int sh = 16; sh >= 0; sh -= 8) if (((uint64_t)(mi->n_seq > 0? mi->n_seq - 1 : 0) >> sh) != 0 || sh == 0) ++n;   // bytes 6, 5, 4: rid
+	for (int sh = 24; sh >= 0; sh -= 8) if (((uint64_t)(max_len - 1) >> sh) != 0 || sh == 0) ++n;                          // bytes 3 .. 0: rpos
+	return n + 1;                                         // (+ 1: slack for the list the last level writes)
 }
 
 static int upload_heavy_order(mm355_ctx *c)   // per-read kernels take the reads with the most anchors first: the slowest block starts at t = 0 instead of last
@@ -539,7 +551,7 @@ int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 				// big tasks first in their list: the longest level walks start at t = 0
 				std::stable_sort(ht, ht + nb, [](const SortTask &x, const SortTask &y) { return x.end > y.end; });
 				const double ts1 = mm355_now_ms();
-				if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, (size_t)c->hb.tot_a, c->sort_tasks.p, task_cap, c->st, c)) return MM355_EHIP;
+				if (mm355_launch_sort(b, a, c->err.as<int>(), ht, nb, nm, ns, (size_t)c->hb.tot_a, c->sort_tasks.p, task_cap, c->st, c, mm355_sort_levels(c->mi))) return MM355_EHIP;
 				mm355_trace_add(c, "s:levels", ts1, mm355_now_ms());
 			}
 		}
@@ -627,12 +639,16 @@ static int rmq_pass(mm355_ctx *c, const RmqParams &rp, const DevParams &pr, int 
 	HIPCHK(hipMemsetAsync(ctr, 0, CTR_RMQ_WORDS * 8, c->st));
 	{ EvTimer t(c, &c->stats.ms_rmq);
 	  if (mm355_launch_rmq(rp, pr, b, a, c->rmq_list.as<int32_t>(), nl, c->rmq_flag.as<uint8_t>(), c->err.as<int>(), ctr, c->st, c)) return MM355_EHIP; }
+	// (the copies below land in a stack array and in pageable vectors: no return between the first of them and the synchronisation in
+	// check_err -- a failed call is remembered and reported behind it.  A pass that bails out leaves f / p / v / u2 / z partly rewritten: the
+	// host fallback re-chains from a[] alone, the only array a HOST / HOST_ALL read relies on)
 	unsigned long long hc[CTR_RMQ_WORDS];
-	HIPCHK(hipMemcpyAsync(hf, c->rmq_flag.p, (size_t)n, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(hb.n_u.data(), c->n_u.p, n * 4, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(hb.n_v.data(), c->n_v.p, n * 4, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(hipMemcpyAsync(hc, ctr, CTR_RMQ_WORDS * 8, hipMemcpyDeviceToHost, c->st));
+	hipError_t ce = hipMemcpyAsync(hf, c->rmq_flag.p, (size_t)n, hipMemcpyDeviceToHost, c->st);
+	if (ce == hipSuccess) ce = hipMemcpyAsync(hb.n_u.data(), c->n_u.p, n * 4, hipMemcpyDeviceToHost, c->st);
+	if (ce == hipSuccess) ce = hipMemcpyAsync(hb.n_v.data(), c->n_v.p, n * 4, hipMemcpyDeviceToHost, c->st);
+	if (ce == hipSuccess) ce = hipMemcpyAsync(hc, ctr, CTR_RMQ_WORDS * 8, hipMemcpyDeviceToHost, c->st);
 	int rc = check_err(c);   // (synchronises the stream)
+	if (ce != hipSuccess) return MM355_EHIP;
 	if (rc) return rc;
 	for (int k = 0; k < nl; ++k) c->stats.n_v_rmq += rp.primary? hb.n_a[hl[k]] : 0;
 	for (int64_t i = 0; i < n; ++i) {

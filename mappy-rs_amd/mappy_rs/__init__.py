@@ -32,7 +32,7 @@ __all__ = ["Aligner", "Mapping", "shard_by_bases", "order_by_length"]
 _CIGAR_OPS = "MIDNSHP=X"
 
 # capacity constants of the reference (lib.rs:429-430, 950)
-SUB_BATCH_READS, SUB_BATCH_BASES = 6144, 64_000_000   # one GPU sub-batch of map_batch (bench.py's default shape)
+SUB_BATCH_READS, SUB_BATCH_BASES = 9216, 96_000_000   # one GPU sub-batch of map_batch (bench.py's default shape: a 73 728-read block over eight contexts)
 WORK_QUEUE_CAP = 50000
 # results a batch may hold before its workers wait for the consumer: the reference's results_queue (ArrayQueue of 50 000, lib.rs:430) plus its
 # bounded(20000) channel (lib.rs:950) -- here one channel.  (With 20 000 alone the workers stall while map_batch is still consuming its
@@ -61,7 +61,10 @@ class Mapping:
 
     A record that comes out of the mapping path is a view: `_r` is the row of the C-ABI hit array (a tuple, converted in bulk), `_b`
     the arenas it points into; fields are read on access (the reference converts its Vec / Strings on access as well, lib.rs:196-284).
-    Creating a record is two slot stores -- the per-hit cost under the GIL that used to cap `map_batch` below the C-ABI rate."""
+    Creating a record is two slot stores -- the per-hit cost under the GIL that used to cap `map_batch` below the C-ABI rate.
+    Retention: an untouched view keeps its sub-batch's arenas alive (CIGAR words + cs / MD bytes of up to SUB_BATCH_READS reads, a few MB).
+    The first access to `cigar`, `cs` or `MD` -- or `detach()` -- copies the record's own slices and drops that reference, so a caller that
+    keeps a few records of a large `map_batch` (the reference's records own their Vec / Strings) holds a few hundred bytes each."""
 
     __slots__ = ("_b", "_r", "_cig", "_own")
     FIELDS = ("query_start", "query_end", "strand", "target_name", "target_len", "target_start", "target_end",
@@ -97,30 +100,36 @@ class Mapping:
     is_primary = property(lambda s: bool(s._r[_PR]) if s._own is None else s._own[10])
     NM = property(lambda s: s._r[_NM] if s._own is None else s._own[11])
 
+    def detach(self):
+        """make the record independent of its sub-batch: copy its fields, CIGAR and cs / MD out of the shared arenas and drop the reference"""
+        if self._own is None:
+            r, b = self._r, self._b
+            w = b.cig[r[_CO]:r[_CO] + r[_NC]]
+            self._cig = list(zip((w >> 4).tolist(), (w & 0xf).tolist()))
+            md = b.sbuf[r[_MDO]:r[_MDO] + r[_MDL]].decode() if r[_MDL] >= 0 else None
+            cs = b.sbuf[r[_CSO]:r[_CSO] + r[_CSL]].decode() if r[_CSL] >= 0 else None
+            self._own = (r[_QS], r[_QE], r[_ST], b.names[r[_RID]], r[_TL], r[_TS], r[_TE], r[_ML], r[_BL], r[_MQ], bool(r[_PR]), r[_NM], md, cs)
+            self._b = self._r = None
+        return self
+
     @property
     def MD(self):
-        if self._own is not None:
-            return self._own[12]
-        r = self._r
-        return self._b.sbuf[r[_MDO]:r[_MDO] + r[_MDL]].decode() if r[_MDL] >= 0 else None
+        if self._own is None:
+            self.detach()
+        return self._own[12]
 
     @property
     def cs(self):
-        if self._own is not None:
-            return self._own[13]
-        r = self._r
-        return self._b.sbuf[r[_CSO]:r[_CSO] + r[_CSL]].decode() if r[_CSL] >= 0 else None
+        if self._own is None:
+            self.detach()
+        return self._own[13]
 
     @property
     def cigar(self):
         """list of (length, op) tuples, as mappy-rs; unpacked from the packed uint32 words (length << 4 | op) on first access"""
-        c = self._cig
-        if c is None:
-            r = self._r
-            w = self._b.cig[r[_CO]:r[_CO] + r[_NC]]
-            c = list(zip((w >> 4).tolist(), (w & 0xf).tolist()))
-            self._cig = c
-        return c
+        if self._own is None:
+            self.detach()
+        return self._cig
 
     # mappy aliases (lib.rs:196-284)
     ctg = property(lambda s: s.target_name)

@@ -67,7 +67,7 @@ class Stats(C.Structure):
                 ("ms_dp_group", C.c_double * 24), ("dp_cells_group", C.c_int64 * 24), ("n_launch_group", C.c_int64 * 24),
                 ("n_ext_rounds", C.c_int64), ("n_sort_fast_reads", C.c_int64), ("n_sort_tie_reads", C.c_int64),
                 ("ms_rmq", C.c_double), ("n_rmq_reads", C.c_int64), ("n_rmq_host", C.c_int64), ("rmq_scanned", C.c_int64),
-                ("host_cpu_ms", C.c_double), ("n_a_kept", C.c_int64), ("ms_kernel", C.c_double * 24), ("chain_pairs_big", C.c_int64), ("n_a_literal", C.c_int64), ("n_v_rmq", C.c_int64), ("n_dp_band", C.c_int64), ("n_dp_band_redo", C.c_int64)]
+                ("host_cpu_ms", C.c_double), ("n_a_kept", C.c_int64), ("ms_kernel", C.c_double * 24), ("chain_pairs_big", C.c_int64), ("n_a_literal", C.c_int64), ("n_v_rmq", C.c_int64), ("n_dp_band", C.c_int64), ("n_dp_band_redo", C.c_int64), ("n_rounds_split", C.c_int64)]
 
 
 class DpJob(C.Structure):

@@ -35,6 +35,8 @@ def _check(line, steps, warmup, cpu, n_gpus=1):
     if cpu:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["parity"]["mismatching_reads"] == 0 and c["parity"]["reads"] > 0
+        # the real minimap2 / mappy is looked for on every run with a CPU leg: null when the box has neither, else timed + diffed
+        assert "reference_on_box" in d and (d["reference_on_box"] is None or "error" in d["reference_on_box"] or d["reference_on_box"]["parity"]["mismatching_reads"] == 0)
     return d
 
 

@@ -531,6 +531,23 @@ def test_stats_counters(ont):
     assert st.dp_cells > 0 and st.n_dp_jobs > 0 and st.ms_seed_lookup > 0
 
 
+def test_round_cut_by_hbm_budget_is_counted_and_exact(ont, monkeypatch):
+    """an extension round whose direction matrices do not fit the HBM budget is cut into several launches: slower, never different -- and
+    counted (mm355_stats_t::n_rounds_split), so that a workload that outgrows the budget shows up in the numbers instead of halving the rate
+    silently"""
+    from mappy_rs import _ffi
+    reads, _ = S.make_reads(84, ont["g"], 40, n50=3000, lo=500)
+    al = ont["al"]
+    ref = [[rec(m) for m in ms] for ms in al._map_many(reads, 1)]
+    st = _ffi.Stats(); _ffi.check(al._L.mm355_get_stats(al._ctx, C.byref(st)))
+    assert st.n_rounds_split == 0 and st.n_ext_rounds >= 1
+    monkeypatch.setenv("MM355_DP_BUDGET_MB", "1")
+    cut = [[rec(m) for m in ms] for ms in al._map_many(reads, 1)]
+    _ffi.check(al._L.mm355_get_stats(al._ctx, C.byref(st)))
+    assert st.n_rounds_split >= 1, st.n_rounds_split
+    assert cut == ref
+
+
 def test_map_batch_pipeline_workers(ont, monkeypatch):
     """map_batch over several worker contexts (sub-batches of 7 reads, 4 host threads) returns what the sequential path returns
     (results stream in completion order, as in the reference: compared by id), and equals the oracle for a sample"""
