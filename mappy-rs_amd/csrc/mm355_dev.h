@@ -107,6 +107,7 @@ int mm355_sort_medium_threshold(void);
 int mm355_chain_chunk(void);
 int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr,
                        const void *chunks, int n_chunks, hipStream_t st, void *kt = 0);
-void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st, void *kt = 0);
+void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, unsigned int *qctr, hipStream_t st, void *kt = 0);
+int mm355_resident_blocks(void);
 #endif
 hipError_t mm355_wait_stream(hipStream_t st);   // like hipStreamSynchronize, but the calling thread sleeps

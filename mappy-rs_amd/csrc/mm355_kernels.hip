@@ -986,9 +986,8 @@ __global__ __launch_bounds__(256) void k_chain_small(DevParams pr, DevBatch bt, 
 #define CH_XMASK (CH_XRING - 1)
 #define CH_XNEAR (CH_XRING - 2 * WAVE)
 #define CH_NEAR (CH_RING - 2 * WAVE)    // j is served from the rings when i - j <= CH_NEAR (the a[] ring also holds one chunk ahead)
-__global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, DevAnchors an, const ChainSeg *segs, unsigned int n_segs, unsigned long long *pairs_ctr)
+__device__ __forceinline__ void chain_big_segment(const DevParams &pr, const DevBatch &bt, const DevAnchors &an, const ChainSeg *segs, unsigned int n_segs, unsigned long long *pairs_ctr, const unsigned int bid)
 {
-	MM355_LATENCY_KERNEL();
 	// t[] marks of the active window, circular by anchor index: 15 bits of the marking anchor + a valid bit (a stale mark
 	// would need an index distance that is a multiple of 32768, larger than window + ring size)
 	__shared__ uint16_t tw[TW_SIZE];
@@ -999,9 +998,9 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 	__shared__ int32_t rf[CH_RING], rp[CH_RING], rv[CH_RING];
 #define CH_SYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 	const int lane = threadIdx.x;
-	if (blockIdx.x >= n_segs) return;
+	if (bid >= n_segs) return;
 	KPROF_BEGIN(bt);
-	const ChainSeg sg = segs[blockIdx.x];
+	const ChainSeg sg = segs[bid];
 	const int r = sg.read;
 	const int64_t o = an.aoff[r];
 	const int i_begin = sg.i0, n = sg.i0 + sg.len;
@@ -1134,20 +1133,45 @@ __global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, D
 	}
 #undef CH_SYNC
 	KPROF(12);
-	if (lane == 0 && pairs) atomicAdd(pairs_ctr + 32 + (blockIdx.x & 31), pairs);                     // words 32..63: long segments
+	if (lane == 0 && pairs) atomicAdd(pairs_ctr + 32 + (bid & 31), pairs);                     // words 32..63: long segments
+}
+
+
+// One wave per block, a RESIDENT grid: a block takes the next entry of the work list when it is free (one atomic per entry) instead of one block
+// per entry.  These kernels hold 30-50 KB of LDS per wave for as long as their read lasts; with a block per entry the first blocks of a launch
+// (the heaviest reads: the lists are sorted) took every CU's LDS for milliseconds, and the LDS kernels of the other contexts waited behind them.
+// A few hundred resident blocks leave LDS for the others, and the tail is no longer: the heaviest entries start first and a free block
+// always takes the next one (longest-processing-time order).  Exit: the shared counter has run past the list -- every block gets there.
+#define MM355_DEQUEUE(ctr_ptr, n_items, idx_var) \
+	for (unsigned int idx_var = mm355_next_item(ctr_ptr); idx_var < (unsigned int)(n_items); idx_var = mm355_next_item(ctr_ptr))
+__device__ __forceinline__ unsigned int mm355_next_item(unsigned int *ctr)
+{
+	__syncthreads();                                        // the block's LDS is free again
+	unsigned int v = 0;
+	if (threadIdx.x == 0) v = atomicAdd(ctr, 1u);
+	return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+}
+__global__ __launch_bounds__(WAVE) void k_chain_big(DevParams pr, DevBatch bt, DevAnchors an, const ChainSeg *segs, unsigned int n_segs, unsigned long long *pairs_ctr, unsigned int *qctr)
+{
+	MM355_LATENCY_KERNEL();
+	MM355_DEQUEUE(qctr, n_segs, bid) chain_big_segment(pr, bt, an, segs, n_segs, pairs_ctr, bid);
 }
 
 #include "mm355_btcore.h"
-__global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, DevAnchors an, int *err, const int32_t *heavy_first)
+__global__ __launch_bounds__(WAVE) void k_backtrack(DevParams pr, DevBatch bt, DevAnchors an, int *err, const int32_t *heavy_first, unsigned int *qctr)
 {
 	MM355_LATENCY_KERNEL();
 	__shared__ BtLds S;
-	const int r = heavy_first[blockIdx.x];
-	wave_backtrack_read(pr, bt, an, err, &S, r, (int)(an.aoff[r+1] - an.aoff[r]), pr.bw);
+	MM355_DEQUEUE(qctr, bt.n_reads, bid) {
+		const int r = heavy_first[bid];
+		wave_backtrack_read(pr, bt, an, err, &S, r, (int)(an.aoff[r+1] - an.aoff[r]), pr.bw);
+	}
 }
 
 // ------------------------------------------------------------------ launchers
 int mm355_sketch_chunk_size(void) { return SK_CHUNK; }
+// resident blocks of the one-wave-per-read kernels that hold tens of KB of LDS each (MM355_DEQUEUE): MM355_RESIDENT_BLOCKS, default 768 = 3 per CU
+int mm355_resident_blocks(void) { static const int n = [] { const char *e = getenv("MM355_RESIDENT_BLOCKS"); return e && atoi(e) > 0? atoi(e) : 768; }(); return n; }
 void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks,
                          const int64_t *read_chunk0, int32_t *chunk_n, hipStream_t st, void *kt)
 {
@@ -1243,13 +1267,15 @@ int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, 
 	unsigned int h[2] = {0, 0};
 	if (hipMemcpyAsync(h, ctr, 8, hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
 	if (mm355_wait_stream(st) != hipSuccess) return -1;
-	if (h[1]) { KtScope ks(kt, KT_CHAIN_BIG, st); hipLaunchKernelGGL(k_chain_big, dim3(h[1]), dim3(WAVE), 0, st, pr, bt, an, (const ChainSeg*)seg_big, h[1], pairs); }
+	if (hipMemsetAsync(ctr + 1, 0, 4, st) != hipSuccess) return -1;   // (read back: the word becomes k_chain_big's work-list cursor)
+	if (h[1]) { KtScope ks(kt, KT_CHAIN_BIG, st); hipLaunchKernelGGL(k_chain_big, dim3(h[1] < (unsigned)mm355_resident_blocks()? h[1] : (unsigned)mm355_resident_blocks()), dim3(WAVE), 0, st, pr, bt, an, (const ChainSeg*)seg_big, h[1], pairs, ctr + 1); }
 	if (h[0]) { KtScope ks(kt, KT_CHAIN_SMALL, st); hipLaunchKernelGGL(k_chain_small, dim3((h[0] + 255) / 256), dim3(256), 0, st, pr, bt, an, (const ChainSeg*)seg_small, h[0], pairs); }
 	return 0;
 }
-void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, hipStream_t st, void *kt)
+void mm355_launch_backtrack(const DevParams &pr, const DevBatch &bt, DevAnchors &an, int *err, const int32_t *heavy_first, unsigned int *qctr, hipStream_t st, void *kt)
 {
 	if (bt.n_reads == 0) return;
+	(void)hipMemsetAsync(qctr, 0, 4, st);
 	KtScope ks(kt, KT_BACKTRACK, st);
-	hipLaunchKernelGGL(k_backtrack, dim3(bt.n_reads), dim3(WAVE), 0, st, pr, bt, an, err, heavy_first);
+	hipLaunchKernelGGL(k_backtrack, dim3(bt.n_reads < mm355_resident_blocks()? bt.n_reads : mm355_resident_blocks()), dim3(WAVE), 0, st, pr, bt, an, err, heavy_first, qctr);
 }

@@ -606,7 +606,7 @@ int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
 {
 	DevBatch b = dev_batch(c); DevAnchors a = dev_anchors(c);
 	HostBatch &hb = c->hb;
-	{ EvTimer t(c, &c->stats.ms_backtrack); mm355_launch_backtrack(pr, b, a, c->err.as<int>(), c->heavy.as<int32_t>(), c->st, c); }
+	{ EvTimer t(c, &c->stats.ms_backtrack); mm355_launch_backtrack(pr, b, a, c->err.as<int>(), c->heavy.as<int32_t>(), (unsigned int*)(c->counters.as<unsigned long long>() + 7), c->st, c); }
 	HIPCHK(hipGetLastError());
 	int64_t n = hb.n_reads;
 	hb.n_u.resize(n); hb.n_v.resize(n);
@@ -638,7 +638,7 @@ static int rmq_pass(mm355_ctx *c, const RmqParams &rp, const DevParams &pr, int 
 	unsigned long long *ctr = c->counters.as<unsigned long long>() + CTR_RMQ_OFF;
 	HIPCHK(hipMemsetAsync(ctr, 0, CTR_RMQ_WORDS * 8, c->st));
 	{ EvTimer t(c, &c->stats.ms_rmq);
-	  if (mm355_launch_rmq(rp, pr, b, a, c->rmq_list.as<int32_t>(), nl, c->rmq_flag.as<uint8_t>(), c->err.as<int>(), ctr, c->st, c)) return MM355_EHIP; }
+	  if (mm355_launch_rmq(rp, pr, b, a, c->rmq_list.as<int32_t>(), nl, c->rmq_flag.as<uint8_t>(), c->err.as<int>(), ctr, (unsigned int*)(c->counters.as<unsigned long long>() + 8), c->st, c)) return MM355_EHIP; }
 	// (the copies below land in a stack array and in pageable vectors: no return between the first of them and the synchronisation in
 	// check_err -- a failed call is remembered and reported behind it.  A pass that bails out leaves f / p / v / u2 / z partly rewritten: the
 	// host fallback re-chains from a[] alone, the only array a HOST / HOST_ALL read relies on)

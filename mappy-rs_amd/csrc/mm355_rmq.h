@@ -19,5 +19,5 @@ struct RmqParams {            // arguments of U:lchain.c::mg_lchain_rmq + the re
                                 // presets whose primary pass handed the read back, or the stage switched off: the host runs every mg_lchain_rmq call
 #ifdef __HIPCC__
 int mm355_launch_rmq(const RmqParams &rp, const DevParams &pr, const DevBatch &bt, DevAnchors &an, const int32_t *d_list, int n_list, uint8_t *d_flag,
-                     int *err, unsigned long long *ctr, hipStream_t st, void *kt = 0);
+                     int *err, unsigned long long *ctr, unsigned int *qctr, hipStream_t st, void *kt = 0);
 #endif

@@ -69,12 +69,11 @@ __device__ inline double rq_ldf64(const double *p)
 }
 
 // ---- stage 1 (long-join re-chain only): the rescue test of U:map.c::mm_map_frag and radix_sort_128x of the chained anchors
-__global__ __launch_bounds__(WAVE) void k_rmq_sort(RmqParams rp, DevBatch bt, DevAnchors an, const int32_t *list, uint8_t *flag, int *err)
+__device__ __forceinline__ void rmq_sort_read(const RmqParams &rp, const DevBatch &bt, const DevAnchors &an, const int32_t *list, uint8_t *flag, int *err, const unsigned int bid)
 {
-	MM355_LATENCY_KERNEL();
 	__shared__ SortLds L;
 	__shared__ mm128 stage[A_STAGE];
-	const int r = list[blockIdx.x], lane = threadIdx.x;
+	const int r = list[bid], lane = threadIdx.x;
 	const int64_t o = an.aoff[r];
 	const int n_u = an.n_u[r], n_v = an.n_v[r];
 	mm128 *a = an.a + o;
@@ -141,9 +140,8 @@ __device__ inline void rq_offer(RqBest &b, double pj, int j, bool tie_in)
 	if (b.bj < 0 || pj < b.best) { b.best = pj; b.bj = j; b.tie = tie_in; } else if (pj == b.best) b.tie = true;
 }
 
-__global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevAnchors an, const int32_t *list, uint8_t *flag, unsigned long long *ctr)
+__device__ __forceinline__ void rmq_dp_read(const RmqParams &rp, const DevBatch &bt, const DevAnchors &an, const int32_t *list, uint8_t *flag, unsigned long long *ctr, const unsigned int bid)
 {
-	MM355_LATENCY_KERNEL();
 	__shared__ long long cand[RQ_RING], sorted[RQ_RING];   // slow path of the inner walk
 	__shared__ uint32_t tw[RQ_TW];
 	__shared__ uint64_t rx[RQ_RING], ryy[RQ_RING];
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 	__shared__ int32_t wy[RQ_WRING];
 	__shared__ double bpri[RQ_NB];
 	__shared__ int32_t bmin[RQ_NB], bmax[RQ_NB], bjj[RQ_NB], btie[RQ_NB];
-	const int r = list[blockIdx.x], lane = threadIdx.x;
+	const int r = list[bid], lane = threadIdx.x;
 	if (flag[r] != MM355_RMQ_DONE) return;
 	const int64_t o = an.aoff[r];
 	const int n = rp.primary? (int)(an.aoff[r + 1] - o) : an.n_v[r];
@@ -398,26 +396,49 @@ __global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevA
 	}
 	KPROF(18);
 	if (bail) { if (lane == 0) flag[r] = MM355_RMQ_HOST; return; }
-	if (lane == 0 && ctr) atomicAdd(ctr + (blockIdx.x & 63), n_scan);
+	if (lane == 0 && ctr) atomicAdd(ctr + (bid & 63), n_scan);
 }
 
 // ---- stage 3: mg_chain_backtrack + compact_a of the re-chained reads (max_drop = the band width mg_lchain_rmq was given)
-__global__ __launch_bounds__(WAVE) void k_rmq_backtrack(RmqParams rp, DevParams pr, DevBatch bt, DevAnchors an, const int32_t *list, const uint8_t *flag, int *err)
+// the resident-grid forms (MM355_DEQUEUE, mm355_kernels.hip): a block takes the next listed read when it is free
+__device__ __forceinline__ unsigned int rmq_next_item(unsigned int *ctr)
+{
+	__syncthreads();
+	unsigned int v = 0;
+	if (threadIdx.x == 0) v = atomicAdd(ctr, 1u);
+	return (unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+}
+__global__ __launch_bounds__(WAVE) void k_rmq_sort(RmqParams rp, DevBatch bt, DevAnchors an, const int32_t *list, int n_list, uint8_t *flag, int *err, unsigned int *qctr)
+{
+	MM355_LATENCY_KERNEL();
+	for (unsigned int bid = rmq_next_item(qctr); bid < (unsigned int)n_list; bid = rmq_next_item(qctr)) rmq_sort_read(rp, bt, an, list, flag, err, bid);
+}
+__global__ __launch_bounds__(WAVE) void k_rmq_dp(RmqParams rp, DevBatch bt, DevAnchors an, const int32_t *list, int n_list, uint8_t *flag, unsigned long long *ctr, unsigned int *qctr)
+{
+	MM355_LATENCY_KERNEL();
+	for (unsigned int bid = rmq_next_item(qctr); bid < (unsigned int)n_list; bid = rmq_next_item(qctr)) rmq_dp_read(rp, bt, an, list, flag, ctr, bid);
+}
+__global__ __launch_bounds__(WAVE) void k_rmq_backtrack(RmqParams rp, DevParams pr, DevBatch bt, DevAnchors an, const int32_t *list, int n_list, const uint8_t *flag, int *err, unsigned int *qctr)
 {
 	MM355_LATENCY_KERNEL();
 	__shared__ BtLds S;
-	const int r = list[blockIdx.x];
-	if (flag[r] != MM355_RMQ_DONE) return;
-	const int n = rp.primary? (int)(an.aoff[r + 1] - an.aoff[r]) : an.n_v[r];
-	wave_backtrack_read(pr, bt, an, err, &S, r, n, rp.bw, 20);
+	for (unsigned int bid = rmq_next_item(qctr); bid < (unsigned int)n_list; bid = rmq_next_item(qctr)) {
+		const int r = list[bid];
+		if (flag[r] != MM355_RMQ_DONE) continue;
+		const int n = rp.primary? (int)(an.aoff[r + 1] - an.aoff[r]) : an.n_v[r];
+		wave_backtrack_read(pr, bt, an, err, &S, r, n, rp.bw, 20);
+	}
 }
 
 int mm355_launch_rmq(const RmqParams &rp, const DevParams &pr, const DevBatch &bt, DevAnchors &an, const int32_t *d_list, int n_list, uint8_t *d_flag,
-                     int *err, unsigned long long *ctr, hipStream_t st, void *kt)
+                     int *err, unsigned long long *ctr, unsigned int *qctr, hipStream_t st, void *kt)
 {
 	if (n_list <= 0) return 0;
-	if (!rp.primary) { KtScope ks(kt, KT_RMQ_SORT, st); hipLaunchKernelGGL(k_rmq_sort, dim3(n_list), dim3(WAVE), 0, st, rp, bt, an, d_list, d_flag, err); }
-	{ KtScope ks(kt, KT_RMQ_DP, st); hipLaunchKernelGGL(k_rmq_dp, dim3(n_list), dim3(WAVE), 0, st, rp, bt, an, d_list, d_flag, ctr); }
-	{ KtScope ks(kt, KT_RMQ_BT, st); hipLaunchKernelGGL(k_rmq_backtrack, dim3(n_list), dim3(WAVE), 0, st, rp, pr, bt, an, d_list, (const uint8_t*)d_flag, err); }
+	// qctr: three u32 work-list cursors (one per kernel); resident grids (k_rmq_dp holds 52 KB of LDS per wave: two per CU)
+	if (hipMemsetAsync(qctr, 0, 16, st) != hipSuccess) return -1;
+	const int rb = mm355_resident_blocks(), g2 = n_list < rb * 2 / 3? n_list : rb * 2 / 3, g3 = n_list < rb? n_list : rb;
+	if (!rp.primary) { KtScope ks(kt, KT_RMQ_SORT, st); hipLaunchKernelGGL(k_rmq_sort, dim3(g2), dim3(WAVE), 0, st, rp, bt, an, d_list, n_list, d_flag, err, qctr); }
+	{ KtScope ks(kt, KT_RMQ_DP, st); hipLaunchKernelGGL(k_rmq_dp, dim3(g2), dim3(WAVE), 0, st, rp, bt, an, d_list, n_list, d_flag, ctr, qctr + 1); }
+	{ KtScope ks(kt, KT_RMQ_BT, st); hipLaunchKernelGGL(k_rmq_backtrack, dim3(g3), dim3(WAVE), 0, st, rp, pr, bt, an, d_list, n_list, (const uint8_t*)d_flag, err, qctr + 2); }
 	return hipGetLastError() == hipSuccess? 0 : -1;
 }
