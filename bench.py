@@ -518,7 +518,8 @@ def main():
         # (the long-target classes are two launches, approx and exact alignments together: targets <= 4096 timed as group 8, longer ones as 10)
         gnames = ["k_ksw_reg<%d, %s>" % (np_, ex) for np_ in (1, 2, 4, 8) for ex in ("false", "true")] + \
                  ["k_ksw_extd2<512> (targets 1025..4096)", "-", "k_ksw_extd2<512> (targets > 4096)", "-", "-", "-", "k_ksw_row<2>", "k_ksw_row<4>", "k_ksw_row<8>", "k_ksw_rowl (targets 1025..8192)", "k_ksw_regw8 (exact, band <= 832, targets > 1024)",
-                  "k_ksw_band<1> (128 diagonals)", "k_ksw_band<2> (256 diagonals)", "k_ksw_band<4> (512 diagonals)", "second run of band problems (k_ksw_row / k_ksw_rowl)"]
+                  "k_ksw_band<1> (128 diagonals)", "k_ksw_band<2> (256 diagonals)", "k_ksw_band<4> (512 diagonals)", "k_ksw_band2 (64 diagonals, two problems per wave)",
+                  "second run of band problems (k_ksw_row / k_ksw_rowl)"]
         cells_g = np.array(agg["dp_cells_group"], dtype=np.float64); cells_g[8] = cells_g[8:10].sum(); cells_g[10] = cells_g[10:14].sum(); cells_g[9] = 0; cells_g[11:14] = 0
         nl_g = np.array(agg["n_launch_group"], dtype=np.float64); nl_g[8] = nl_g[8:10].max(); nl_g[10] = nl_g[10:14].max(); nl_g[9] = 0; nl_g[11:14] = 0
         n_lfront = float(n_str)                            # one launch of every front kernel per sub-batch
@@ -540,7 +541,7 @@ def main():
                               hbm_gbs=round(units * bytes_per_unit / (ms * 1e-3) / 1e9, 3) if ms > 0 else 0.0,
                               hbm_frac=round(units * bytes_per_unit / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else 0.0, formula=how)
 
-        for i in range(23):   # every extension kernel that ran, each timed alone on its own stream
+        for i in range(24):   # every extension kernel that ran, each timed alone on its own stream
             if nl_g[i] > 0 and agg["ms_dp_group"][i] > 0:
                 add_valu(gnames[i], cells_g[i] / K, agg["ms_dp_group"][i] / K, max(1.0, nl_g[i] / K), DP_LANE_OPS_PER_CELL, "Gcells/s",
                          "cell updates of the two-piece affine recurrence per second against the VALU issue peak (%.3g lane-ops/s / %g lane-ops per cell, "
@@ -563,7 +564,10 @@ def main():
             (4, "k_seed_expand", expand_bytes, "8*n_a_multi + 16*n_a (pos[] entry read + anchor written)"),
             (5, "k_cull", 16 * n_a + 8 * n_a + 8 * n_keep, "16*n_a read + 8*n_a position words + 8*n_kept survivors written"),
             (6, "k_asort", 16 * n_keep + 32 * n_keep, "8*n_kept words in + out, 16*n_kept anchors gathered + written"),
-            (7, "radix_sort_128x emulation (k_sort_level_mw, k_sort_tasks, k_tie_copy, k_tie_emit)", 32 * n_lit * 2, "2 passes of 2*16 B over the anchors of the reads with equal keys"),
+            (7, "k_sort_level_mw<1024> (radix_sort_128x emulation, buckets > 16384)", 32 * n_lit * 2, "2 levels of 2*16 B over the anchors of the reads with equal keys"),
+            (20, "k_sort_level_mw<256> (radix_sort_128x emulation, buckets > 2048)", 32 * n_lit, "2*16 B over the anchors of the reads with equal keys"),
+            (21, "k_sort_tasks (radix_sort_128x emulation, one wave per bucket)", 32 * n_lit, "2*16 B over the anchors of the reads with equal keys"),
+            (22, "k_tie_copy + k_asort + k_tie_tcnt (plain sort of the reads with equal keys)", 56 * n_lit, "(16 + 16 + 8 + 8 + 8) B per anchor of those reads"),
             (8, "k_chain_segments", 16 * n_keep, "16*n_kept"),
             (11, "k_backtrack", 28 * n_keep, "(16 + 12)*n_kept: anchors, f / p / v"),
             (12, "k_rmq_sort", 32 * n_vr, "2*16*n_v of the re-chained reads"),
@@ -591,7 +595,7 @@ def main():
         # RULE: `roofline` = the kernel with the largest summed duration among ALL kernels of the path, each timed alone with HIP events on the
         # stream it is launched on: the extension kernels (ms_dp_group) and every other kernel (ms_kernel).  No exclusion list; the rocprofv3
         # kernel statistics of the same command (profiles/) rank the same kernels by the same quantity.
-        ms_all = {gnames[i]: float(agg["ms_dp_group"][i]) / K for i in range(23) if nl_g[i] > 0 and agg["ms_dp_group"][i] > 0}
+        ms_all = {gnames[i]: float(agg["ms_dp_group"][i]) / K for i in range(24) if nl_g[i] > 0 and agg["ms_dp_group"][i] > 0}
         ms_all.update({name: float(mk[slot]) for slot, name, _b, _h in front if mk[slot] > 0})
         ms_all.update({n_: float(mk[sl]) for n_, sl in (("k_chain_big", 9), ("k_chain_small", 10)) if mk[sl] > 0})
         dom = max(ms_all, key=ms_all.get)
@@ -649,8 +653,8 @@ def main():
                                   "alone with HIP events on the stream it is launched on; kernel_ms_per_step_all) -- no exclusion list"),
             "kernel_ms_per_step_all": {k: round(v, 3) for k, v in sorted(ms_all.items(), key=lambda kv: -kv[1])},
             "roofline_seed_lookup": rl, "roofline_all": roof, "latency_chains": latency_chains, "kernel_ms_per_step": {k: round(v, 3) for k, v in kern_ms.items()},
-            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(23) if nl_g[i] > 0},
-            "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(23) if nl_g[i] > 0},
+            "dp_kernel_ms_per_step": {gnames[i]: round(float(agg["ms_dp_group"][i]) / K, 3) for i in range(24) if nl_g[i] > 0},
+            "dp_cells_per_step": {gnames[i]: int(cells_g[i] / K) for i in range(24) if nl_g[i] > 0},
             "counters_per_step": dict(n_mz=int(n_mz), n_hit=int(n_hit), n_a=int(n_a), n_a_kept_by_cull=int(n_keep), n_a_sorted_literally=int(n_lit), n_a_multi=int(n_am), chain_pairs=int(pairs), dp_cells=int(cells),
                                       n_dp_jobs=int(agg["n_dp_jobs"] / K), n_dp_band=int(agg["n_dp_band"] / K), n_dp_band_redo=int(agg["n_dp_band_redo"] / K), n_rounds_split=int(agg["n_rounds_split"]), n_sort_tie_reads=int(agg["n_sort_tie_reads"] / K),
                                       n_rmq_reads=int(agg["n_rmq_reads"] / K), n_rmq_host_fallback=int(agg["n_rmq_host"] / K),

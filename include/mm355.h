@@ -151,7 +151,8 @@ typedef struct {
 	/* per extension kernel of a launch group, timed with HIP events on the stream it is launched on; group = 2 * size class + exact,
 	 * size classes: targets <= 128, 256, 512, 1024 (k_ksw_reg<1|2|4|8, exact>), <= 4096, <= 12288, larger (k_ksw_extd2<512>; one launch
 	 * for groups 8-9, timed as 8, and one for 10-13, timed as 10); 14 / 15 / 16 = k_ksw_row<2|4|8> (full-band approximate gap fills), 17 k_ksw_rowl,
-	 * 18 k_ksw_regw8, 19 / 20 / 21 = k_ksw_band<1|2|4> (the same fills on a band of 128 / 256 / 512 diagonals), 22 = second run of band problems */
+	 * 18 k_ksw_regw8, 19 / 20 / 21 = k_ksw_band<1|2|4> (the same fills on a band of 128 / 256 / 512 diagonals), 22 = k_ksw_band2 (64 diagonals, two problems per wave),
+	 * 23 = second run of band problems */
 	double ms_dp_group[24];
 	int64_t dp_cells_group[24], n_launch_group[24];
 	int64_t n_ext_rounds;                        /* extension rounds of the last call (the reference has no bound on them) */
@@ -168,7 +169,8 @@ typedef struct {
 	 * ms_dp_group).  Slots: 0 sketch, 1 mz_flt, 2 seed lookup (tile list + probes), 3 seed select, 4 seed expand, 5 anchor cull, 6 anchor
 	 * sort (LDS), 7 literal radix_sort_128x emulation (reads with equal keys), 8 chain segments, 9 chain (long segments, a wave each),
 	 * 10 chain (short segments, a lane each), 11 chain backtrack, 12 / 13 / 14 mg_lchain_rmq sort / recurrence / backtrack, 15 extension
-	 * gather, 16 extension backtrack (CIGAR), 17 mm_update_extra + cs walk, 18 read codes, 19 chain / anchor pack */
+	 * gather, 16 extension backtrack (CIGAR), 17 mm_update_extra + cs walk, 18 read codes, 19 chain / anchor pack; the literal emulation by kernel:
+	 * 7 k_sort_level_mw<1024> (all its levels), 20 k_sort_level_mw<256>, 21 k_sort_tasks, 22 its plain sort / copy / tcnt of the tie reads */
 	double ms_kernel[24];
 	int64_t chain_pairs_big;                     /* k_chain_big's share of chain_pairs */
 	int64_t n_a_literal;                         /* anchors (all of them, culled ones included) of the reads that were sorted literally */

@@ -26,14 +26,14 @@
 #include "mm355_pipeline.h"
 #include "mm355_wave.h"
 
-#define CS_WPL   12288                 // words per bitmap level: 393216 bins, 3 x 48 KB of LDS
+#define CS_WPL_MAX 12288               // most words per bitmap level: 393216 bins, 3 x 48 KB of LDS (the kernel takes the number as an argument)
 #define CS_GUARD 3                     // bins a run is followed to either side of an anchor's own bin
-#define CS_BPP   (CS_WPL * 32 - 2 * CS_GUARD)   // bins decided per pass (the table also holds the guard bins of both neighbours)
-#define CS_NT    1024
+
 
 struct CullPar {
 	uint64_t tot_len;                  // bases of all contigs; position word = strand * tot_len + seq_off[rid] + rpos < 2 * tot_len
 	int32_t ib, sh, n_pass, T;         // ib: bits of (index in generation order << 1 | kept) below the position
+	int32_t wpl, bpp;                  // words per bitmap level (LDS: 3 * 4 * wpl bytes), bins decided per pass = 32 * wpl - 2 * CS_GUARD
 };
 
 __device__ __forceinline__ uint64_t cs_pos(const DevIndex &ix, uint64_t x, uint64_t tot_len)
@@ -42,7 +42,7 @@ __device__ __forceinline__ uint64_t cs_pos(const DevIndex &ix, uint64_t x, uint6
 	return (x >> 63) * tot_len + ix.seq_off[rid] + (uint32_t)x;
 }
 
-__device__ __forceinline__ void cs_add(uint32_t *bm, uint32_t rel)
+__device__ __forceinline__ void cs_add(uint32_t *bm, uint32_t rel, const uint32_t CS_WPL)
 {
 	const uint32_t w = rel >> 5, m = 1u << (rel & 31);
 	if (bm[2 * CS_WPL + w] & m) return;                       // (bits only ever get set: a stale read costs an atomic, not correctness)
@@ -50,7 +50,7 @@ __device__ __forceinline__ void cs_add(uint32_t *bm, uint32_t rel)
 	if (!(atomicOr(&bm[CS_WPL + w], m) & m)) return;
 	atomicOr(&bm[2 * CS_WPL + w], m);
 }
-__device__ __forceinline__ uint32_t cs_cnt(const uint32_t *bm, uint32_t rel)   // 0, 1, 2, 3 (= three or more)
+__device__ __forceinline__ uint32_t cs_cnt(const uint32_t *bm, uint32_t rel, const uint32_t CS_WPL)   // 0, 1, 2, 3 (= three or more)
 {
 	const uint32_t w = rel >> 5, b = rel & 31;
 	uint32_t c = bm[w] >> b & 1u;
@@ -59,14 +59,14 @@ __device__ __forceinline__ uint32_t cs_cnt(const uint32_t *bm, uint32_t rel)   /
 }
 // does the run of non-empty bins around table entry `rel` hold at least T anchors?  Conservative: "yes" whenever a count is saturated
 // or the walk stops at the guard distance without having met an empty bin.
-__device__ __forceinline__ bool cs_keep(const uint32_t *bm, uint32_t rel, uint32_t T)
+__device__ __forceinline__ bool cs_keep(const uint32_t *bm, uint32_t rel, uint32_t T, const uint32_t CS_WPL)
 {
-	uint32_t tot = cs_cnt(bm, rel);
+	uint32_t tot = cs_cnt(bm, rel, CS_WPL);
 	if (tot >= 3 || tot >= T) return true;
 #pragma unroll
 	for (int dir = -1; dir <= 1; dir += 2)
 		for (int s = 1; s <= CS_GUARD; ++s) {
-			const uint32_t c = cs_cnt(bm, (uint32_t)((int)rel + dir * s));
+			const uint32_t c = cs_cnt(bm, (uint32_t)((int)rel + dir * s), CS_WPL);
 			if (c == 0) break;
 			tot += c;
 			if (c == 3 || tot >= T || s == CS_GUARD) return true;
@@ -76,14 +76,15 @@ __device__ __forceinline__ bool cs_keep(const uint32_t *bm, uint32_t rel, uint32
 
 // One block per read.  keys[o + i] = position word << ib | i << 1 | kept for every anchor (generation order); surv[o ..] = the words of the
 // anchors that are kept, in no particular order; n_keep[r] = how many.
-__global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff, const mm128 *a, uint64_t *keys, uint64_t *surv, int32_t *n_keep, int n_reads, CullPar cp, const int32_t *heavy_first)
+__global__ __launch_bounds__(1024) void k_cull(DevIndex ix, const int64_t *aoff, const mm128 *a, uint64_t *keys, uint64_t *surv, int32_t *n_keep, int n_reads, CullPar cp, const int32_t *heavy_first)
 {
 	extern __shared__ uint32_t bm[];   // 3 * CS_WPL
 	__shared__ uint32_t s_cur;
 	if ((int)blockIdx.x >= n_reads) return;
 	const int r = heavy_first[blockIdx.x];   // the reads with the most anchors first: the longest block starts at t = 0
 	const int64_t o = aoff[r];
-	const uint32_t n = (uint32_t)(aoff[r + 1] - o), tid = threadIdx.x, lane = tid & 63;
+	const uint32_t n = (uint32_t)(aoff[r + 1] - o), tid = threadIdx.x, lane = tid & 63, CS_NT = blockDim.x, CS_WPL = (uint32_t)cp.wpl;
+	const int64_t CS_BPP = cp.bpp;
 	if (tid == 0) s_cur = 0;
 	if (n == 0) { if (tid == 0) n_keep[r] = 0; return; }
 	for (int p = 0; p < cp.n_pass; ++p) {
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff
 			if (p == 0) { k = cs_pos(ix, a[o + i].x, cp.tot_len); keys[o + i] = k << cp.ib | (uint64_t)i << 1; }
 			else k = keys[o + i] >> cp.ib;
 			const int64_t rel = (int64_t)(k >> cp.sh) - lo;
-			if (rel >= 0 && rel < CS_BPP + 2 * CS_GUARD) cs_add(bm, (uint32_t)rel);
+			if (rel >= 0 && rel < CS_BPP + 2 * CS_GUARD) cs_add(bm, (uint32_t)rel, CS_WPL);
 		}
 		__syncthreads();
 		for (uint32_t base = 0; base < n; base += CS_NT) {
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(CS_NT) void k_cull(DevIndex ix, const int64_t *aoff
 			if (i < n) {
 				kw = keys[o + i] | 1ULL;                                // (written by this very thread in pass 0)
 				const int64_t rel = (int64_t)((kw >> cp.ib) >> cp.sh) - lo;
-				if (rel >= CS_GUARD && rel < CS_BPP + CS_GUARD) keep = cs_keep(bm, (uint32_t)rel, (uint32_t)cp.T);
+				if (rel >= CS_GUARD && rel < CS_BPP + CS_GUARD) keep = cs_keep(bm, (uint32_t)rel, (uint32_t)cp.T, CS_WPL);
 				if (keep) keys[o + i] = kw;                             // the decision in bit 0, for the reads that are sorted literally
 			}
 			const unsigned long long mk = __ballot(keep);
@@ -336,11 +337,19 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	if (D < 1) D = 1;
 	cp.T = T;
 	const bool do_cull = cull && T >= 2;
+	// MM355_CULL_WPL / _NT / _SH (experiments): words per bitmap level, threads per block, least bin shift
+	static const int env_wpl = [] { const char *e = getenv("MM355_CULL_WPL"); return e? atoi(e) : 0; }();
+	static const int env_nt = [] { const char *e = getenv("MM355_CULL_NT"); return e? atoi(e) : 0; }();
+	static const int env_sh = [] { const char *e = getenv("MM355_CULL_SH"); return e? atoi(e) : 0; }();
+	cp.wpl = env_wpl >= 256 && env_wpl <= CS_WPL_MAX? (env_wpl & ~3) : CS_WPL_MAX;
+	cp.bpp = cp.wpl * 32 - 2 * CS_GUARD;
+	const int cull_nt = env_nt == 256 || env_nt == 512? env_nt : 1024;
 	if (do_cull) {
 		cp.sh = 0; while ((1LL << cp.sh) < D) ++cp.sh;
+		if (env_sh > cp.sh) cp.sh = env_sh;
 		for (;; ++cp.sh) {   // at most four passes over a read's anchors: wider bins beyond that
 			const uint64_t bins = ((2 * cp.tot_len) >> cp.sh) + 1;
-			cp.n_pass = (int)((bins + CS_BPP - 1) / CS_BPP);
+			cp.n_pass = (int)((bins + cp.bpp - 1) / cp.bpp);
 			if (cp.n_pass <= 4) break;
 		}
 	}
@@ -352,9 +361,9 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	int32_t *d_nk = c->n_keep.as<int32_t>();
 	const double t0 = mm355_now_ms();
 	if (do_cull) {
-		if (hipFuncSetAttribute((const void*)k_cull, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CS_WPL * 4) != hipSuccess) return MM355_EHIP;
+		if (hipFuncSetAttribute((const void*)k_cull, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CS_WPL_MAX * 4) != hipSuccess) return MM355_EHIP;
 		KtScope ks(c, KT_CULL, c->st);
-		hipLaunchKernelGGL(k_cull, dim3((unsigned)n_reads), dim3(CS_NT), 3 * CS_WPL * 4, c->st, c->dix, aoff, c->a.as<mm128>(), keys, surv, d_nk, n_reads, cp, c->heavy.as<int32_t>());
+		hipLaunchKernelGGL(k_cull, dim3((unsigned)n_reads), dim3(cull_nt), 3 * cp.wpl * 4, c->st, c->dix, aoff, c->a.as<mm128>(), keys, surv, d_nk, n_reads, cp, c->heavy.as<int32_t>());
 	} else hipLaunchKernelGGL(k_keys_all, dim3((unsigned)n_reads), dim3(256), 0, c->st, c->dix, aoff, c->a.as<mm128>(), surv, d_nk, n_reads, cp);
 	// pinned staging: [n_keep: nr x i32][aoff2: (nr + 1) x i64][flags: nr x u8][lists: nr x i32]
 	int32_t *h_nk = (int32_t*)c->h_cs.p;
@@ -425,6 +434,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		int64_t *d_toff = c->tie_list.as<int64_t>(); int32_t *d_tl = (int32_t*)(d_toff + n_tie + 1);
 		HIPCHK(hipMemcpyAsync(d_toff, h_toff, ((size_t)n_tie + 1) * 8, hipMemcpyHostToDevice, c->st));
 		HIPCHK(hipMemcpyAsync(d_tl, h_tl, (size_t)n_tie * 4, hipMemcpyHostToDevice, c->st));
+		mm355_kt(c, KT_TIE_AUX, 0, c->st);
 		hipLaunchKernelGGL(k_tie_copy, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, c->a.as<mm128>(), keys, c->tie_a.as<mm128>(), do_cull? 0 : 1);
 		// the plain sort of the WHOLE array of these reads (with the cull off the survivors are the whole array, sorted already): where its equal
 		// positions are, so that the emulation only descends into the buckets that hold some (MM355_TIE_SKIP=0: it sorts everything)
@@ -433,6 +443,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		if (do_cull) hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_tie), dim3(1024), CS_BIG_CAP * 8, c->st, d_tl, n_tie, aoff, d_off2, (const int32_t*)0, c->a.as<mm128>(), keys,
 		                                (mm128*)0, (uint8_t*)0, cp.ib);
 		if (tie_skip) hipLaunchKernelGGL(k_tie_tcnt, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, full_sorted, c->tie_tcnt.as<int32_t>(), cp.ib);
+		mm355_kt(c, KT_TIE_AUX, 1, c->st);
 		DevAnchors at; memset(&at, 0, sizeof(at));
 		at.aoff = d_toff; at.a = c->tie_a.as<mm128>(); at.b = c->tie_b.as<mm128>(); at.f = c->tie_f.as<int32_t>(); at.p = c->tie_p.as<int32_t>(); at.t8 = c->tie_t8.as<uint8_t>(); at.tcnt = tie_skip? c->tie_tcnt.as<int32_t>() : 0;
 		const size_t task_cap = (size_t)tt / 64 + (size_t)n_tie + 1024;

@@ -88,7 +88,7 @@ struct DevAnchors {
 // between them) on the stream it is launched on.  kt = the context, or null for "not timed".  bench.py's `roofline` is the entry with the
 // largest summed duration among these and the extension kernels' own timers (ms_dp_group) -- no exclusion list.
 enum { KT_SKETCH = 0, KT_MZFLT, KT_LOOKUP, KT_SELECT, KT_EXPAND, KT_CULL, KT_ASORT, KT_LITERAL, KT_CHAIN_SEG, KT_CHAIN_BIG, KT_CHAIN_SMALL, KT_BACKTRACK,
-       KT_RMQ_SORT, KT_RMQ_DP, KT_RMQ_BT, KT_DP_GATHER, KT_DP_BACKTRACK, KT_EXTRA, KT_CODES, KT_PACK, KT_N };
+       KT_RMQ_SORT, KT_RMQ_DP, KT_RMQ_BT, KT_DP_GATHER, KT_DP_BACKTRACK, KT_EXTRA, KT_CODES, KT_PACK, KT_LIT_MED, KT_LIT_TASKS, KT_TIE_AUX, KT_N };
 #ifdef __HIPCC__
 void mm355_kt(void *kt, int slot, int end, hipStream_t st);
 struct KtScope { void *kt; int slot; hipStream_t st; KtScope(void *k, int s, hipStream_t t) : kt(k), slot(s), st(t) { if (kt) mm355_kt(kt, slot, 0, st); } ~KtScope() { if (kt) mm355_kt(kt, slot, 1, st); } };

@@ -454,7 +454,7 @@ struct DpClass { int cap, kind, np; };   // kind 0: k_ksw_reg, 1: k_ksw_extd2<64
 static const DpClass DP_CLASSES[] = { {128, 0, 1}, {256, 0, 2}, {512, 0, 4}, {1024, 0, 8}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 static const DpClass DP_CLASSES_LEGACY[] = { {256, 1, 0}, {512, 1, 0}, {1024, 1, 0}, {1024, 1, 0}, {4096, 2, 0}, {12288, 2, 0}, {0, 2, 0} };
 #define DP_N_CLASS 7
-#define DP_N_GROUP 22                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills), 17 = k_ksw_rowl (the same, targets 1025..8192)
+#define DP_N_GROUP 23                    // group = class * 2 + exact for the seven classes; 14 / 15 / 16 = k_ksw_row<2> / <4> / <8> (full-band approximate fills), 17 = k_ksw_rowl (the same, targets 1025..8192)
 #define DP_G_ROW2 14
 #define DP_G_ROW4 15
 #define DP_G_ROW8 16
@@ -462,7 +462,8 @@ static const DpClass DP_CLASSES_LEGACY[] = { {256, 1, 0}, {512, 1, 0}, {1024, 1,
 #define DP_G_BAND1 19                   // k_ksw_band<1 | 2 | 4>: the row sweep on a band of 128 / 256 / 512 diagonals with a sufficiency proof (mm355_dpband.h)
 #define DP_G_BAND2 20
 #define DP_G_BAND4 21
-#define DP_G_REDO 22                    // (not a class: the second, full-matrix run of band problems whose proof failed -- timer / counter slot)
+#define DP_G_BANDH 22                   // k_ksw_band2: two problems per wave, 64 diagonals each
+#define DP_G_REDO 23                    // (not a class: the second, full-matrix run of band problems whose proof failed -- timer / counter slot)
 #define DP_G_REGW 18                    // k_ksw_regw: exact, narrow band (w <= DP_WIN_MAX_W), targets > 1024 -- the register kernel with a moving window
 
 // value range of the row sweep on a qlen x tlen problem (int16 halves; ROW_NEG must stay below every real value, differences of two real
@@ -515,7 +516,7 @@ static int row_class(const DpConst &dc, int qlen, int tlen, int w_in, int flag)
 __global__ void k_dp_patch(DpJobDev *jobs, const int32_t *ids, const DpJobDev *nj, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) jobs[ids[i]] = nj[i]; }
 
 // ---- band kernels (mm355_dpband.h): which problems take them, with which band
-struct BandPlan { int nsb, dlo, lmin; };   // nsb = 0: the full-matrix kernels
+struct BandPlan { int nsb, dlo, lmin, bw; };   // nsb = 0: the full-matrix kernels; bw = 64 (two problems per wave, nsb = 1), 128, 256, 512
 static int band_ubound(const DpConst &dc, int qlen, int tlen, int d)   // no path through diagonal d (outside [min(0, D0), max(0, D0)]) scores more
 {
 	const int D0 = tlen - qlen, g1 = d < 0? -d : d, g2 = D0 - d < 0? d - D0 : D0 - d;
@@ -526,7 +527,7 @@ static int band_ubound(const DpConst &dc, int qlen, int tlen, int d)   // no pat
 }
 static BandPlan band_plan(const DpConst &dc, int qlen, int tlen, int full_sets)
 {
-	BandPlan bp; bp.nsb = 0; bp.dlo = 0; bp.lmin = 0;
+	BandPlan bp; bp.nsb = 0; bp.dlo = 0; bp.lmin = 0; bp.bw = 0;
 	static const bool use_band = [] { const char *e = getenv("MM355_DP_BAND"); return !(e && atoi(e) == 0); }();        // MM355_DP_BAND=0: full-matrix kernels only
 	static const double thr = [] { const char *e = getenv("MM355_DP_BAND_THR"); return e? atof(e) : 0.65; }();          // a band is tried when a score of thr x (all matches) would prove it
 	static const int force = [] { const char *e = getenv("MM355_DP_BAND_FORCE"); return e? atoi(e) : 0; }();            // test hook: this many register sets whenever the geometry allows
@@ -536,10 +537,11 @@ static BandPlan band_plan(const DpConst &dc, int qlen, int tlen, int full_sets)
 	auto cost = [&](int g) { const int c1 = dc.q + g * dc.e, c2 = dc.q2 + g * dc.e2; return c1 < c2? c1 : c2; };
 	int a = dc.sc_mch > 0? dc.sc_mch : 0;
 	const int n = qlen < tlen? qlen : tlen;
-	for (int nsb = 1; nsb <= 4; nsb *= 2) {
-		const int W = 128 * nsb;
-		if (force && nsb != force) continue;
-		if (nsb >= full_sets && !force) break;                          // no narrower than the full matrix
+	static const double thr_half = [] { const char *e = getenv("MM355_DP_BAND_THR_HALF"); return e? atof(e) : 0.72; }();   // ... for the 64-diagonal band (0 = never)
+	for (int nsb = 0; nsb <= 4; nsb = nsb? nsb * 2 : 1) {   // nsb = 0: half a register set (64 diagonals, k_ksw_band2)
+		const int W = nsb? 128 * nsb : 64;
+		if (force && (nsb? nsb : 64) != force) continue;
+		if (nsb && nsb >= full_sets && !force) break;                   // no narrower than the full matrix
 		if (W < span + 2 * BAND_MIN_MARGIN) continue;
 		// int16 range: real values stay above -(cost(qlen + 1) + cost(tlen + 1)) - ..., the cells left of the border column start at ROW_NEG and
 		// drift by at most a per row for W rows; prefix terms G + d e with |d| <= W + span
@@ -547,8 +549,8 @@ static BandPlan band_plan(const DpConst &dc, int qlen, int tlen, int full_sets)
 		const int dlo = lo - (W - span) / 2;
 		int u1 = band_ubound(dc, qlen, tlen, dlo - 1), u2 = band_ubound(dc, qlen, tlen, dlo + W);
 		const int lmin = (u1 > u2? u1 : u2) + 1;
-		if (!force && (double)lmin > thr * (double)(a * n)) continue;   // not worth a try: only a nearly perfect alignment would prove this band
-		bp.nsb = nsb; bp.dlo = dlo; bp.lmin = lmin;
+		if (!force && (double)lmin > (nsb? thr : thr_half) * (double)(a * n)) continue;   // not worth a try: only a nearly perfect alignment would prove this band
+		bp.nsb = nsb? nsb : 1; bp.dlo = dlo; bp.lmin = lmin; bp.bw = W;
 		return bp;
 	}
 	return bp;
@@ -570,7 +572,7 @@ size_t mm355_dp_matrix_bytes(const mm355_mapopt_t *mo, const DpConst &dc, int ql
 	const bool row = rk == 1, rowl = rk == 2;
 	if (row || rowl) {
 		const BandPlan bp = band_plan(dc, qlen, tlen, rowl? 64 : tlen <= 256? 2 : tlen <= 512? 4 : 8);
-		if (bp.nsb) return band_matrix_bytes(qlen, 128 * bp.nsb) + 64;
+		if (bp.nsb) return band_matrix_bytes(qlen, bp.bw) + 64;
 		return row_matrix_bytes(qlen, T) + 64;   // (+ the alignment of its first tile)
 	}
 	return ((size_t)(qlen + tlen - 1) * n_col_ + 1) * 16;
@@ -614,9 +616,9 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 				p_tot = (p_tot + 63) & ~(size_t)63;            // tiles are 64-byte lines
 				j.p_off = (int64_t)p_tot;
 				if (bp.nsb) {                                  // a band of 128 * nsb diagonals with a sufficiency proof (mm355_dpband.h)
-					j.pad = 2; j.dlo = bp.dlo; j.lmin = bp.lmin; j.bw = 128 * bp.nsb;
-					p_tot += band_matrix_bytes(j.qlen, 128 * bp.nsb);
-					g = bp.nsb == 1? DP_G_BAND1 : bp.nsb == 2? DP_G_BAND2 : DP_G_BAND4;
+					j.pad = 2; j.dlo = bp.dlo; j.lmin = bp.lmin; j.bw = bp.bw;
+					p_tot += band_matrix_bytes(j.qlen, bp.bw);
+					g = bp.bw == 64? DP_G_BANDH : bp.nsb == 1? DP_G_BAND1 : bp.nsb == 2? DP_G_BAND2 : DP_G_BAND4;
 				} else {
 					j.pad = 1;
 					p_tot += row_matrix_bytes(j.qlen, T);
@@ -647,7 +649,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	}
 	if (c->h_ids.ensure((2 * n + 64) * 4)) return MM355_ENOMEM;
 	int32_t *h_ids = (int32_t*)c->h_ids.p, *h_ord = h_ids + n + 8;
-	size_t grp_off[DP_N_GROUP + 1];
+	size_t grp_off[DP_N_GROUP + 1], n_half_right = 0;
 	{
 		size_t acc = 0;
 		for (int g = 0; g < DP_N_GROUP; ++g) { grp_off[g] = acc; acc += n_grp[g]; }
@@ -663,6 +665,8 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 		// launch lists in the same order (most anti-diagonals first): a wave is one alignment, so the longest sweeps of a class start at
 		// t = 0 and the short ones fill in behind them instead of the launch ending on a late-started long one
 		for (size_t k = 0; k < n; ++k) { const int32_t i = h_ord[k]; h_ids[cur[grp[i]]++] = i; }
+		// k_ksw_band2 pairs neighbours of its list and both share KSW_EZ_RIGHT: the list is cut in two by that flag (order kept)
+		n_half_right = (size_t)(std::stable_partition(h_ids + grp_off[DP_G_BANDH], h_ids + grp_off[DP_G_BANDH] + n_grp[DP_G_BANDH], [&](int32_t i) { return (jobs[i].flag & EZ_RIGHT) != 0; }) - (h_ids + grp_off[DP_G_BANDH]));
 	}
 	if (c->dp_jobs.ensure(n * sizeof(DpJobDev)) || c->dp_res.ensure(n * sizeof(mm355_dpres_t)) || c->dp_bt.ensure(p_tot + 64, 4) ||
 	    c->dp_work.ensure((off_tot + 16) * 4 + (2 * n + 32) * 4) || c->dp_cig.ensure((cig_tot + 16) * 4) || c->dp_dense.ensure((cig_tot + 16) * 4) ||
@@ -693,7 +697,7 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 	HIPCHK(hipMemsetAsync(d_cells, 0, 8, c->st));
 	HIPCHK(hipMemsetAsync(d_gcells, 0, CTR_GCELLS_WORDS * 8, c->st));
 	// band kernels: [0] = problems whose proof failed, then their ids; behind it the launch lists of their second run
-	const size_t n_band = n_grp[DP_G_BAND1] + n_grp[DP_G_BAND2] + n_grp[DP_G_BAND4];
+	const size_t n_band = n_grp[DP_G_BAND1] + n_grp[DP_G_BAND2] + n_grp[DP_G_BAND4] + n_grp[DP_G_BANDH];
 	if (c->dp_fail.ensure((2 * n_band + 64) * 4 + (n_band + 8) * sizeof(DpJobDev)) || c->h_fail.ensure((2 * n_band + 64) * 4 + (n_band + 8) * sizeof(DpJobDev))) return MM355_ENOMEM;
 	int32_t *d_fail = c->dp_fail.as<int32_t>();
 	if (n_band) HIPCHK(hipMemsetAsync(d_fail, 0, 4, c->st));
@@ -784,9 +788,14 @@ int mm355_dp_run(mm355_ctx *c, const mm355_mapopt_t *mo, DpJobDev *jobs, size_t 
 			if (n_grp[g] == 0 || g == DP_G_ROWL || g == DP_G_REGW) continue;
 			if (g >= DP_G_ROW2) {   // the row sweep of the full-band approximate fills: the wide throughput grids of a round
 				hipStream_t gst; int rc2;
-				if ((rc2 = group_stream(g == DP_G_ROW2 || g == DP_G_BAND1? 0 : g == DP_G_ROW4 || g == DP_G_BAND2? 3 : 2, &gst))) return rc2;
+				if ((rc2 = group_stream(g == DP_G_ROW2 || g == DP_G_BAND1 || g == DP_G_BANDH? 0 : g == DP_G_ROW4 || g == DP_G_BAND2? 3 : 2, &gst))) return rc2;
 				if ((rc2 = group_begin(g, gst))) return rc2;
-				if (g == DP_G_BAND1) hipLaunchKernelGGL(k_ksw_band<1>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
+				if (g == DP_G_BANDH) {
+					const size_t nr = n_half_right, nl = n_grp[g] - nr;
+					if (nr) hipLaunchKernelGGL(k_ksw_band2, dim3((unsigned)((nr + 1) / 2)), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)nr, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
+					if (nl) hipLaunchKernelGGL(k_ksw_band2, dim3((unsigned)((nl + 1) / 2)), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g] + nr, (int)nl, d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
+				}
+				else if (g == DP_G_BAND1) hipLaunchKernelGGL(k_ksw_band<1>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
 				else if (g == DP_G_BAND2) hipLaunchKernelGGL(k_ksw_band<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
 				else if (g == DP_G_BAND4) hipLaunchKernelGGL(k_ksw_band<4>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g, d_fail);
 				else if (g == DP_G_ROW2) hipLaunchKernelGGL(k_ksw_row<2>, dim3((unsigned)n_grp[g]), dim3(64), 0, gst, dc, dj, d_ids + grp_off[g], (int)n_grp[g], d_q, d_t, c->dp_bt.as<uint8_t>(), dres, d_gcells + DP_CTR_SPREAD * g);

@@ -180,3 +180,154 @@ __global__ __launch_bounds__(64) void k_ksw_band(DpConst dc, const DpJobDev *job
 		atomicAdd(cells_ctr + (blockIdx.x & (DP_CTR_SPREAD - 1)), (unsigned long long)jb.qlen * (unsigned long long)jb.tlen);
 	}
 }
+
+// ------------------------------------------------------------------ two problems per wave: bands of 64 diagonals
+// The typical gap fill of an ONT read is ~210 x 210 with |tlen - qlen| of a few bases: a band of 64 diagonals proves itself there
+// (lmin = a n - 4 B - 2 q2 - ... with B ~ 27: a score of 0.63 of all-matches suffices at n = 212).  Lanes 0..31 own problem A, lanes 32..63
+// problem B (neighbours of the launch list: similar lengths); every per-problem quantity is a per-lane value, the row loop runs to the longer
+// query, and the three things that cross lanes -- the one-diagonal shifts, the prefix scan, the row's query / incoming target base -- stop at
+// the half boundary (a select on lane 31 / 32, one DPP step less in the scan, two v_readlane + a select).  Half the instructions per cell of
+// k_ksw_band<1>, half the direction bytes.
+__device__ __forceinline__ int32_t half_incl_scan_max32(int32_t x)   // inclusive prefix maximum over the lanes of the own half (0..31 / 32..63)
+{
+	int32_t y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x111, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x112, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x114, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x118, 0xf, 0xf, false); x = x > y? x : y;
+	y = __builtin_amdgcn_update_dpp(INT32_MIN, x, 0x142, 0xa, 0xf, false); x = x > y? x : y;
+	return x;
+}
+__device__ __forceinline__ uint32_t half_shl(uint32_t cur, uint32_t carry, bool top)   // band_shl inside a half: the half's last lane takes the carry
+{
+	uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)cur, 0x130, 0xf, 0xf, false);
+	nx = top? carry : nx;
+	return __builtin_amdgcn_alignbit(nx, cur, 16);
+}
+__device__ __forceinline__ uint32_t half_scan(const uint32_t A, const int32_t cneg, bool first)
+{
+	const int32_t incl = half_incl_scan_max32((int32_t)pk_max_swap(A));
+	int32_t ex = __builtin_amdgcn_update_dpp(cneg, incl, 0x138, 0xf, 0xf, false);
+	ex = first? cneg : ex;
+	return pk_max((uint32_t)ex, __builtin_amdgcn_perm(A, ROW_PKNEG, 0x05040100));
+}
+
+template <bool RIGHT>
+__device__ __forceinline__ void band2_sweep(const DpConst &dc, const RowK &K, const int qlen, const int tlen, const int dlo, const int qmax, const uint8_t *query, const uint8_t *target,
+                                            uint8_t *p, const bool any_n, const int lane, int32_t &h_end)
+{
+	const int hl = lane & 31;                                 // lane inside the half
+	const bool top = hl == 31, first = hl == 0, hi = lane >= 32;
+	const uint32_t negw = pk2(ROW_NEG, ROW_NEG);
+	const int d0 = dlo + 2 * hl;
+	int h0, h1;
+	{ const int t = d0 - 1; h0 = t >= 0? row_hb(t, dc) : t == -1? 0 : ROW_NEG; }
+	{ const int t = d0; h1 = t >= 0? row_hb(t, dc) : t == -1? 0 : ROW_NEG; }
+	uint32_t Hp = pk2(h0, h1);
+	uint32_t Fn = pk_max(pk_sub_s(Hp, K.qe1), negw), F2n = pk_max(pk_sub_s(Hp, K.qe2), negw);
+	uint32_t TQ = ((d0 >= 0 && d0 < tlen)? (uint32_t)target[d0] : 0u) | ((d0 + 1 >= 0 && d0 + 1 < tlen)? (uint32_t)target[d0 + 1] : 0u) << 16;
+	const uint32_t KE1 = pk2(d0 * dc.e, (d0 + 1) * dc.e), KE2 = pk2(d0 * dc.e2, (d0 + 1) * dc.e2);
+	const uint32_t KQ1 = pk2(d0 * dc.e + dc.q, (d0 + 1) * dc.e + dc.q), KQ2 = pk2(d0 * dc.e2 + dc.q2, (d0 + 1) * dc.e2 + dc.q2);
+	const uint32_t dmis = vreg_const(pk8w(dc.sc_mis - dc.sc_mch));
+	const int dhi = dlo + 63;
+	uint32_t qv = 0, tv = 0, A0 = 0, A1 = 0, Hend = 0;
+	uint8_t *ptile = p + 8 * hl;
+	const int32_t cneg = row_dbl(ROW_NEG);
+	for (int q0 = 0; q0 < qmax; q0 += ROW_TILE_ROWS) {
+#pragma unroll
+		for (int u = 0; u < ROW_TILE_ROWS; ++u) {
+			const int q = q0 + u;
+			if (q >= qmax) break;                              // (wave-uniform)
+			if ((q & 31) == 0) {
+				qv = q + hl < qlen? query[q + hl] : 0;
+				const int ti = q + 1 + dhi + hl;
+				tv = (ti >= 0 && ti < tlen)? target[ti] : 0;
+			}
+			const uint32_t qa = (uint32_t)__builtin_amdgcn_readlane((int)qv, q & 31), qb = (uint32_t)__builtin_amdgcn_readlane((int)qv, 32 + (q & 31));
+			const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)tv, q & 31), tb = (uint32_t)__builtin_amdgcn_readlane((int)tv, 32 + (q & 31));
+			const uint32_t qc2 = hi? (qb | qb << 16) : (qa | qa << 16), tin = hi? tb : ta;
+			// one register set, as band_set
+			const uint32_t F = half_shl(Fn, negw, top), F2 = half_shl(F2n, negw, top);
+			uint32_t s = pk_mad_vvs(pk_minu_s(TQ ^ qc2, K.one), dmis, K.mch);
+			if (any_n) s = pk_mad(pk_shr2(TQ | qc2), pk_rsub_s(K.N, s), s);
+			const uint32_t M = pk_add(Hp, s);
+			const uint32_t G = pk_max(pk_max(M, F), F2);
+			const uint32_t E = pk_sub(half_scan(pk_add(G, KE1), cneg, first), KQ1);
+			const uint32_t E2 = pk_sub(half_scan(pk_add(G, KE2), cneg, first), KQ2);
+			const uint32_t H = pk_max(pk_max(G, E), E2);
+			const uint32_t xE = pk_sub(H, E), xF = pk_sub(H, F), xE2 = pk_sub(H, E2), xF2 = pk_sub(H, F2);
+			const uint32_t n1 = pk_minu_s(xE, K.one), n2 = pk_minu_s(xF, K.one), n3 = pk_minu_s(xE2, K.one);
+			uint32_t d;
+			if (!RIGHT) {
+				const uint32_t n0 = pk_minu_s(pk_sub(H, M), K.one);
+				d = pk_mad_vss(n3, K.one);
+				d = pk_mad_vvs(n2, d, K.one);
+				d = pk_mad_vvs(n1, d, K.one);
+				d = pk_mul(n0, d);
+			} else {
+				const uint32_t n4 = pk_minu_s(xF2, K.one);
+				d = pk_rsub_s(K.one, n1);
+				d = pk_mad_vvs(n2, pk_sub_s(d, K.two), K.two);
+				d = pk_mad_vvs(n3, pk_sub_s(d, K.three), K.three);
+				d = pk_mad_vvs(n4, pk_sub_s(d, K.four), K.four);
+			}
+			const uint32_t c1 = RIGHT? K.q1p : K.q1, c2 = RIGHT? K.q2p : K.q2;
+			d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c1, xE), K.one), K.f8, d);
+			d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c1, xF), K.one), K.f16, d);
+			d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c2, xE2), K.one), K.f32, d);
+			d = pk_mad_vsv(pk_minu_s(pk_rsubsat_s(c2, xF2), K.one), K.f64, d);
+			uint32_t &accw = u < 2? A0 : A1;
+			if (!(u & 1)) accw = __builtin_amdgcn_perm(0, d, 0x0c0c0200);
+			else accw = __builtin_amdgcn_perm(d, accw, 0x06040100);
+			Hp = H;
+			Fn = pk_max(pk_sub_s(H, K.qe1), pk_sub_s(F, K.e1));
+			F2n = pk_max(pk_sub_s(H, K.qe2), pk_sub_s(F2, K.e2));
+			TQ = half_shl(TQ, tin, top);
+			if (q == qlen - 1) Hend = Hp;                      // (per lane: the halves end on different rows)
+		}
+		if (q0 < qlen) *(uint2*)ptile = make_uint2(A0, A1);     // rows of the own matrix only
+		ptile += 4 * 64;
+	}
+	const int idx = tlen - qlen - dlo;
+	const uint32_t hv = (uint32_t)__shfl((int)Hend, (lane & 32) | ((idx >> 1) & 31));
+	h_end = (int32_t)(int16_t)(idx & 1? hv >> 16 : hv & 0xffff);
+}
+
+__global__ __launch_bounds__(64) void k_ksw_band2(DpConst dc, const DpJobDev *jobs, const int32_t *job_ids, int n_jobs,
+                                                   const uint8_t *qbase, const uint8_t *tbase, uint8_t *pbase, mm355_dpres_t *res, unsigned long long *cells_ctr, int32_t *fail)
+{
+	const int lane = threadIdx.x;
+	const int ja = 2 * (int)blockIdx.x, jb_ = ja + 1;
+	if (ja >= n_jobs) return;
+	const bool has_b = jb_ < n_jobs, hi = lane >= 32;
+	const int jid = job_ids[hi && has_b? jb_ : ja];          // (an odd list: the upper half repeats problem A and writes nothing)
+	const DpJobDev jb = jobs[jid];
+	const bool live = !hi || has_b;
+	const uint8_t *target = tbase + jb.toff, *query = qbase + jb.qoff;
+	RowK K;
+	K.qe1 = pk8w(dc.q + dc.e); K.e1 = pk8w(dc.e); K.qe2 = pk8w(dc.q2 + dc.e2); K.e2 = pk8w(dc.e2); K.q1 = pk8w(dc.q); K.q2 = pk8w(dc.q2);
+	K.mch = pk8w(dc.sc_mch); K.N = pk8w(dc.sc_N); K.one = 0x00010001u; K.two = 0x00020002u; K.three = 0x00030003u; K.four = 0x00040004u;
+	K.f8 = 0x00080008u; K.f16 = 0x00100010u; K.f32 = 0x00200020u; K.f64 = 0x00400040u; K.q1i = dc.q; K.q2i = dc.q2; K.q1p = pk8w(dc.q + 1); K.q2p = pk8w(dc.q2 + 1);
+	bool n = false;
+	for (int i = lane & 31; i < jb.tlen; i += 32) n |= target[i] > 3;
+	for (int i = lane & 31; i < jb.qlen; i += 32) n |= query[i] > 3;
+	const bool any_n = __ballot(n) != 0;                      // (either problem: the ambiguity term is exact for both)
+	const int qlen = live? jb.qlen : 0;                       // the dead half stores nothing (its rows are "beyond its matrix")
+	int qmax = jb.qlen;
+	{ const int o = __shfl(qmax, lane ^ 32); qmax = qmax > o? qmax : o; }
+	qmax = __builtin_amdgcn_readfirstlane(qmax);
+	int32_t h_end = KSW_NEG_INF;
+	const int rflag = __builtin_amdgcn_readfirstlane(jb.flag & EZ_RIGHT);   // (the two problems of a wave share KSW_EZ_RIGHT: the launch list is split by it)
+	if (rflag) band2_sweep<true>(dc, K, qlen, jb.tlen, jb.dlo, qmax, query, target, pbase + jb.p_off, any_n, lane, h_end);
+	else band2_sweep<false>(dc, K, qlen, jb.tlen, jb.dlo, qmax, query, target, pbase + jb.p_off, any_n, lane, h_end);
+	if ((lane & 31) == 0 && live) {
+		const bool ok = h_end >= jb.lmin;
+		mm355_dpres_t o;
+		o.max = 0; o.zdropped = 0; o.max_q = o.max_t = o.mqe_t = o.mte_q = -1; o.mqe = o.mte = KSW_NEG_INF; o.reach_end = 0;
+		o.score = h_end + (dc.q + dc.e) - dc.qe_preswap;
+		o.n_cigar = ok? jb.tlen - 1 : -1; o.cigar_off = ok? jb.qlen - 1 : -1;
+		res[jid] = o;
+		if (!ok) fail[1 + atomicAdd(&fail[0], 1)] = jid;
+		atomicAdd(cells_ctr + ((blockIdx.x + (hi? 1 : 0)) & (DP_CTR_SPREAD - 1)), (unsigned long long)jb.qlen * (unsigned long long)jb.tlen);
+	}
+}

@@ -777,7 +777,7 @@ __global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTa
 #define MW_MED_LAB (MW_BIG + 64)
 #define MW_LEVELS 9
 template <typename T, typename Key>
-static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, size_t n_elems, size_t task_cap, int n_levels, int *err, hipStream_t st)
+static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, size_t n_elems, size_t task_cap, int n_levels, int *err, hipStream_t st, void *kt)
 {
 	(void)hipFuncSetAttribute((const void*)k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, MW_LAB_CAP);
 	const uint32_t big_min = (uint32_t)mm355_sort_heavy_threshold(), med_min = (uint32_t)mm355_sort_medium_threshold();
@@ -797,12 +797,12 @@ static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2]
 		const size_t gb = level == 0? (size_t)n_big : cap_big, gm = level == 0? (size_t)n_med : cap_med;
 		if (level == 0 && n_big + n_med == 0) break;
 		unsigned int *c_in = d_ctr + 2 * level, *c_out = d_ctr + 2 * (level + 1);
-		if (gb) hipLaunchKernelGGL((k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>), dim3((unsigned)gb), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], c_in, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err);
-		if (gm) hipLaunchKernelGGL((k_sort_level_mw<T, Key, 256, MW_MED_LAB>), dim3((unsigned)gm), dim3(256), MW_MED_LAB, st, an, d_med[cur], c_in + 1, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err);
+		if (gb) { KtScope ks(kt, KT_LITERAL, st); hipLaunchKernelGGL((k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>), dim3((unsigned)gb), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], c_in, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err); }
+		if (gm) { KtScope ks(kt, KT_LIT_MED, st); hipLaunchKernelGGL((k_sort_level_mw<T, Key, 256, MW_MED_LAB>), dim3((unsigned)gm), dim3(256), MW_MED_LAB, st, an, d_med[cur], c_in + 1, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err); }
 		cur ^= 1;
 	}
 	const size_t gs = n_big + n_med == 0? (size_t)n_small : std::min<size_t>(task_cap, 16384);
-	if (gs) hipLaunchKernelGGL((k_sort_tasks<T, Key>), dim3((unsigned)gs), dim3(WAVE), 0, st, an, d_small, d_small_ctr, err);
+	if (gs) { KtScope ks(kt, KT_LIT_TASKS, st); hipLaunchKernelGGL((k_sort_tasks<T, Key>), dim3((unsigned)gs), dim3(WAVE), 0, st, an, d_small, d_small_ctr, err); }
 	return 0;
 }
 
@@ -1228,7 +1228,6 @@ void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const Dev
 int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st, void *kt, int n_levels)
 {
 	(void)bt;
-	KtScope ks(kt, KT_LITERAL, st);
 	const int n = n_big + n_med + n_small;
 	if (n == 0) return 0;
 	SortTask *base = (SortTask*)task_buf;
@@ -1239,7 +1238,7 @@ int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *
 	if (n_big && hipMemcpyAsync(big[0], ht, (size_t)n_big * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 	if (n_med && hipMemcpyAsync(med[0], ht + n_big, (size_t)n_med * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 	if (n_small && hipMemcpyAsync(small, ht + n_big + n_med, (size_t)n_small * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, n_elems, task_cap, n_levels > 0? n_levels : MW_LEVELS, err, st);
+	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, n_elems, task_cap, n_levels > 0? n_levels : MW_LEVELS, err, st, kt);
 }
 int mm355_sort_task_bytes(void) { return (int)sizeof(SortTask); }
 int mm355_sort_heavy_threshold(void)   // MM355_SORT_HEAVY_MIN: test hook that pushes ordinary reads through the 1024-thread path

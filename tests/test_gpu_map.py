@@ -436,17 +436,17 @@ def test_dp_kernel_parity(ont):
     forced = os.environ.get("MM355_DP_BAND_FORCE") or os.environ.get("MM355_DP_BAND") == "0"
     if not forced:
         assert groups[14] > 0 and groups[15] > 0 and groups[16] > 0, groups      # k_ksw_row<2>, <4> and <8> ran ...
-        assert groups[19] > 0 and st.n_dp_band > 50, (groups, st.n_dp_band)          # ... and the band kernel with its sufficiency proof (mm355_dpband.h)
-        assert 0 < st.n_dp_band_redo < st.n_dp_band and groups[22] == 1, (st.n_dp_band_redo, st.n_dp_band, groups)   # some proofs fail (long indels): run again on the full matrix
+        assert groups[19] + groups[22] > 0 and st.n_dp_band > 50, (groups, st.n_dp_band)          # ... and the band kernel with its sufficiency proof (mm355_dpband.h)
+        assert 0 < st.n_dp_band_redo < st.n_dp_band and groups[23] == 1, (st.n_dp_band_redo, st.n_dp_band, groups)   # some proofs fail (long indels): run again on the full matrix
     elif os.environ.get("MM355_DP_BAND") == "0":
-        assert groups[19] + groups[20] + groups[21] == 0 and st.n_dp_band == 0
+        assert groups[19] + groups[20] + groups[21] + groups[22] == 0 and st.n_dp_band == 0
     else:
-        k = {"1": 19, "2": 20, "4": 21}[os.environ["MM355_DP_BAND_FORCE"]]
+        k = {"64": 22, "1": 19, "2": 20, "4": 21}[os.environ["MM355_DP_BAND_FORCE"]]
         assert groups[k] > 0 and st.n_dp_band > 300 and st.n_dp_band_redo > 20, (groups, st.n_dp_band, st.n_dp_band_redo)   # forced: every problem whose end cell fits the band tries it
     sr.close()
 
 
-@pytest.mark.parametrize("env", [{"MM355_DP_BAND_FORCE": "1"}, {"MM355_DP_BAND_FORCE": "2"}, {"MM355_DP_BAND_FORCE": "4"}, {"MM355_DP_BAND": "0"}])
+@pytest.mark.parametrize("env", [{"MM355_DP_BAND_FORCE": "64"}, {"MM355_DP_BAND_FORCE": "1"}, {"MM355_DP_BAND_FORCE": "2"}, {"MM355_DP_BAND_FORCE": "4"}, {"MM355_DP_BAND": "0"}])
 def test_dp_band_kernels_forced(built, env):
     """the 1000 problems of test_dp_kernel_parity once more (a child process: the switches are read once) with every full-band fill pushed onto a
     band of 128 / 256 / 512 diagonals whenever its end cell fits -- unrelated sequences, 700-base insertions and all: the proof must fail for
@@ -490,7 +490,7 @@ def test_dp_row_kernel_with_reordered_gap_costs(ont):
         sr = al._stage_runner()
         _ffi.check(L.mm355_stage_dp(sr.ctx, C.byref(mo), len(jobs), ja, qcat.ctypes.data, qcat.size, tcat.ctypes.data, tcat.size, res, cig.ctypes.data, cap))
         groups = list(sr.stats().n_launch_group)
-        assert (groups[14] + groups[15] + groups[16] + groups[19] + groups[20] + groups[21] > 0) == expect_row, (groups, (q, e, q2, e2))
+        assert (groups[14] + groups[15] + groups[16] + groups[19] + groups[20] + groups[21] + groups[22] > 0) == expect_row, (groups, (q, e, q2, e2))
         # k_ksw_rowl takes a long problem only where its int16 range allows (mm355_dp.hip::rowl_range_ok, restated here): with
         # (4, 6, 1, 10, 1, 3, 4) -- match 4, e = 4 after ksw2's ordering -- 4096 columns do not fit, nor with the single piece (5, 2)
         def range_ok(ql, tl):
