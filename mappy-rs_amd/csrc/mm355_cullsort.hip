@@ -341,6 +341,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	static const int env_wpl = [] { const char *e = getenv("MM355_CULL_WPL"); return e? atoi(e) : 0; }();
 	static const int env_nt = [] { const char *e = getenv("MM355_CULL_NT"); return e? atoi(e) : 0; }();
 	static const int env_sh = [] { const char *e = getenv("MM355_CULL_SH"); return e? atoi(e) : 0; }();
+	static const int max_pass = [] { const char *e = getenv("MM355_CULL_MAX_PASS"); return e && atoi(e) > 0? atoi(e) : 4; }();
 	cp.wpl = env_wpl >= 256 && env_wpl <= CS_WPL_MAX? (env_wpl & ~3) : CS_WPL_MAX;
 	cp.bpp = cp.wpl * 32 - 2 * CS_GUARD;
 	const int cull_nt = env_nt == 256 || env_nt == 512? env_nt : 1024;
@@ -350,7 +351,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		for (;; ++cp.sh) {   // at most four passes over a read's anchors: wider bins beyond that
 			const uint64_t bins = ((2 * cp.tot_len) >> cp.sh) + 1;
 			cp.n_pass = (int)((bins + cp.bpp - 1) / cp.bpp);
-			if (cp.n_pass <= 4) break;
+			if (cp.n_pass <= max_pass) break;
 		}
 	}
 	const size_t nr = (size_t)n_reads;

@@ -794,7 +794,10 @@ static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2]
 	const size_t cap_big = std::min<size_t>(std::min(task_cap, n_elems / big_min + 1), lim_big), cap_med = std::min<size_t>(std::min(task_cap, n_elems / med_min + 1), lim_med);
 	int cur = 0;
 	for (int level = 0; level < MW_LEVELS && level < n_levels; ++level) {
-		const size_t gb = level == 0? (size_t)n_big : cap_big, gm = level == 0? (size_t)n_med : cap_med;
+		// (a big-class block wants a whole CU -- 1024 threads, 120 KB of LDS -- even to find its list empty: behind the first two levels the buckets
+		// of more than 16384 elements are few, and a short grid strides over them)
+		static const size_t deep_big = [] { const char *e = getenv("MM355_SORT_CAP_DEEP"); return (size_t)(e && atoi(e) > 0? atoi(e) : 48); }();
+		const size_t gb = level == 0? (size_t)n_big : level == 1? cap_big : std::min(cap_big, deep_big), gm = level == 0? (size_t)n_med : cap_med;
 		if (level == 0 && n_big + n_med == 0) break;
 		unsigned int *c_in = d_ctr + 2 * level, *c_out = d_ctr + 2 * (level + 1);
 		if (gb) { KtScope ks(kt, KT_LITERAL, st); hipLaunchKernelGGL((k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>), dim3((unsigned)gb), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], c_in, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err); }

@@ -10,7 +10,12 @@ out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path
 WIDE_LOADS = ("k_seed_lookup",)
 # bench.py roofline names <- kernel name prefixes
 ALIAS = {"k_ksw_extd2<512> (targets 1025..4096)": "k_ksw_extd2<512>", "k_ksw_extd2<512> (targets > 4096)": "k_ksw_extd2<512>",
-         "k_ksw_rowl (targets 1025..8192)": "k_ksw_rowl", "k_ksw_regw8 (exact, band <= 832, targets > 1024)": "k_ksw_regw8"}
+         "k_ksw_rowl (targets 1025..8192)": "k_ksw_rowl", "k_ksw_regw8 (exact, band <= 832, targets > 1024)": "k_ksw_regw8",
+         "k_ksw_band2 (64 diagonals, two problems per wave)": "k_ksw_band2", "k_ksw_band<1> (128 diagonals)": "k_ksw_band<1>",
+         "k_ksw_band<2> (256 diagonals)": "k_ksw_band<2>", "k_ksw_band<4> (512 diagonals)": "k_ksw_band<4>",
+         "k_sort_level_mw<1024> (radix_sort_128x emulation, buckets > 16384)": "k_sort_level_mw<mm128, mm_key_x, 1024, 122880>",
+         "k_sort_level_mw<256> (radix_sort_128x emulation, buckets > 2048)": "k_sort_level_mw<mm128, mm_key_x, 256, 16448>",
+         "k_sort_tasks (radix_sort_128x emulation, one wave per bucket)": "k_sort_tasks<mm128, mm_key_x>"}
 
 
 def load(fn):
