@@ -448,7 +448,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		DevAnchors at; memset(&at, 0, sizeof(at));
 		at.aoff = d_toff; at.a = c->tie_a.as<mm128>(); at.b = c->tie_b.as<mm128>(); at.f = c->tie_f.as<int32_t>(); at.p = c->tie_p.as<int32_t>(); at.t8 = c->tie_t8.as<uint8_t>(); at.tcnt = tie_skip? c->tie_tcnt.as<int32_t>() : 0;
 		const size_t task_cap = (size_t)tt / 64 + (size_t)n_tie + 1024;
-		if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 512)) return MM355_ENOMEM;
+		if (c->sort_tasks.ensure(mm355_sort_buf_bytes(task_cap))) return MM355_ENOMEM;
 		DevBatch bt; memset(&bt, 0, sizeof(bt));
 		if (mm355_launch_sort(bt, at, c->err.as<int>(), ht, nb, nm, ns, (size_t)tt, c->sort_tasks.p, task_cap, c->st, c, mm355_sort_levels(c->mi))) return MM355_EHIP;
 		hipLaunchKernelGGL(k_tie_emit, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, d_off2, c->a.as<mm128>(), c->tie_a.as<mm128>(), full_sorted, c->b.as<mm128>(), cp.ib);

@@ -103,6 +103,7 @@ void mm355_launch_seed_expand(const DevIndex &ix, const DevParams &pr, const Dev
 struct SortTask { int32_t read; uint32_t beg, end; int32_t s; };   // a bucket [beg, end) of one read's array, to be sorted from byte shift s
 int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *h_tasks, int n_big, int n_med, int n_small, size_t n_elems, void *task_buf, size_t task_cap, hipStream_t st, void *kt = 0, int n_levels = 0);
 int mm355_sort_heavy_threshold(void);
+size_t mm355_sort_buf_bytes(size_t task_cap);   // device scratch mm355_launch_sort needs for `task_cap`
 int mm355_sort_medium_threshold(void);
 int mm355_chain_chunk(void);
 int mm355_launch_chain(const DevParams &pr, const DevBatch &bt, DevAnchors &an, unsigned long long *pairs, void *seg_small, void *seg_big, unsigned int *ctr,

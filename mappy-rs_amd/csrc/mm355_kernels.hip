@@ -583,6 +583,9 @@ __global__ __launch_bounds__(WAVE) void k_sort_anchors(DevBatch bt, DevAnchors a
 // is finished by one wave each (k_sort_tasks).  The latency of the slowest read drops from O(n) wave-serial steps per
 // level to O(n/1024) + the 1-byte label walk.
 #define MW_NT 1024
+#ifndef MW_STK
+#define MW_STK 128                   // entries of a big-class block's own stack of big buckets (depth first inside the block)
+#endif
 #define MW_LAB_CAP 122880   // 120 KB of labels in LDS
 #define MW_BIG 16384        // buckets larger than this take a 1024-thread level
 #define MW_MED 2048         // ... larger than this a 256-thread level; smaller ones are finished by one wave in LDS
@@ -626,7 +629,7 @@ __device__ inline uint32_t block_ordered_prefix(bool flag, uint32_t &base, MwLds
 // own size class; ctr = { next-level big, next-level medium, wave tasks (running total) }.
 template <typename T, typename Key, int NT, int LABCAP>
 __device__ inline void mw_level_task(MwLds<NT> &L, uint8_t *lds_lab, const DevAnchors &an, const SortTask tk, SortTask *out_big, SortTask *out_med, SortTask *out_small,
-                                     unsigned int *ctr, unsigned int *ctr_small, uint32_t big_min, uint32_t med_min)
+                                     unsigned int *ctr, unsigned int *ctr_small, uint32_t big_min, uint32_t med_min, SortTask *stk = 0, unsigned int *stk_n = 0, uint32_t stk_cap = 0)
 {
 	const int64_t o = an.aoff[tk.read];
 	T *a = SortArr<T>::arr(an, o);
@@ -722,7 +725,11 @@ __device__ inline void mw_level_task(MwLds<NT> &L, uint8_t *lds_lab, const DevAn
 		if (sz > 1 && !ws_has_tie(ws.tcnt, beg + b0, beg + b0 + sz)) { /* unique content, restored by the caller */ }
 		else if (sz > MM355_RS_MIN_SIZE) {
 			SortTask c; c.read = tk.read; c.beg = beg + b0; c.end = beg + b0 + sz; c.s = s - 8;
-			if (sz > big_min) out_big[atomicAdd(&ctr[0], 1u)] = c;
+			if (sz > big_min) {   // the block's own stack first (it goes on with this read's big buckets itself), the next level's list when that is full
+				unsigned int k = stk? atomicAdd(stk_n, 1u) : stk_cap;
+				if (k < stk_cap) stk[k] = c;
+				else { if (stk) atomicSub(stk_n, 1u); out_big[atomicAdd(&ctr[0], 1u)] = c; }
+			}
 			else if (sz > med_min) out_med[atomicAdd(&ctr[1], 1u)] = c;
 			else out_small[atomicAdd(ctr_small, 1u)] = c;
 		} else if (sz > 1) mm_rs_insertsort(a + beg + b0, a + beg + b0 + sz, key);
@@ -733,14 +740,31 @@ __device__ inline void mw_level_task(MwLds<NT> &L, uint8_t *lds_lab, const DevAn
 // blocks that each wait for a whole free CU beside the other contexts' kernels.
 template <typename T, typename Key, int NT, int LABCAP>
 __global__ __launch_bounds__(NT) void k_sort_level_mw(DevAnchors an, const SortTask *tasks, const unsigned int *n_tasks_p, SortTask *out_big, SortTask *out_med, SortTask *out_small,
-                                                      unsigned int *ctr, unsigned int *ctr_small, uint32_t big_min, uint32_t med_min, int *err)
+                                                      unsigned int *ctr, unsigned int *ctr_small, uint32_t big_min, uint32_t med_min, int *err, SortTask *stacks)
 {
 	__shared__ MwLds<NT> L;
+	__shared__ unsigned int s_stk_n;
 	extern __shared__ uint8_t lds_lab[];   // LABCAP labels
 	const unsigned int n_tasks = *n_tasks_p;
+	// stacks != 0 (the big class): a block keeps the big buckets its task produces on a stack of its own (MW_STK entries in HBM) and works them
+	// off itself, depth first, before it takes another task: the 1024-thread / 120-KB block got its CU once, instead of once per level beside the
+	// other contexts' kernels.  Medium and small buckets go to the lists as before; a full stack spills to the next level's list.
+	SortTask *stk = stacks? stacks + (size_t)blockIdx.x * MW_STK : 0;
 	for (unsigned int t = blockIdx.x; t < n_tasks; t += gridDim.x) {
-		mw_level_task<T, Key, NT, LABCAP>(L, lds_lab, an, tasks[t], out_big, out_med, out_small, ctr, ctr_small, big_min, med_min);
+		if (threadIdx.x == 0) s_stk_n = 0;
 		__syncthreads();
+		mw_level_task<T, Key, NT, LABCAP>(L, lds_lab, an, tasks[t], out_big, out_med, out_small, ctr, ctr_small, big_min, med_min, stk, &s_stk_n, stk? MW_STK : 0);
+		for (;;) {
+			__threadfence_block();
+			__syncthreads();
+			const unsigned int n = s_stk_n;
+			if (n == 0) break;
+			const SortTask tk = stk[n - 1];
+			__syncthreads();
+			if (threadIdx.x == 0) s_stk_n = n - 1;
+			__syncthreads();
+			mw_level_task<T, Key, NT, LABCAP>(L, lds_lab, an, tk, out_big, out_med, out_small, ctr, ctr_small, big_min, med_min, stk, &s_stk_n, MW_STK);
+		}
 	}
 	(void)err;
 }
@@ -776,8 +800,11 @@ __global__ __launch_bounds__(WAVE) void k_sort_tasks(DevAnchors an, const SortTa
 // counters back after every level: up to nine host round trips per sub-batch, each a few ms under the bench load).
 #define MW_MED_LAB (MW_BIG + 64)
 #define MW_LEVELS 9
+#define MW_STACK_BLOCKS 4096          // most blocks of a big-class launch that get a stack (grids are capped below this)
+size_t mm355_sort_buf_bytes(size_t task_cap);
+#define MW_STK 128                   // entries of a big-class block's own stack of big buckets
 template <typename T, typename Key>
-static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, size_t n_elems, size_t task_cap, int n_levels, int *err, hipStream_t st, void *kt)
+static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2], SortTask *d_small, unsigned int *d_ctr, int n_big, int n_med, int n_small, size_t n_elems, size_t task_cap, int n_levels, int *err, hipStream_t st, void *kt, SortTask *stacks)
 {
 	(void)hipFuncSetAttribute((const void*)k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, MW_LAB_CAP);
 	const uint32_t big_min = (uint32_t)mm355_sort_heavy_threshold(), med_min = (uint32_t)mm355_sort_medium_threshold();
@@ -800,8 +827,8 @@ static int sort_tasks_run(DevAnchors &an, SortTask *d_big[2], SortTask *d_med[2]
 		const size_t gb = level == 0? (size_t)n_big : level == 1? cap_big : std::min(cap_big, deep_big), gm = level == 0? (size_t)n_med : cap_med;
 		if (level == 0 && n_big + n_med == 0) break;
 		unsigned int *c_in = d_ctr + 2 * level, *c_out = d_ctr + 2 * (level + 1);
-		if (gb) { KtScope ks(kt, KT_LITERAL, st); hipLaunchKernelGGL((k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>), dim3((unsigned)gb), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], c_in, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err); }
-		if (gm) { KtScope ks(kt, KT_LIT_MED, st); hipLaunchKernelGGL((k_sort_level_mw<T, Key, 256, MW_MED_LAB>), dim3((unsigned)gm), dim3(256), MW_MED_LAB, st, an, d_med[cur], c_in + 1, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err); }
+		if (gb) { KtScope ks(kt, KT_LITERAL, st); hipLaunchKernelGGL((k_sort_level_mw<T, Key, MW_NT, MW_LAB_CAP>), dim3((unsigned)std::min<size_t>(gb, MW_STACK_BLOCKS)), dim3(MW_NT), MW_LAB_CAP, st, an, d_big[cur], c_in, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err, stacks); }
+		if (gm) { KtScope ks(kt, KT_LIT_MED, st); hipLaunchKernelGGL((k_sort_level_mw<T, Key, 256, MW_MED_LAB>), dim3((unsigned)gm), dim3(256), MW_MED_LAB, st, an, d_med[cur], c_in + 1, d_big[cur ^ 1], d_med[cur ^ 1], d_small, c_out, d_small_ctr, big_min, med_min, err, (SortTask*)0); }
 		cur ^= 1;
 	}
 	const size_t gs = n_big + n_med == 0? (size_t)n_small : std::min<size_t>(task_cap, 16384);
@@ -1237,13 +1264,20 @@ int mm355_launch_sort(const DevBatch &bt, DevAnchors &an, int *err, const void *
 	SortTask *big[2] = { base, base + task_cap }, *med[2] = { base + 2 * task_cap, base + 3 * task_cap };
 	SortTask *small = base + 4 * task_cap;
 	unsigned int *ctr = (unsigned int*)(base + 5 * task_cap);
+	// stacks of the big-class blocks (depth first inside a block): MW_STK entries per block of the widest grid, behind the counters
+	// (MM355_SORT_DFS=1; off by default: measured under the bench load the big levels take 300-310 ms per step with it against 233 without -- a read's two
+	// strand buckets then run one after the other in ONE block instead of side by side in two, and that costs more than the launches it saves)
+	static const bool use_stacks = [] { const char *e = getenv("MM355_SORT_DFS"); return e && atoi(e) != 0; }();
+	SortTask *stacks = use_stacks? (SortTask*)((char*)task_buf + mm355_sort_buf_bytes(task_cap) - (size_t)MW_STACK_BLOCKS * MW_STK * sizeof(SortTask)) : 0;
 	const SortTask *ht = (const SortTask*)h_tasks;
 	if (n_big && hipMemcpyAsync(big[0], ht, (size_t)n_big * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 	if (n_med && hipMemcpyAsync(med[0], ht + n_big, (size_t)n_med * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
 	if (n_small && hipMemcpyAsync(small, ht + n_big + n_med, (size_t)n_small * sizeof(SortTask), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, n_elems, task_cap, n_levels > 0? n_levels : MW_LEVELS, err, st, kt);
+	return sort_tasks_run<mm128, mm_key_x>(an, big, med, small, ctr, n_big, n_med, n_small, n_elems, task_cap, n_levels > 0? n_levels : MW_LEVELS, err, st, kt, stacks);
 }
 int mm355_sort_task_bytes(void) { return (int)sizeof(SortTask); }
+// device scratch of mm355_launch_sort for `task_cap`: five task lists, 64 counters, the stacks of the big-class blocks
+size_t mm355_sort_buf_bytes(size_t task_cap) { return task_cap * 5 * sizeof(SortTask) + 512 + (size_t)MW_STACK_BLOCKS * MW_STK * sizeof(SortTask); }
 int mm355_sort_heavy_threshold(void)   // MM355_SORT_HEAVY_MIN: test hook that pushes ordinary reads through the 1024-thread path
 {
 	static int thr = [] { const char *e = getenv("MM355_SORT_HEAVY_MIN"); int v = e? atoi(e) : MW_BIG; return v < 65? 65 : v; }();

@@ -528,7 +528,7 @@ int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 			DevAnchors a = dev_anchors(c);
 			// every emitted task covers > 64 elements, so tot_a / 64 (+ one whole-array task per read) bounds each list
 			const size_t task_cap = (size_t)c->hb.tot_a / 64 + (size_t)c->hb.n_reads + 1024;
-			if (c->sort_tasks.ensure(task_cap * 5 * sizeof(SortTask) + 512)) return MM355_ENOMEM;
+			if (c->sort_tasks.ensure(mm355_sort_buf_bytes(task_cap))) return MM355_ENOMEM;
 			// whole-array tasks of the reads, by size class: 1024-thread levels, 256-thread levels, one wave
 			const int big_min = mm355_sort_heavy_threshold(), med_min = mm355_sort_medium_threshold();
 			int nb = 0, nm = 0, ns = 0;
