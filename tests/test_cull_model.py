@@ -1,0 +1,75 @@
+"""The claim k_cull (mappy-rs_amd/csrc/mm355_cullsort.hip) rests on, checked on the CPU with the oracle's literal mg_lchain_dp: anchors whose
+run of non-empty position bins holds fewer than T = max(min_cnt, ceil(min_chain_score / k)) anchors can be deleted from the SORTED array
+before chaining -- u[] and the compacted anchors do not change.  The rule is restated here in numpy exactly as the kernel applies it (bins of
+2^sh >= max_dist_x bases of the concatenated, strand-doubled reference; a run = consecutive non-empty bins; counts as they are, no
+saturation -- the kernel only ever keeps MORE), on a genome whose repeat families scatter lone hits all over it; also with a larger min_cnt /
+min_chain_score (larger T) and with bins that are too NARROW (sh below log2 max_dist_x), where the deletion must be seen to change results --
+the bin width is what the argument needs.  GPU side: tests/test_gpu_human.py::test_anchor_cull_and_sort_mid_scale."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+import synthdata as S
+
+
+def cull(a, seq_off, tot_len, sh, T):
+    """keep[i] for the sorted anchor array a[n, 2]: the rule of k_cull"""
+    x = a[:, 0]
+    strand = (x >> np.uint64(63)).astype(np.int64); rid = ((x >> np.uint64(32)) & np.uint64(0x7fffffff)).astype(np.int64); rpos = (x & np.uint64(0xffffffff)).astype(np.int64)
+    pos = strand * tot_len + seq_off[rid] + rpos
+    b = pos >> sh
+    ub, inv, cnt = np.unique(b, return_inverse=True, return_counts=True)
+    run = np.cumsum(np.concatenate(([True], ub[1:] - ub[:-1] > 1))) - 1
+    tot = np.bincount(run, weights=cnt)
+    return tot[run][inv] >= T
+
+
+@pytest.fixture(scope="module")
+def world(built, tmp_path_factory):
+    td = tmp_path_factory.mktemp("cull")
+    g = S.make_genome(41, [14000000, 9000000], repeats=((300, 9000, 0.10), (1500, 700, 0.06), (171, 2500, 0.03)), n_runs=2)
+    fa = str(td / "ref.fa")
+    S.write_fasta(fa, g, ["chrA", "chrB"])
+    reads, _ = S.make_reads(42, g, 40, n50=6000, lo=500)
+    return dict(fa=fa, g=g, reads=reads)
+
+
+@pytest.mark.parametrize("kw", [{}, {"min_cnt": 5}, {"min_chain_score": 100}])
+def test_culled_anchors_never_chain(world, kw):
+    orc = O.OracleAligner(world["fa"], preset="map-ont", **kw)
+    g = world["g"]
+    seq_off = np.concatenate(([0], np.cumsum([len(c) for c in g])[:-1])).astype(np.int64)
+    tot_len = int(sum(len(c) for c in g))
+    mo = orc.mo
+    D = max(mo.max_gap_ref if mo.max_gap_ref > 0 else mo.max_gap, mo.bw)
+    sh = int(np.ceil(np.log2(D)))
+    T = max(mo.min_cnt, -(-mo.min_chain_score // orc.k))
+    n_all = n_kept = n_chains = 0
+    for rd in world["reads"]:
+        a, _, _, _ = orc.anchors(rd, sorted_=True)
+        if len(a) == 0:
+            continue
+        keep = cull(a, seq_off, tot_len, sh, T)
+        u0, b0 = orc.chains(a, len(rd))
+        u1, b1 = orc.chains(a[keep], len(rd))
+        assert np.array_equal(u0, u1) and np.array_equal(b0, b1)
+        n_all += len(a); n_kept += int(keep.sum()); n_chains += len(u0)
+    assert n_chains > 30 and n_kept < 0.8 * n_all, (n_all, n_kept, n_chains)      # the test data must have something to drop
+
+
+def test_bins_narrower_than_max_dist_x_are_not_enough(world):
+    """with 64-base bins anchors of one chain fall into runs of their own: deleting by that rule loses chains"""
+    orc = O.OracleAligner(world["fa"], preset="map-ont")
+    g = world["g"]
+    seq_off = np.concatenate(([0], np.cumsum([len(c) for c in g])[:-1])).astype(np.int64)
+    tot_len = int(sum(len(c) for c in g))
+    differs = 0
+    for rd in world["reads"][:30]:
+        a, _, _, _ = orc.anchors(rd, sorted_=True)
+        if len(a) == 0:
+            continue
+        keep = cull(a, seq_off, tot_len, 6, 3)
+        u0, b0 = orc.chains(a, len(rd))
+        u1, b1 = orc.chains(a[keep], len(rd))
+        differs += not (np.array_equal(u0, u1) and np.array_equal(b0, b1))
+    assert differs > 0
