@@ -315,6 +315,15 @@ static int bits_for(uint64_t v) { int b = 1; while (b < 64 && (1ULL << b) <= v) 
 #define CS_SMALL_CAP 2048
 #define CS_BIG_CAP   16384
 
+bool mm355_cull_sort_fits(const mm355_ctx *c)
+{
+	const mm355_index *mi = c->mi;
+	const uint64_t tot_len = mi->n_seq? mi->seq_off[mi->n_seq - 1] + mi->seq_len[mi->n_seq - 1] : 1;
+	int32_t max_na = 1;
+	for (int64_t i = 0; i < c->hb.n_reads; ++i) if (c->hb.n_a[i] > max_na) max_na = c->hb.n_a[i];
+	return bits_for(2 * tot_len - 1) + bits_for((uint64_t)max_na - 1) + 1 <= 64;
+}
+
 // Sorts the anchors of every read of the batch (c->a, offsets c->aoff / hb.aoff) and, with cull != 0, drops the anchors that cannot chain.
 // On return c->a / c->aoff / c->n_a, hb.aoff, hb.n_a and hb.tot_a describe the new (dense) array; the old buffers are scratch again.
 int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)

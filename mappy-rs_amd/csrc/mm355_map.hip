@@ -292,6 +292,8 @@ extern "C" int mm355_batch_select(mm355_ctx_t *c, int slot)
 	return 0;
 }
 
+static const bool g_parallel_hook_set = [] { mm355_parallel_hook = [](int64_t n, const std::function<void(int64_t)> &f) { parallel_for(n, host_threads(), [&](int64_t i, int) { f(i); }); }; return true; }();
+
 extern "C" int mm355_batch_upload(mm355_ctx_t *c, int64_t n_reads, const char *const *seqs, const int32_t *lens)
 {
 	if (c == 0 || n_reads < 0) return MM355_EINVAL;

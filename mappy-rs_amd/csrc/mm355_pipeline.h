@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <stdlib.h>
+#include <functional>
 #include "mm355_host.h"
 #include "mm355_dev.h"
 
@@ -113,6 +114,7 @@ int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi);
 
 // stage drivers (each leaves its outputs resident on the device and the per-read counts in ctx->hb)
 extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int flags, mm355_hits_t **out);
+extern void (*mm355_parallel_hook)(int64_t n, const std::function<void(int64_t)> &f);   // the host pool's parallel loop (mm355_map.hip), or null
 int mm355_run_pack(mm355_ctx *ctx, int64_t n_reads, const char *const *seqs, const int32_t *lens);
 int mm355_run_sketch(mm355_ctx *ctx);
 int mm355_run_seeds(mm355_ctx *ctx, const DevParams &pr);                  // mz_flt + lookup + select (+ D2H counts, anchor offsets)
@@ -152,6 +154,7 @@ struct EvTimer {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)
 
 int mm355_sort_levels(const mm355_index *mi);
+bool mm355_cull_sort_fits(const mm355_ctx *c);   // the 8-byte words of mm355_cullsort.hip can hold this batch (position bits + index bits <= 64)
 int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull);   // mm355_cullsort.hip: anchors that cannot chain dropped, the rest sorted per read in LDS
 hipError_t mm355_wait_stream(hipStream_t st);   // polls hipStreamQuery with short naps (MM355_BLOCKING_WAIT=0: hipStreamSynchronize, =1: blocking-sync event)
 void mm355_trace_add(const void *ctx, const char *phase, double t0, double t1);   // MM355_TRACE timeline (no-op when unset)

@@ -8,6 +8,7 @@
 #include <numeric>
 #include <mutex>
 #include <atomic>
+#include <functional>
 #include "mm355_pipeline.h"
 #include "mm355_rmq.h"
 
@@ -360,6 +361,7 @@ static DevAnchors dev_anchors(mm355_ctx *c)
 }
 
 // ------------------------------------------------------------------ stage drivers
+void (*mm355_parallel_hook)(int64_t n, const std::function<void(int64_t)> &f) = 0;
 int mm355_run_pack(mm355_ctx *c, int64_t n_reads, const char *const *seqs, const int32_t *lens)
 {
 	HIPCHK(hipSetDevice(c->dev));
@@ -368,8 +370,20 @@ int mm355_run_pack(mm355_ctx *c, int64_t n_reads, const char *const *seqs, const
 	int64_t off = 0, bases = 0;
 	for (int64_t i = 0; i < n_reads; ++i) { hb.roff[i] = off; off += ((int64_t)lens[i] + 15) / 16 * 16; bases += lens[i]; }
 	hb.roff[n_reads] = off; hb.n_bytes = off; hb.n_bases = bases;
-	hb.seq.assign((size_t)off + 32, 'N');
-	for (int64_t i = 0; i < n_reads; ++i) if (lens[i] > 0) memcpy(&hb.seq[hb.roff[i]], seqs[i], lens[i]);
+	// the packed copy of the reads: reads in parallel on the host pool (mm355_parallel_hook, set by mm355_map.hip), only the padding is filled
+	// (this is inside the timed region of the drop-in call: 70 MB per sub-batch were filled with 'N' and then copied by one thread)
+	hb.seq.resize((size_t)off + 32);
+	memset(&hb.seq[(size_t)off], 'N', 32);
+	{
+		auto one = [&](int64_t i) {
+			const int64_t o = hb.roff[i], e = hb.roff[i + 1];
+			const int64_t l = lens[i] > 0? lens[i] : 0;
+			if (l) memcpy(&hb.seq[o], seqs[i], (size_t)l);
+			if (e > o + l) memset(&hb.seq[o + l], 'N', (size_t)(e - o - l));
+		};
+		if (mm355_parallel_hook && n_reads >= 256) mm355_parallel_hook(n_reads, one);
+		else for (int64_t i = 0; i < n_reads; ++i) one(i);
+	}
 	std::iota(hb.order.begin(), hb.order.end(), 0);
 	std::stable_sort(hb.order.begin(), hb.order.end(), [&](int32_t x, int32_t y) { return hb.rlen[x] > hb.rlen[y]; });
 	size_t nb = (size_t)off + 32, nr = (size_t)std::max<int64_t>(n_reads, 1);
@@ -515,7 +529,8 @@ int mm355_run_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		// anchor-rich batches (GRCh38-scale): cull + per-read LDS sort; only the reads with equal keys among what is left -- where the tie order of
 		// the reference's unstable sort is observable -- go through the literal emulation (MM355_FAST_SORT=0/1 forces the choice)
 		static const int force = [] { const char *e = getenv("MM355_FAST_SORT"); return e? atoi(e) : -1; }();
-		const bool fast = force >= 0? force != 0 : (n_reads > 0 && c->hb.tot_a / n_reads >= 2048);
+		bool fast = force >= 0? force != 0 : (n_reads > 0 && c->hb.tot_a / n_reads >= 2048);
+		if (fast && !mm355_cull_sort_fits(c)) fast = false;   // (position + index do not fit a 64-bit word: a 2^40-base reference with 2^22 anchors on a read -- the literal path sorts anything)
 		if (fast) {
 			const bool cull_env = [] { const char *e = getenv("MM355_CULL"); return !(e && atoi(e) == 0); }();   // (read per call: the tests switch it)
 			const bool rmq_primary = (pr.flag & MMF_RMQ) != 0;   // mg_lchain_rmq as the primary chainer sees every anchor (its windows are not mg_lchain_dp's)
