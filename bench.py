@@ -564,8 +564,8 @@ def main():
             (4, "k_seed_expand", expand_bytes, "8*n_a_multi + 16*n_a (pos[] entry read + anchor written)"),
             (5, "k_cull", 16 * n_a + 8 * n_a + 8 * n_keep, "16*n_a read + 8*n_a position words + 8*n_kept survivors written"),
             (6, "k_asort", 16 * n_keep + 32 * n_keep, "8*n_kept words in + out, 16*n_kept anchors gathered + written"),
-            (7, "k_sort_level_mw<1024> (radix_sort_128x emulation, buckets > 16384)", 32 * n_lit * 2, "2 levels of 2*16 B over the anchors of the reads with equal keys"),
-            (20, "k_sort_level_mw<256> (radix_sort_128x emulation, buckets > 2048)", 32 * n_lit, "2*16 B over the anchors of the reads with equal keys"),
+            (7, "k_sort_level_mw<1024> (radix_sort_128x emulation, buckets > 16384)", 32 * n_lit * 2, "2 levels of 2*16 B over the anchors of the reads with equal keys; ms_per_launch: all level launches of a sub-batch together (7 for GRCh38), traffic: bytes of ONE of them"),
+            (20, "k_sort_level_mw<256> (radix_sort_128x emulation, buckets > 2048)", 32 * n_lit, "2*16 B over the anchors of the reads with equal keys; ms_per_launch: all level launches of a sub-batch together, traffic: bytes of ONE of them"),
             (21, "k_sort_tasks (radix_sort_128x emulation, one wave per bucket)", 32 * n_lit, "2*16 B over the anchors of the reads with equal keys"),
             (22, "k_tie_copy + k_asort + k_tie_tcnt (plain sort of the reads with equal keys)", 56 * n_lit, "(16 + 16 + 8 + 8 + 8) B per anchor of those reads"),
             (8, "k_chain_segments", 16 * n_keep, "16*n_kept"),
