@@ -313,6 +313,7 @@ __global__ __launch_bounds__(256) void k_tie_emit(const int32_t *list, int n_lis
 static int bits_for(uint64_t v) { int b = 1; while (b < 64 && (1ULL << b) <= v) ++b; return b; }   // bits that hold the values 0 .. v
 
 #define CS_SMALL_CAP 2048
+#define CS_MID_CAP   8192
 #define CS_BIG_CAP   16384
 
 bool mm355_cull_sort_fits(const mm355_ctx *c)
@@ -384,19 +385,20 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	HIPCHK(mm355_wait_stream(c->st));
 	mm355_trace_add(c, "s:cull", t0, mm355_now_ms());
 	int64_t tk = 0;
-	int n_small = 0, n_big = 0;
-	for (int i = 0; i < n_reads; ++i) { h_off2[i] = tk; tk += h_nk[i]; if (h_nk[i] > CS_SMALL_CAP) ++n_big; else if (h_nk[i] > 0) ++n_small; }
+	int n_small = 0, n_mid = 0, n_big = 0;
+	for (int i = 0; i < n_reads; ++i) { h_off2[i] = tk; tk += h_nk[i]; if (h_nk[i] > CS_MID_CAP) ++n_big; else if (h_nk[i] > CS_SMALL_CAP) ++n_mid; else if (h_nk[i] > 0) ++n_small; }
 	h_off2[n_reads] = tk;
-	{   // small reads in index order, big ones by size (longest first)
-		int is = 0, ib2 = n_small;
-		for (int i = 0; i < n_reads; ++i) { if (h_nk[i] > CS_SMALL_CAP) h_list[ib2++] = i; else if (h_nk[i] > 0) h_list[is++] = i; }
-		std::stable_sort(h_list + n_small, h_list + n_small + n_big, [&](int32_t x, int32_t y) { return h_nk[x] > h_nk[y]; });
+	{   // three size classes (16 KB / 64 KB / 128 KB of LDS per block): small reads in index order, the others by size (longest first)
+		int is = 0, im = n_small, ib2 = n_small + n_mid;
+		for (int i = 0; i < n_reads; ++i) { if (h_nk[i] > CS_MID_CAP) h_list[ib2++] = i; else if (h_nk[i] > CS_SMALL_CAP) h_list[im++] = i; else if (h_nk[i] > 0) h_list[is++] = i; }
+		std::stable_sort(h_list + n_small, h_list + n_small + n_mid, [&](int32_t x, int32_t y) { return h_nk[x] > h_nk[y]; });
+		std::stable_sort(h_list + n_small + n_mid, h_list + n_small + n_mid + n_big, [&](int32_t x, int32_t y) { return h_nk[x] > h_nk[y]; });
 	}
 	if (c->b.ensure(((size_t)tk + 64) * 16)) return MM355_ENOMEM;
 	int32_t *d_list = c->cs_list.as<int32_t>();
 	int64_t *d_off2 = c->aoff2.as<int64_t>();
 	HIPCHK(hipMemcpyAsync(d_off2, h_off2, (nr + 1) * 8, hipMemcpyHostToDevice, c->st));
-	if (n_small + n_big) HIPCHK(hipMemcpyAsync(d_list, h_list, (size_t)(n_small + n_big) * 4, hipMemcpyHostToDevice, c->st));
+	if (n_small + n_mid + n_big) HIPCHK(hipMemcpyAsync(d_list, h_list, (size_t)(n_small + n_mid + n_big) * 4, hipMemcpyHostToDevice, c->st));
 	const double t1 = mm355_now_ms();
 	HIPCHK(hipMemsetAsync(c->sort_flag.p, 0, nr, c->st));   // (reads without survivors are not listed: their flag stays 0)
 	mm355_kt(c, KT_ASORT, 0, c->st);
@@ -404,8 +406,13 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	                                c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
 	// (per call, not once per process: the attribute belongs to the function on the CURRENT device, and one process may drive several)
 	if (hipFuncSetAttribute((const void*)k_asort<1024, CS_BIG_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_BIG_CAP * 8) != hipSuccess) return MM355_EHIP;
+	if (n_mid) {   // (64 KB: two blocks per CU, and a block that does not need a whole CU to itself beside the other contexts' kernels)
+		if (hipFuncSetAttribute((const void*)k_asort<512, CS_MID_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_MID_CAP * 8) != hipSuccess) return MM355_EHIP;
+		hipLaunchKernelGGL((k_asort<512, CS_MID_CAP>), dim3((unsigned)n_mid), dim3(512), CS_MID_CAP * 8, c->st, d_list + n_small, n_mid, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
+		                   c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
+	}
 	if (n_big) {
-		hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_big), dim3(1024), CS_BIG_CAP * 8, c->st, d_list + n_small, n_big, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
+		hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_big), dim3(1024), CS_BIG_CAP * 8, c->st, d_list + n_small + n_mid, n_big, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
 		                   c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
 	}
 	mm355_kt(c, KT_ASORT, 1, c->st);

@@ -196,3 +196,15 @@ def test_anchor_cull_and_sort_mid_scale(human_mid):
     finally:
         sr.close()
         L.mm355_index_free(idx)
+
+
+def test_anchor_cull_in_many_passes(built):
+    """k_cull with 8192-bin tables (1 KB per bitmap level instead of 48 KB) and 256 threads: the mid-scale genome's 38 k bins then take five
+    passes over a read's anchors -- the pass boundaries and their guard bins, which only the 3.1-Gbp genome reaches with the default table --
+    and everything test_anchor_cull_and_sort_mid_scale checks must still hold (a child process: the switches are read once)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MM355_CULL_WPL="256", MM355_CULL_MAX_PASS="16", MM355_CULL_NT="256")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_human.py", "-x", "-q", "-k", "test_anchor_cull_and_sort_mid_scale"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
