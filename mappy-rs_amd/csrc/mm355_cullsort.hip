@@ -27,6 +27,7 @@
 #include "mm355_wave.h"
 
 #define CS_WPL_MAX 12288               // most words per bitmap level: 393216 bins, 3 x 48 KB of LDS (the kernel takes the number as an argument)
+#define CS_WPL_DEFAULT 6144            // ... and the default: 3 x 24 KB, so that a block needs half a CU, not a whole one, beside the other contexts' kernels (+1.5 % in the bench; twice the passes)
 #define CS_GUARD 3                     // bins a run is followed to either side of an anchor's own bin
 
 
@@ -351,14 +352,14 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	static const int env_wpl = [] { const char *e = getenv("MM355_CULL_WPL"); return e? atoi(e) : 0; }();
 	static const int env_nt = [] { const char *e = getenv("MM355_CULL_NT"); return e? atoi(e) : 0; }();
 	static const int env_sh = [] { const char *e = getenv("MM355_CULL_SH"); return e? atoi(e) : 0; }();
-	static const int max_pass = [] { const char *e = getenv("MM355_CULL_MAX_PASS"); return e && atoi(e) > 0? atoi(e) : 4; }();
-	cp.wpl = env_wpl >= 256 && env_wpl <= CS_WPL_MAX? (env_wpl & ~3) : CS_WPL_MAX;
+	static const int max_pass = [] { const char *e = getenv("MM355_CULL_MAX_PASS"); return e && atoi(e) > 0? atoi(e) : 8; }();
+	cp.wpl = env_wpl >= 256 && env_wpl <= CS_WPL_MAX? (env_wpl & ~3) : CS_WPL_DEFAULT;
 	cp.bpp = cp.wpl * 32 - 2 * CS_GUARD;
 	const int cull_nt = env_nt == 256 || env_nt == 512? env_nt : 1024;
 	if (do_cull) {
 		cp.sh = 0; while ((1LL << cp.sh) < D) ++cp.sh;
 		if (env_sh > cp.sh) cp.sh = env_sh;
-		for (;; ++cp.sh) {   // at most four passes over a read's anchors: wider bins beyond that
+		for (;; ++cp.sh) {   // at most max_pass passes over a read's anchors: wider bins beyond that
 			const uint64_t bins = ((2 * cp.tot_len) >> cp.sh) + 1;
 			cp.n_pass = (int)((bins + cp.bpp - 1) / cp.bpp);
 			if (cp.n_pass <= max_pass) break;
@@ -389,11 +390,16 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	for (int i = 0; i < n_reads; ++i) { h_off2[i] = tk; tk += h_nk[i]; if (h_nk[i] > CS_MID_CAP) ++n_big; else if (h_nk[i] > CS_SMALL_CAP) ++n_mid; else if (h_nk[i] > 0) ++n_small; }
 	h_off2[n_reads] = tk;
 	{   // three size classes (16 KB / 64 KB / 128 KB of LDS per block): small reads in index order, the others by size (longest first)
-		int is = 0, im = n_small, ib2 = n_small + n_mid;
+		int is = 0, ib2 = n_small, im = n_small + n_big;   // [small][big][mid]
 		for (int i = 0; i < n_reads; ++i) { if (h_nk[i] > CS_MID_CAP) h_list[ib2++] = i; else if (h_nk[i] > CS_SMALL_CAP) h_list[im++] = i; else if (h_nk[i] > 0) h_list[is++] = i; }
-		std::stable_sort(h_list + n_small, h_list + n_small + n_mid, [&](int32_t x, int32_t y) { return h_nk[x] > h_nk[y]; });
-		std::stable_sort(h_list + n_small + n_mid, h_list + n_small + n_mid + n_big, [&](int32_t x, int32_t y) { return h_nk[x] > h_nk[y]; });
+		std::stable_sort(h_list + n_small, h_list + n_small + n_big, [&](int32_t x, int32_t y) { return h_nk[x] > h_nk[y]; });
+		std::stable_sort(h_list + n_small + n_big, h_list + n_small + n_big + n_mid, [&](int32_t x, int32_t y) { return h_nk[x] > h_nk[y]; });
 	}
+	// No 128-KB class by default: reads with more than CS_MID_CAP survivors go through the 64-KB class and its HBM stages (two blocks per CU, and
+	// no block that waits for a whole free CU beside the other contexts' kernels: k_asort 84 -> 52 ms per step in the bench, 1380 against 1351
+	// Mbases/s over three alternating pairs).  MM355_ASORT_BIG=1 brings the <1024, 16384> class back.
+	static const bool big_class = [] { const char *e = getenv("MM355_ASORT_BIG"); return e && atoi(e) != 0; }();
+	if (!big_class) { n_mid += n_big; n_big = 0; }
 	if (c->b.ensure(((size_t)tk + 64) * 16)) return MM355_ENOMEM;
 	int32_t *d_list = c->cs_list.as<int32_t>();
 	int64_t *d_off2 = c->aoff2.as<int64_t>();
@@ -408,11 +414,11 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	if (hipFuncSetAttribute((const void*)k_asort<1024, CS_BIG_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_BIG_CAP * 8) != hipSuccess) return MM355_EHIP;
 	if (n_mid) {   // (64 KB: two blocks per CU, and a block that does not need a whole CU to itself beside the other contexts' kernels)
 		if (hipFuncSetAttribute((const void*)k_asort<512, CS_MID_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_MID_CAP * 8) != hipSuccess) return MM355_EHIP;
-		hipLaunchKernelGGL((k_asort<512, CS_MID_CAP>), dim3((unsigned)n_mid), dim3(512), CS_MID_CAP * 8, c->st, d_list + n_small, n_mid, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
+		hipLaunchKernelGGL((k_asort<512, CS_MID_CAP>), dim3((unsigned)n_mid), dim3(512), CS_MID_CAP * 8, c->st, d_list + n_small + n_big, n_mid, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
 		                   c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
 	}
 	if (n_big) {
-		hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_big), dim3(1024), CS_BIG_CAP * 8, c->st, d_list + n_small + n_mid, n_big, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
+		hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_big), dim3(1024), CS_BIG_CAP * 8, c->st, d_list + n_small, n_big, aoff, d_off2, d_nk, c->a.as<mm128>(), surv,
 		                   c->b.as<mm128>(), c->sort_flag.as<uint8_t>(), cp.ib);
 	}
 	mm355_kt(c, KT_ASORT, 1, c->st);
@@ -457,8 +463,13 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		// positions are, so that the emulation only descends into the buckets that hold some (MM355_TIE_SKIP=0: it sorts everything)
 		static const bool tie_skip = [] { const char *e = getenv("MM355_TIE_SKIP"); return !(e && atoi(e) == 0); }();
 		const uint64_t *full_sorted = do_cull? keys : surv;
-		if (do_cull) hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_tie), dim3(1024), CS_BIG_CAP * 8, c->st, d_tl, n_tie, aoff, d_off2, (const int32_t*)0, c->a.as<mm128>(), keys,
-		                                (mm128*)0, (uint8_t*)0, cp.ib);
+		if (do_cull && big_class) hipLaunchKernelGGL((k_asort<1024, CS_BIG_CAP>), dim3((unsigned)n_tie), dim3(1024), CS_BIG_CAP * 8, c->st, d_tl, n_tie, aoff, d_off2, (const int32_t*)0, c->a.as<mm128>(), keys,
+		                                             (mm128*)0, (uint8_t*)0, cp.ib);
+		else if (do_cull) {
+			if (hipFuncSetAttribute((const void*)k_asort<512, CS_MID_CAP>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_MID_CAP * 8) != hipSuccess) return MM355_EHIP;
+			hipLaunchKernelGGL((k_asort<512, CS_MID_CAP>), dim3((unsigned)n_tie), dim3(512), CS_MID_CAP * 8, c->st, d_tl, n_tie, aoff, d_off2, (const int32_t*)0, c->a.as<mm128>(), keys,
+			                   (mm128*)0, (uint8_t*)0, cp.ib);
+		}
 		if (tie_skip) hipLaunchKernelGGL(k_tie_tcnt, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, full_sorted, c->tie_tcnt.as<int32_t>(), cp.ib);
 		mm355_kt(c, KT_TIE_AUX, 1, c->st);
 		DevAnchors at; memset(&at, 0, sizeof(at));

@@ -327,6 +327,7 @@ extern "C" int mm355_map_resident(mm355_ctx_t *c, const mm355_mapopt_t *mo, int 
 	DevParams pr = mm355_make_params(mo, mi);
 	const int64_t n_reads = c->hb.n_reads;
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
+	{ static const int tm = [] { const char *e = getenv("MM355_TIMERS"); return e? atoi(e) : -1; }(); c->timers_on = tm > 0 || (tm < 0 && n_reads >= 16); }
 	c->n_arena = 0;
 	c->stats.n_reads = n_reads; c->stats.n_bases = c->hb.n_bases;
 	HIPCHK(hipMemsetAsync(c->counters.p, 0, CTR_BYTES, c->st));

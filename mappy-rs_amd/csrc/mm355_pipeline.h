@@ -102,6 +102,7 @@ struct mm355_ctx {
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
 	std::vector<hipEvent_t> tev; std::vector<double*> tacc; int n_tpend = 0;   // lazy stage timers (EvTimer, mm355_kt)
+	bool timers_on = true;             // off for calls of fewer than 16 reads (two event records per kernel are a fifth of a single-read call); MM355_TIMERS=1 / 0 forces
 	int kt_open[KT_N] = {};   // open mm355_kt pair of a slot: its event-pair index + 1
 	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[24] = {}, dp_ev0[24] = {}, dp_ev1[24] = {};
 	HostBatch hb;
@@ -139,8 +140,9 @@ void mm355_timers_resolve(mm355_ctx *c);
 void mm355_kprof_dump(mm355_ctx *c);
 struct EvTimer {
 	mm355_ctx *c; int slot;
-	EvTimer(mm355_ctx *c_, double *a) : c(c_)
+	EvTimer(mm355_ctx *c_, double *a) : c(c_), slot(-1)
 	{
+		if (!c->timers_on) return;
 		if (c->n_tpend >= 120) mm355_timers_resolve(c);
 		slot = c->n_tpend++;
 		while ((int)c->tev.size() < 2 * (slot + 1)) { hipEvent_t e = 0; (void)hipEventCreate(&e); c->tev.push_back(e); }
@@ -148,7 +150,7 @@ struct EvTimer {
 		c->tacc[slot] = a;
 		(void)hipEventRecord(c->tev[2 * slot], c->st);
 	}
-	~EvTimer() { (void)hipEventRecord(c->tev[2 * slot + 1], c->st); }
+	~EvTimer() { if (slot >= 0) (void)hipEventRecord(c->tev[2 * slot + 1], c->st); }
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "[mm355] HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return MM355_EHIP; } } while (0)

@@ -67,7 +67,7 @@ void mm355_timers_resolve(mm355_ctx *c)
 void mm355_kt(void *kt, int slot, int end, hipStream_t st)
 {
 	mm355_ctx *c = (mm355_ctx*)kt;
-	if (c == 0 || slot < 0 || slot >= KT_N) return;
+	if (c == 0 || slot < 0 || slot >= KT_N || !c->timers_on) return;
 	if (!end) {
 		if (c->n_tpend >= 120) mm355_timers_resolve(c);
 		const int k = c->n_tpend++;
@@ -594,14 +594,7 @@ int mm355_run_chain(mm355_ctx *c, const DevParams &pr)
 	// segment lists live in scratch that is free at this point: z (8 B/anchor) and wk (16 B/anchor) hold >= tot_a/2 16-byte entries each
 	{ EvTimer t(c, &c->stats.ms_chain); if (mm355_launch_chain(pr, b, a, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, c->z.p, c->wk.p, (unsigned int*)(c->counters.as<unsigned long long>() + 6), c->d_chunks.p, (int)n_chunks, c->st, c)) return MM355_EHIP; }
 	HIPCHK(hipGetLastError());
-	unsigned long long pairs[CTR_PAIRS_WORDS];   // spread over 64 words (slot = block & 63): one word takes ~88 atomics per microsecond
-	HIPCHK(hipMemcpyAsync(pairs, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, CTR_PAIRS_WORDS * 8, hipMemcpyDeviceToHost, c->st));
-	HIPCHK(mm355_wait_stream(c->st));
-	c->stats.chain_pairs = 0;
-	for (int k = 0; k < CTR_PAIRS_WORDS; ++k) c->stats.chain_pairs += (int64_t)pairs[k];
-	c->stats.chain_pairs_big = 0;
-	for (int k = 32; k < CTR_PAIRS_WORDS; ++k) c->stats.chain_pairs_big += (int64_t)pairs[k];   // (k_chain_big's share)
-	return 0;
+	return 0;   // (no synchronisation here: the pair counters are statistics, mm355_run_backtrack reads them behind its own)
 }
 
 // MM_F_RMQ presets: no device chaining -- every sorted anchor of the read goes to the host chainer (mm355_glue_chain_rmq)
@@ -629,7 +622,14 @@ int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
 		HIPCHK(hipMemcpyAsync(hb.n_u.data(), c->n_u.p, n * 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipMemcpyAsync(hb.n_v.data(), c->n_v.p, n * 4, hipMemcpyDeviceToHost, c->st));
 	}
-	return check_err(c);
+	unsigned long long pairs[CTR_PAIRS_WORDS];   // k_chain_*'s counters, spread over 64 words (slot = block & 63): one word takes ~88 atomics per microsecond
+	HIPCHK(hipMemcpyAsync(pairs, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, CTR_PAIRS_WORDS * 8, hipMemcpyDeviceToHost, c->st));
+	const int rc = check_err(c);   // (synchronises the stream)
+	c->stats.chain_pairs = 0;
+	for (int k = 0; k < CTR_PAIRS_WORDS; ++k) c->stats.chain_pairs += (int64_t)pairs[k];
+	c->stats.chain_pairs_big = 0;
+	for (int k = 32; k < CTR_PAIRS_WORDS; ++k) c->stats.chain_pairs_big += (int64_t)pairs[k];   // (k_chain_big's share)
+	return rc;
 }
 
 // mg_lchain_rmq on the device (mm355_rmq.hip), as U:map.c::mm_map_frag calls it:
