@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_tie_copy(const int32_t *list, int n_lis
 }
 // tcnt[d + i] = equal-position neighbour pairs among the first i + 1 elements of the read's plainly sorted array (sorted[o ..]): the literal
 // emulation skips every bucket without such a pair -- its content is unique and comes from the plain sort (WalkScratch::tcnt)
-__global__ __launch_bounds__(256) void k_tie_tcnt(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const uint64_t *sorted, int32_t *tcnt, int ib)
+__global__ __launch_bounds__(256) void k_tie_tcnt(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const uint64_t *sorted, int32_t *tcnt, int ib, int kept_only)
 {
 	__shared__ uint32_t s_w[4];
 	const int t = blockIdx.x;
@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256) void k_tie_tcnt(const int32_t *list, int n_lis
 	uint32_t base = 0;
 	for (uint32_t b0 = 0; b0 < n; b0 += 256) {
 		const uint32_t i = b0 + tid;
-		const bool tie = i > 0 && i < n && (sorted[o + i] >> ib) == (sorted[o + i - 1] >> ib);
+		// (kept_only: equal positions share a bin of k_cull, hence its decision -- a pair of culled anchors is dropped whatever its order, and
+		// the emulation need not descend into a bucket for it)
+		const bool tie = i > 0 && i < n && (sorted[o + i] >> ib) == (sorted[o + i - 1] >> ib) && (!kept_only || (sorted[o + i] & 1ULL));
 		const unsigned long long mk = __ballot(tie);
 		if (lane == 0) s_w[wv] = (uint32_t)__popcll(mk);
 		__syncthreads();
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void k_tie_tcnt(const int32_t *list, int n_lis
 // ... and after the emulation: the kept anchors of the read's sorted array, in order.  Inside a run of equal positions the emulation's
 // result (and the decision it carried); everywhere else the plain sort's element
 __global__ __launch_bounds__(256) void k_tie_emit(const int32_t *list, int n_list, const int64_t *aoff, const int64_t *toff, const int64_t *aoff2, const mm128 *a, const mm128 *ta,
-                                                  const uint64_t *sorted, mm128 *out, int ib)
+                                                  const uint64_t *sorted, mm128 *out, int ib, int kept_only)
 {
 	__shared__ uint32_t s_w[4];
 	const int t = blockIdx.x;
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(256) void k_tie_emit(const int32_t *list, int n_lis
 		bool keep = false; mm128 el; el.x = el.y = 0;
 		if (i < n) {
 			const uint64_t w = sorted[o + i], k = w >> ib;
-			const bool run = (i > 0 && (sorted[o + i - 1] >> ib) == k) || (i + 1 < n && (sorted[o + i + 1] >> ib) == k);
+			const bool run = ((i > 0 && (sorted[o + i - 1] >> ib) == k) || (i + 1 < n && (sorted[o + i + 1] >> ib) == k)) && (!kept_only || (w & 1ULL));   // (a culled run: its bucket may have been skipped, and it is dropped anyway)
 			if (run) { el = ta[d + i]; keep = el.y >> 63 != 0; el.y &= ~(1ULL << 63); }
 			else { el = a[o + (w >> 1 & im)]; keep = (w & 1ULL) != 0; }
 		}
@@ -470,7 +472,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 			hipLaunchKernelGGL((k_asort<512, CS_MID_CAP>), dim3((unsigned)n_tie), dim3(512), CS_MID_CAP * 8, c->st, d_tl, n_tie, aoff, d_off2, (const int32_t*)0, c->a.as<mm128>(), keys,
 			                   (mm128*)0, (uint8_t*)0, cp.ib);
 		}
-		if (tie_skip) hipLaunchKernelGGL(k_tie_tcnt, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, full_sorted, c->tie_tcnt.as<int32_t>(), cp.ib);
+		if (tie_skip) hipLaunchKernelGGL(k_tie_tcnt, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, full_sorted, c->tie_tcnt.as<int32_t>(), cp.ib, do_cull? 1 : 0);
 		mm355_kt(c, KT_TIE_AUX, 1, c->st);
 		DevAnchors at; memset(&at, 0, sizeof(at));
 		at.aoff = d_toff; at.a = c->tie_a.as<mm128>(); at.b = c->tie_b.as<mm128>(); at.f = c->tie_f.as<int32_t>(); at.p = c->tie_p.as<int32_t>(); at.t8 = c->tie_t8.as<uint8_t>(); at.tcnt = tie_skip? c->tie_tcnt.as<int32_t>() : 0;
@@ -478,7 +480,7 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 		if (c->sort_tasks.ensure(mm355_sort_buf_bytes(task_cap))) return MM355_ENOMEM;
 		DevBatch bt; memset(&bt, 0, sizeof(bt));
 		if (mm355_launch_sort(bt, at, c->err.as<int>(), ht, nb, nm, ns, (size_t)tt, c->sort_tasks.p, task_cap, c->st, c, mm355_sort_levels(c->mi))) return MM355_EHIP;
-		hipLaunchKernelGGL(k_tie_emit, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, d_off2, c->a.as<mm128>(), c->tie_a.as<mm128>(), full_sorted, c->b.as<mm128>(), cp.ib);
+		hipLaunchKernelGGL(k_tie_emit, dim3((unsigned)n_tie), dim3(256), 0, c->st, d_tl, n_tie, aoff, d_toff, d_off2, c->a.as<mm128>(), c->tie_a.as<mm128>(), full_sorted, c->b.as<mm128>(), cp.ib, do_cull && tie_skip? 1 : 0);
 		HIPCHK(hipGetLastError());
 		HIPCHK(mm355_wait_stream(c->st));   // (the pinned lists above are reused by the next call)
 		mm355_trace_add(c, "s:levels", t2, mm355_now_ms());
