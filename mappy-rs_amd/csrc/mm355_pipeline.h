@@ -102,6 +102,8 @@ struct mm355_ctx {
 	mm355_stats_t stats;
 	hipEvent_t ev0 = 0, ev1 = 0;
 	std::vector<hipEvent_t> tev; std::vector<double*> tacc; int n_tpend = 0;   // lazy stage timers (EvTimer, mm355_kt)
+	unsigned long long pairs_land[64] = {};   // landing zone of the chain stage's pair counters (mm355_run_backtrack)
+	int pool_slot = -1;                // >= 0: st / aux_st are the device pool's (mm355_ctx_create), not this context's
 	bool timers_on = true;             // off for calls of fewer than 16 reads (two event records per kernel are a fifth of a single-read call); MM355_TIMERS=1 / 0 forces
 	int kt_open[KT_N] = {};   // open mm355_kt pair of a slot: its event-pair index + 1
 	hipStream_t dp_st[16] = {}; hipEvent_t dp_ev[24] = {}, dp_ev0[24] = {}, dp_ev1[24] = {};

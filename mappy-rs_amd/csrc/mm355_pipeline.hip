@@ -100,6 +100,9 @@ extern "C" int mm355_device_synchronize(int device_id)
 // Measured (round 3, default bench, alternating runs on one box): shared pool 853 / 795 Mbases/s against 876 / 865 with eight streams per
 // context -- the exact classes and the long chains of different contexts then wait for one another on their one stream, which costs more
 // than the occasional held turn.  Kept as an experiment switch (MM355_DP_SHARED_STREAMS=1); the default is a set of streams per context.
+struct StreamPool { hipStream_t main[8], aux[8]; bool ready; uint8_t used; };   // main + sort stream of up to eight contexts per device (mm355_ctx_create)
+static StreamPool g_pool[16];
+static std::mutex g_pool_mu;
 bool mm355_dp_shared_streams() { static const bool on = [] { const char *e = getenv("MM355_DP_SHARED_STREAMS"); return e && atoi(e) != 0; }(); return on; }
 int mm355_dp_stream(mm355_ctx *c, int sidx, hipStream_t *out)
 {
@@ -143,7 +146,25 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		int lo = 0, hi = 0;
 		static const bool use_prio = [] { const char *e = getenv("MM355_STREAM_PRIO"); return !(e && atoi(e) == 0); }();
 		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest (numerically lower)
-		if (use_prio && hi < lo) HIPCHK(hipStreamCreateWithPriority(&c->st, hipStreamDefault, hi));
+		// The main and the sort stream of the first eight contexts of a device come from a pool that is created in one go -- eight main streams, then
+		// eight sort streams: the runtime multiplexes the streams of a priority level over eight hardware queues, handed out in turn at stream
+		// creation, and a kernel waits for everything in front of it on its QUEUE.  Created context by context (main, sort, main, sort ...) the main
+		// streams of contexts i and i + 4 shared a queue, and so did their sort streams: the front of one context waited for the other's kernels.
+		// From the pool, the two streams of a context share a queue with each other and with no other context (1401 against 1350 Mbases/s, six and
+		// four alternating runs; MM355_STREAM_POOL=0: streams of its own for every context, as before).
+		static const bool pool_on = [] { const char *e = getenv("MM355_STREAM_POOL"); return !(e && atoi(e) == 0); }();
+		if (pool_on && use_prio && hi < lo) {
+			std::lock_guard<std::mutex> lk(g_pool_mu);
+			StreamPool &P = g_pool[device_id & 15];
+			if (!P.ready) {
+				for (int i = 0; i < 8; ++i) HIPCHK(hipStreamCreateWithPriority(&P.main[i], hipStreamDefault, hi));
+				for (int i = 0; i < 8; ++i) HIPCHK(hipStreamCreateWithPriority(&P.aux[i], hipStreamNonBlocking, hi));
+				P.ready = true;
+			}
+			for (int k = 0; k < 8; ++k) if (!(P.used >> k & 1)) { P.used |= (uint8_t)(1u << k); c->pool_slot = k; c->st = P.main[k]; c->aux_st = P.aux[k]; break; }
+		}
+		if (c->st) {}
+		else if (use_prio && hi < lo) HIPCHK(hipStreamCreateWithPriority(&c->st, hipStreamDefault, hi));
 		else HIPCHK(hipStreamCreate(&c->st));
 		c->prio_low = use_prio && hi < lo? lo : 0; c->prio_high = use_prio && hi < lo? hi : 0; c->use_prio = use_prio && hi < lo;
 		// The streams of the extension classes are created here, back to back under a lock: the runtime hands out hardware queues round-robin at
@@ -157,21 +178,21 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 				if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, c->prio_low));
 				else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[i], hipStreamNonBlocking));
 			}
-		} else { hipStream_t t; int rc = mm355_dp_stream(c, 0, &t); if (rc) { delete c; return rc; } }
+		} else { hipStream_t t; int rc = mm355_dp_stream(c, 0, &t); if (rc) { mm355_ctx_destroy(c); return rc; } }
 		// the stream of the block-level sort of anchor-rich reads: same consideration (7 streams per context, 8 hardware queues)
-		if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->aux_st, hipStreamNonBlocking, c->prio_high)); else HIPCHK(hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking));
+		if (c->aux_st) {} else if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->aux_st, hipStreamNonBlocking, c->prio_high)); else HIPCHK(hipStreamCreateWithFlags(&c->aux_st, hipStreamNonBlocking));
 		HIPCHK(hipEventCreateWithFlags(&c->aux_ev, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->aux_ev2, hipEventDisableTiming));
 	}
 	HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
 	// the index replica of this device (shared by all its contexts; created on first use: H2D from the host image or a peer copy)
 	mm355_replica rp;
-	{ int rc = mm355_index_replica(mi, device_id, &rp); if (rc) { delete c; return rc; } }
+	{ int rc = mm355_index_replica(mi, device_id, &rp); if (rc) { mm355_ctx_destroy(c); return rc; } }
 	c->dix.slots = (const mm355_slot*)rp.slots; c->dix.line_mask = mi->n_lines - 1;
 	c->dix.pos = (const uint64_t*)rp.pos; c->dix.S2 = (const uint32_t*)rp.S2; c->dix.nr = (const uint64_t*)rp.nr; c->dix.n_nr = rp.n_nr;
 	c->dix.seq_off = (const uint64_t*)rp.seq_off; c->dix.seq_len = (const uint32_t*)rp.seq_len;
 	c->dix.k = mi->k; c->dix.w = mi->w; c->dix.b = mi->b; c->dix.flag = mi->flag; c->dix.n_seq = mi->n_seq;
-	if (c->counters.ensure(CTR_BYTES) || c->err.ensure(16)) { delete c; return MM355_ENOMEM; }
-	if (getenv("MM355_KPROF")) { if (c->kprof.ensure(512)) { delete c; return MM355_ENOMEM; } HIPCHK(hipMemset(c->kprof.p, 0, 512)); }
+	if (c->counters.ensure(CTR_BYTES) || c->err.ensure(16)) { mm355_ctx_destroy(c); return MM355_ENOMEM; }
+	if (getenv("MM355_KPROF")) { if (c->kprof.ensure(512)) { mm355_ctx_destroy(c); return MM355_ENOMEM; } HIPCHK(hipMemset(c->kprof.p, 0, 512)); }
 	c->n_tpend = 0; memset(&c->stats, 0, sizeof(c->stats));
 	*out = c;
 	return 0;
@@ -321,13 +342,14 @@ extern "C" void mm355_ctx_destroy(mm355_ctx_t *c)
 	for (int i = 0; i < 16; ++i) if (c->dp_st[i]) (void)hipStreamDestroy(c->dp_st[i]);
 	for (int i = 0; i < 24; ++i) { if (c->dp_ev[i]) (void)hipEventDestroy(c->dp_ev[i]); if (c->dp_ev0[i]) (void)hipEventDestroy(c->dp_ev0[i]); if (c->dp_ev1[i]) (void)hipEventDestroy(c->dp_ev1[i]); }
 	if (c->dp_up_ev) (void)hipEventDestroy(c->dp_up_ev);
-	if (c->aux_st) (void)hipStreamDestroy(c->aux_st);
+	if (c->aux_st && c->pool_slot < 0) (void)hipStreamDestroy(c->aux_st);
 	if (c->aux_ev) (void)hipEventDestroy(c->aux_ev);
 	if (c->aux_ev2) (void)hipEventDestroy(c->aux_ev2);
 	for (hipEvent_t e : c->tev) (void)hipEventDestroy(e);
 	if (c->ev0) (void)hipEventDestroy(c->ev0);
 	if (c->ev1) (void)hipEventDestroy(c->ev1);
-	if (c->st) (void)hipStreamDestroy(c->st);
+	if (c->st && c->pool_slot < 0) (void)hipStreamDestroy(c->st);
+	if (c->pool_slot >= 0) { std::lock_guard<std::mutex> lk(g_pool_mu); g_pool[c->dev & 15].used &= (uint8_t)~(1u << c->pool_slot); }   // (the streams stay with the device's pool)
 	delete c;
 }
 
@@ -622,7 +644,8 @@ int mm355_run_backtrack(mm355_ctx *c, const DevParams &pr)
 		HIPCHK(hipMemcpyAsync(hb.n_u.data(), c->n_u.p, n * 4, hipMemcpyDeviceToHost, c->st));
 		HIPCHK(hipMemcpyAsync(hb.n_v.data(), c->n_v.p, n * 4, hipMemcpyDeviceToHost, c->st));
 	}
-	unsigned long long pairs[CTR_PAIRS_WORDS];   // k_chain_*'s counters, spread over 64 words (slot = block & 63): one word takes ~88 atomics per microsecond
+	unsigned long long *pairs = c->pairs_land;   // k_chain_*'s counters, spread over 64 words (slot = block & 63): one word takes ~88 atomics per microsecond
+	// (they land in the context, not on this frame: check_err may return before it has synchronised the stream)
 	HIPCHK(hipMemcpyAsync(pairs, c->counters.as<unsigned long long>() + CTR_PAIRS_OFF, CTR_PAIRS_WORDS * 8, hipMemcpyDeviceToHost, c->st));
 	const int rc = check_err(c);   // (synchronises the stream)
 	c->stats.chain_pairs = 0;

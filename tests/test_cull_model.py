@@ -73,3 +73,27 @@ def test_bins_narrower_than_max_dist_x_are_not_enough(world):
         u1, b1 = orc.chains(a[keep], len(rd))
         differs += not (np.array_equal(u0, u1) and np.array_equal(b0, b1))
     assert differs > 0
+
+
+def test_equal_positions_share_the_decision(world):
+    """What the literal path of mm355_cull_sort relies on when it only descends into buckets that hold equal positions among KEPT anchors
+    (k_tie_tcnt, kept_only): anchors with the same x fall into the same bin, so the rule keeps all of them or none -- a pair of culled
+    anchors is dropped whatever order the unstable sort would have left it in."""
+    orc = O.OracleAligner(world["fa"], preset="map-ont")
+    g = world["g"]
+    seq_off = np.concatenate(([0], np.cumsum([len(c) for c in g])[:-1])).astype(np.int64)
+    tot_len = int(sum(len(c) for c in g))
+    mo = orc.mo
+    D = max(mo.max_gap_ref if mo.max_gap_ref > 0 else mo.max_gap, mo.bw)
+    sh = int(np.ceil(np.log2(D)))
+    T = max(mo.min_cnt, -(-mo.min_chain_score // orc.k))
+    n_pairs = n_kept_pairs = 0
+    for rd in world["reads"]:
+        a, _, _, _ = orc.anchors(rd, sorted_=True)
+        if len(a) < 2:
+            continue
+        keep = cull(a, seq_off, tot_len, sh, T)
+        same = a[1:, 0] == a[:-1, 0]
+        assert np.array_equal(keep[1:][same], keep[:-1][same])
+        n_pairs += int(same.sum()); n_kept_pairs += int((same & keep[1:]).sum())
+    assert n_pairs > 0 and n_kept_pairs < n_pairs, (n_pairs, n_kept_pairs)   # the data has such pairs, and the rule drops some of them
