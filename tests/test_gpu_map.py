@@ -1014,3 +1014,54 @@ def test_update_extra_host_walk(ont, monkeypatch):
     n_hits, _ = check_reads(al, ont["orc"], reads)
     host = [[(m.r_st, m.r_en, m.mlen, m.blen, m.NM, m.mapq, m.cs) for m in al.map(r, cs=True)] for r in reads]
     assert n_hits > 50 and host == dev
+
+
+def test_more_contexts_than_the_stream_pool_holds(ont):
+    """mm355_ctx_create hands the main and the sort stream of the first eight contexts of a device out of a pool (two streams of one context
+    on one hardware queue, mm355_pipeline.hip); the ninth and later contexts get streams of their own, and a destroyed context's pool slot
+    goes to the next one created.  Eleven contexts map the same reads at the same time, three are destroyed and created again: every result
+    equals the first."""
+    import threading
+    from mappy_rs import _ffi
+    al = ont["al"]
+    L = al._L
+    reads, _ = S.make_reads(97, ont["g"], 40, n50=4000, lo=300)
+    rarr, rlens, keep = _ffi.pack_reads(reads)
+
+    def run(ctx, out, k):
+        hp = C.POINTER(_ffi.Hits)()
+        _ffi.check(L.mm355_map_batch(ctx, C.byref(al._mo), len(keep), rarr, rlens, 1, C.byref(hp)))
+        h = hp.contents
+        off = list(np.ctypeslib.as_array(h.hit_off, shape=(len(keep) + 1,)))
+        rec = [(h.hits[i].rid, h.hits[i].target_start, h.hits[i].target_end, h.hits[i].query_start, h.hits[i].query_end, h.hits[i].strand, h.hits[i].mapq,
+                h.hits[i].n_cigar, h.hits[i].NM) for i in range(int(h.n_hits))]
+        cig = list(np.ctypeslib.as_array(h.cigar, shape=(max(1, int(h.n_cigar)),))[:int(h.n_cigar)])
+        L.mm355_free_hits(hp)
+        out[k] = (off, rec, cig)
+
+    ctxs = []
+    try:
+        for _ in range(11):
+            c = C.c_void_p()
+            _ffi.check(L.mm355_ctx_create(al._idx, 0, C.byref(c)))
+            ctxs.append(c)
+        for rnd in range(2):
+            out = [None] * len(ctxs)
+            th = [threading.Thread(target=run, args=(c, out, k)) for k, c in enumerate(ctxs)]
+            for t in th: t.start()
+            for t in th: t.join()
+            assert all(o is not None for o in out) and len(out[0][1]) > 20
+            for k in range(1, len(out)):
+                assert out[k] == out[0], (rnd, k)
+            if rnd == 0:   # slots 1, 4 and 6 of the pool become free and are taken again
+                for k in (1, 4, 6):
+                    L.mm355_ctx_destroy(ctxs[k])
+                    ctxs[k] = None
+                for k in (1, 4, 6):
+                    c = C.c_void_p()
+                    _ffi.check(L.mm355_ctx_create(al._idx, 0, C.byref(c)))
+                    ctxs[k] = c
+    finally:
+        for c in ctxs:
+            if c is not None:
+                L.mm355_ctx_destroy(c)
