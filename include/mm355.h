@@ -29,7 +29,7 @@ extern "C" {
 #define MM355_EIO      (-4)   /* cannot open / parse index or FASTA */
 #define MM355_ENOIDX   (-5)   /* "No index" (L2 crate error string) */
 #define MM355_EEMPTY   (-6)   /* "Sequence is empty" (L2 crate error string) */
-#define MM355_EUNSUP   (-7)   /* option outside the long-read hot path (HPC index, sr/splice presets) */
+#define MM355_EUNSUP   (-7)   /* option outside the long-read hot path (sr/splice presets, query-strand / heap-sort flags) */
 #define MM355_EHIP     (-8)   /* a HIP runtime call failed */
 
 typedef struct mm355_index mm355_index_t;     /* replaces mm_idx_t* (lib.rs:400-410) */

@@ -11,7 +11,7 @@ extern "C" const char *mm355_strerror(int code)
 	case MM355_EIO: return "Did not create or open an index";
 	case MM355_ENOIDX: return "No index";
 	case MM355_EEMPTY: return "Sequence is empty";
-	case MM355_EUNSUP: return "option outside the long-read hot path (HPC index, sr/splice presets, query-strand / heap-sort flags)";
+	case MM355_EUNSUP: return "option outside the long-read hot path (sr/splice presets, query-strand / heap-sort flags)";
 	case MM355_EHIP: return "a HIP runtime call failed";
 	default: return "unknown error";
 	}

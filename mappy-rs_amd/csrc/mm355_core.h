@@ -72,16 +72,21 @@ MM_HD uint64_t mm_table_hash(uint64_t minier)
 struct mm355_slot { uint64_t key, val; };
 #define MM355_SLOTS_PER_LINE 8      // 8 x 16 B = one 128-B line: a probe sequence stays inside one HBM fetch
 
-// ---- sequential (w,k)-minimizer state machine: U:sketch.c::mm_sketch, non-HPC ----
+// ---- sequential (w,k)-minimizer state machine: U:sketch.c::mm_sketch ----
+// is_hpc (MM_I_HPC, the map-pb / ava-pb presets): a homopolymer run counts as ONE base of the k-mer, at the position of its last
+// base; the span of a k-mer is the sum of its k run lengths (the reference's tiny_queue of the last k of them).  Run lengths are kept
+// clamped to 4096: a span that holds such a run is >= 256 either way (no record), and what is added is what is subtracted later.
+#define MM355_HPC_RUN_CAP 4096
 // The window logic is order-dependent (rightmost minimum, duplicate emission rules, symmetric
 // k-mers skipped without advancing the ring), so one lane runs it per read; out[] receives
 // at most `cap` entries, the return value is the number that would have been written.
 // `buf` is caller-provided ring storage of w entries spaced `bstride` apart (LDS on the device).
 template <typename GetBase>
-MM_HD int64_t mm_sketch_seq(GetBase get, int len, int w, int k, uint32_t rid, mm128 *out, int64_t cap, mm128 *buf, int bstride)
+MM_HD int64_t mm_sketch_seq(GetBase get, int len, int w, int k, uint32_t rid, mm128 *out, int64_t cap, mm128 *buf, int bstride, bool is_hpc = false)
 {
 	uint64_t shift1 = 2 * (k - 1), mask = (1ULL<<2*k) - 1, kmer[2] = {0,0};
 	int i, j, l, buf_pos, min_pos, kmer_span = 0;
+	uint16_t tq[32]; int tq_front = 0, tq_count = 0;   // run lengths of the last k runs (HPC)
 	int64_t n = 0;
 	mm128 min = { UINT64_MAX, UINT64_MAX };
 #define BUF(j) buf[(j) * bstride]
@@ -92,7 +97,15 @@ MM_HD int64_t mm_sketch_seq(GetBase get, int len, int w, int k, uint32_t rid, mm
 		mm128 info = { UINT64_MAX, UINT64_MAX };
 		if (c < 4) {
 			int z;
-			kmer_span = l + 1 < k? l + 1 : k;
+			if (is_hpc) {
+				int skip_len = 1;
+				while (i + skip_len < len && get(i + skip_len) == c) ++skip_len;
+				i += skip_len - 1;
+				if (skip_len > MM355_HPC_RUN_CAP) skip_len = MM355_HPC_RUN_CAP;
+				tq[(tq_count + tq_front) & 31] = (uint16_t)skip_len; ++tq_count;
+				kmer_span += skip_len;
+				if (tq_count > k) { kmer_span -= tq[tq_front]; tq_front = (tq_front + 1) & 31; --tq_count; }
+			} else kmer_span = l + 1 < k? l + 1 : k;
 			kmer[0] = (kmer[0] << 2 | c) & mask;
 			kmer[1] = (kmer[1] >> 2) | (3ULL^c) << shift1;
 			if (kmer[0] == kmer[1]) continue;
@@ -102,7 +115,7 @@ MM_HD int64_t mm_sketch_seq(GetBase get, int len, int w, int k, uint32_t rid, mm
 				info.x = mm_hash64(kmer[z], mask) << 8 | kmer_span;
 				info.y = (uint64_t)rid<<32 | (uint32_t)i<<1 | z;
 			}
-		} else l = 0, kmer_span = 0;
+		} else l = 0, kmer_span = 0, tq_count = tq_front = 0;
 		BUF(buf_pos) = info;
 		if (l == w + k - 1 && min.x != UINT64_MAX) {
 			for (j = buf_pos + 1; j < w; ++j)

@@ -1302,12 +1302,36 @@ static void fix_bad_ends(const Reg *r, const mm128 *a, int bw, int min_match, in
 	}
 }
 
+// U:align.c::mm_adjust_minier (+ mm_get_hplen_back): where a seed cuts the alignment.  Plain index: the middle of the k-mer.  HPC index
+// (MM_I_HPC: map-pb / ava-pb): a seed ends on the last base of a homopolymer run on both sequences, and the cut is the FIRST base of
+// that run (the query scan stops at position 1, as the reference's `i > 0` does).
+static inline void adjust_minier(const mm355_index *mi, const ReadState &rs, const mm128 *a, int32_t *r, int32_t *q)
+{
+	if (mi->flag & 1) {
+		const uint8_t *qseq = rs.qc[a->x >> 63].data();
+		int32_t i = (int32_t)a->y;
+		const int c = qseq[i];
+		for (--i; i > 0; --i) if (qseq[i] != c) break;
+		*q = i + 1;
+		const uint32_t rid = (uint32_t)(a->x << 1 >> 33);
+		const int64_t off0 = (int64_t)mi->seq_off[rid], off = off0 + (int64_t)(uint32_t)a->x;
+		const uint32_t *S = mi->S.data();
+		const uint32_t ct = S[off >> 3] >> ((off & 7) << 2) & 0xf;
+		int64_t j;
+		for (j = off - 1; j >= off0; --j) if ((S[j >> 3] >> ((j & 7) << 2) & 0xf) != ct) break;
+		*r = (int32_t)a->x + 1 - (int32_t)(off - j);
+	} else {
+		*r = (int32_t)a->x - (mi->k >> 1);
+		*q = (int32_t)a->y - (mi->k >> 1);
+	}
+}
+
 // one-off part of mm_align1: seed filtering and the extension windows
 static void task_prepare(const mm355_index *mi, const mm355_mapopt_t *opt, ReadState &rs, const Reg *r, AlnTask &T)
 {
 	ProfScope pf(PF_TASK_PREPARE);
 	mm128 *a = rs.a.data();
-	const int qlen = rs.qlen, n_a = rs.n_a, kh = mi->k >> 1;
+	const int qlen = rs.qlen, n_a = rs.n_a;
 	int32_t i, l, rs1, qs1, re1, qe1;
 	T.rid = (int32_t)(a[r->as].x << 1 >> 33); T.rev = (int32_t)(a[r->as].x >> 63);
 	T.split_inv = (int)r->split_inv;
@@ -1318,8 +1342,9 @@ static void task_prepare(const mm355_index *mi, const mm355_mapopt_t *opt, ReadS
 	else T.as1 = r->as, T.cnt1 = r->cnt;
 	filter_bad_seeds(T.as1, T.cnt1, a, 10, 40, opt->max_gap >> 1, 10);
 	filter_bad_seeds_alt(T.as1, T.cnt1, a, 30, opt->max_gap >> 1);
-	int32_t rs_ = (int32_t)a[T.as1].x - kh, qs_ = (int32_t)a[T.as1].y - kh;
-	int32_t re_ = (int32_t)a[T.as1 + T.cnt1 - 1].x - kh, qe_ = (int32_t)a[T.as1 + T.cnt1 - 1].y - kh;
+	int32_t rs_, qs_, re_, qe_;
+	adjust_minier(mi, rs, &a[T.as1], &rs_, &qs_);
+	adjust_minier(mi, rs, &a[T.as1 + T.cnt1 - 1], &re_, &qe_);
 	int32_t rs0, qs0, re0, qe0;
 	const int32_t rlen = (int32_t)mi->seq_len[T.rid];
 	rs0 = (int32_t)a[r->as].x + 1 - (int32_t)(a[r->as].y >> 32 & 0xff);
@@ -1403,7 +1428,7 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 	AlnTask &T = rs.tasks[task_id];
 	Reg *r = &rs.regs[ri];
 	mm128 *a = rs.a.data();
-	const int qlen = rs.qlen, kh = mi->k >> 1;
+	const int qlen = rs.qlen;
 	const int32_t rid = T.rid, rev = T.rev, as1 = T.as1, cnt1 = T.cnt1;
 	int32_t rs_ = T.rs, qs_ = T.qs, re_ = T.re, qe_ = T.qe;
 	const int32_t qs0 = T.qs0, re0 = T.re0, qe0 = T.qe0;
@@ -1433,7 +1458,7 @@ static bool task_run(const mm355_index *mi, const mm355_mapopt_t *opt, int read_
 	int32_t rs_run = rs_, qs_run = qs_, re_run = re_, qe_run = qe_;
 	for (int32_t i = 1; i < cnt1; ++i) {   // gap filling
 		if ((a[as1 + i].y & (MM355_SEED_IGNORE | MM355_SEED_TANDEM)) && i != cnt1 - 1) continue;
-		re_run = (int32_t)a[as1 + i].x - kh; qe_run = (int32_t)a[as1 + i].y - kh;
+		adjust_minier(mi, rs, &a[as1 + i], &re_run, &qe_run);
 		re1 = re_run, qe1 = qe_run;
 		if (i == cnt1 - 1 || (a[as1 + i].y & MM355_SEED_LONG_JOIN) || (qe_run - qs_run >= opt->min_ksw_len && re_run - rs_run >= opt->min_ksw_len)) {
 			int bw1 = T.bw_long, zdrop_code = 0;

@@ -17,7 +17,8 @@
 
 #define WAVE 64
 
-__global__ __launch_bounds__(WAVE) void k_sketch_contig(const uint8_t *seq, int len, int w, int k, int n_chunks, mm128 *slots, int32_t *chunk_n)
+template <bool HPC>
+__device__ __forceinline__ void sketch_contig_chunk(const uint8_t *seq, int len, int w, int k, int n_chunks, mm128 *slots, int32_t *chunk_n)
 {
 	extern __shared__ mm128 ring[];
 	int t = blockIdx.x * WAVE + threadIdx.x;
@@ -25,7 +26,15 @@ __global__ __launch_bounds__(WAVE) void k_sketch_contig(const uint8_t *seq, int 
 	const int cs = t * SK_CHUNK;
 	int ce = cs + SK_CHUNK;
 	if (ce > len) ce = len;
-	chunk_n[t] = sketch_chunk(seq, len, w, k, cs, ce, slots + cs, ring + threadIdx.x, WAVE);
+	chunk_n[t] = sketch_chunk<HPC>(seq, len, w, k, cs, ce, slots + cs, ring + threadIdx.x, WAVE);
+}
+__global__ __launch_bounds__(WAVE) void k_sketch_contig(const uint8_t *seq, int len, int w, int k, int n_chunks, mm128 *slots, int32_t *chunk_n)
+{
+	sketch_contig_chunk<false>(seq, len, w, k, n_chunks, slots, chunk_n);
+}
+__global__ __launch_bounds__(WAVE) void k_sketch_contig_hpc(const uint8_t *seq, int len, int w, int k, int n_chunks, mm128 *slots, int32_t *chunk_n)   // MM_I_HPC
+{
+	sketch_contig_chunk<true>(seq, len, w, k, n_chunks, slots, chunk_n);
 }
 
 __global__ __launch_bounds__(WAVE) void k_gather_pairs(const mm128 *slots, const int32_t *chunk_n, const uint32_t *chunk_off, int n_chunks, uint32_t rid,
@@ -121,7 +130,6 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 	*out = 0;
 	if (n_seq <= 0) return MM355_EINVAL;
 	if (io->k <= 0 || io->k > 28 || io->w <= 0 || io->w >= 256) return MM355_EINVAL;   // U:sketch.c::mm_sketch asserts the same ranges (e.g. options never initialised with mm355_set_opt(NULL, ..))
-	if (io->flag & 1) return MM355_EUNSUP;
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) return MM355_ENODEV;
 	HIPCHK(hipSetDevice(device));
@@ -159,7 +167,7 @@ extern "C" int mm355_index_build_device(const mm355_idxopt_t *io, int n_seq, con
 		if (hipMemcpyAsync(d_seq.p, seqs[i], (size_t)len, hipMemcpyHostToDevice, st) != hipSuccess) FAIL(MM355_EHIP);
 		(void)hipMemsetAsync((uint8_t*)d_seq.p + len, 4, 32, st);   // padding reads as 'N'
 		hipLaunchKernelGGL(k_pack4, GRID((len >> 3) + 2, 256), dim3(256), 0, st, d_seq.as<uint8_t>(), len, mi->seq_off[i], (uint32_t*)dS);
-		hipLaunchKernelGGL(k_sketch_contig, GRID(nch, WAVE), dim3(WAVE), (size_t)mi->w * WAVE * sizeof(mm128), st, d_seq.as<uint8_t>(), (int)len, mi->w, mi->k, nch,
+		hipLaunchKernelGGL((mi->flag & 1)? k_sketch_contig_hpc : k_sketch_contig, GRID(nch, WAVE), dim3(WAVE), (size_t)mi->w * WAVE * sizeof(mm128), st, d_seq.as<uint8_t>(), (int)len, mi->w, mi->k, nch,
 		                   d_slots16.as<mm128>(), d_cn.as<int32_t>());
 		if (hipGetLastError() != hipSuccess) FAIL(MM355_EHIP);   // k_pack4 / k_sketch_contig launch
 		size_t tb = 0;

@@ -80,9 +80,20 @@ extern "C" int mm355_set_opt(const char *preset, mm355_idxopt_t *io, mm355_mapop
 		else return MM355_EINVAL;
 		return 0;
 	}
-	// known minimap2 2.26 presets that are outside the long-read hot path (HPC sketches, short reads, spliced): nothing is modified, the
+	if (p == "map-pb" || p == "map10k") {   // homopolymer-compressed minimizers (MM_I_HPC = 1), U:options.c::mm_set_opt
+		io->flag |= 1; io->k = 19;
+		return 0;
+	}
+	if (p == "ava-pb") {
+		io->flag |= 1; io->k = 19; io->w = 5;
+		mo->flag |= 0x800000LL | 0x001LL | 0x002LL | 0x400LL;   // ALL_CHAINS | NO_DIAG | NO_DUAL | NO_LJOIN, as ava-ont
+		mo->min_chain_score = 100; mo->pri_ratio = 0.0f; mo->max_chain_skip = 25;
+		mo->bw_long = mo->bw; mo->occ_dist = 0;
+		return 0;
+	}
+	// known minimap2 2.26 presets that are outside the long-read hot path (short reads, spliced): nothing is modified, the
 	// caller gets MM355_EUNSUP and must refuse (mappy_rs.Aligner raises)
-	static const char *const unsup[] = { "map-pb", "map10k", "ava-pb", "sr", "short", "splice", "splice:hq", "cdna", 0 };
+	static const char *const unsup[] = { "sr", "short", "splice", "splice:hq", "cdna", 0 };
 	for (int i = 0; unsup[i]; ++i) if (p == unsup[i]) return MM355_EUNSUP;
 	return MM355_EINVAL;   // unknown name: options untouched, as U:options.c::mm_set_opt's -1 (the reference ignores it, lib.rs:336)
 }
@@ -229,19 +240,18 @@ static mm355_index *load_mmi(FILE *fp)
 // ------------------------------------------------------------------ builder (U:index.c::mm_idx_gen)
 struct HostBase { const char *s; int operator()(int i) const { return mm_nt4((uint8_t)s[i]); } };
 
-static void sketch_contig(const char *s, int64_t len, int w, int k, uint32_t rid, std::vector<mm128> &out)
+static void sketch_contig(const char *s, int64_t len, int w, int k, uint32_t rid, bool is_hpc, std::vector<mm128> &out)
 {
 	if (len <= 0) return;
 	std::vector<mm128> ring(w);
 	std::vector<mm128> tmp((size_t)len);
 	HostBase hb = { s };
-	int64_t n = mm_sketch_seq(hb, (int)len, w, k, rid, tmp.data(), len, ring.data(), 1);
+	int64_t n = mm_sketch_seq(hb, (int)len, w, k, rid, tmp.data(), len, ring.data(), 1, is_hpc);
 	for (int64_t i = 0; i < n; ++i) { mm128 m; m.x = tmp[i].x >> 8; m.y = tmp[i].y; out.push_back(m); }
 }
 
 static mm355_index *build_from_seqs(const mm355_idxopt_t *io, int n_seq, const char *const *seqs, const int64_t *lens, const char *const *names, int n_threads)
 {
-	if (io->flag & 1) return 0;   // HPC
 	mm355_index *mi = new mm355_index();
 	mi->w = io->w < 1? 1 : io->w; mi->k = io->k; mi->b = io->bucket_bits; mi->flag = io->flag; mi->n_seq = n_seq;
 	if (mi->k * 2 < mi->b) mi->b = mi->k * 2;
@@ -258,7 +268,7 @@ static mm355_index *build_from_seqs(const mm355_idxopt_t *io, int n_seq, const c
 	if (n_threads < 1) n_threads = 1;
 	std::vector<std::vector<mm128>> parts(n_seq);
 	std::atomic<int> next(0);
-	auto work = [&]() { for (;;) { int i = next.fetch_add(1); if (i >= n_seq) break; sketch_contig(seqs[i], lens[i], mi->w, mi->k, (uint32_t)i, parts[i]); } };
+	auto work = [&]() { for (;;) { int i = next.fetch_add(1); if (i >= n_seq) break; sketch_contig(seqs[i], lens[i], mi->w, mi->k, (uint32_t)i, (mi->flag & 1) != 0, parts[i]); } };
 	std::vector<std::thread> th;
 	for (int t = 1; t < n_threads && t < n_seq; ++t) th.emplace_back(work);
 	work();
@@ -326,13 +336,11 @@ extern "C" int mm355_index_load(const char *path, const mm355_idxopt_t *io, int 
 	if (n == 4 && strncmp(magic, "MMI\2", 4) == 0) mi = load_mmi(fp);
 	else if (n > 0) {
 		fclose(fp); fp = 0;
-		if (io->flag & 1) return MM355_EUNSUP;
 		if (io->k <= 0 || io->k > 28 || io->w <= 0 || io->w >= 256) return MM355_EINVAL;
 		mi = build_from_fastx(path, io, n_threads);
 	}
 	if (fp) fclose(fp);
 	if (mi == 0 || mi->n_seq == 0) { delete mi; return MM355_EIO; }
-	if (mi->flag & 1) { delete mi; return MM355_EUNSUP; }   // HPC index
 	finish_index(mi);
 	*out = mi;
 	return 0;
@@ -343,7 +351,6 @@ extern "C" int mm355_index_build(const mm355_idxopt_t *io, int n_seq, const char
 	*out = 0;
 	if (n_seq <= 0) return MM355_EINVAL;
 	if (io->k <= 0 || io->k > 28 || io->w <= 0 || io->w >= 256) return MM355_EINVAL;   // U:sketch.c::mm_sketch asserts the same ranges
-	if (io->flag & 1) return MM355_EUNSUP;
 	mm355_index *mi = build_from_seqs(io, n_seq, seqs, lens, names, n_threads);
 	if (mi == 0) return MM355_EINVAL;
 	finish_index(mi);

@@ -40,7 +40,8 @@
 // MM355_KPROF diagnostics: shader cycles of a kernel phase, summed over reads and the maximum over reads (lane 0 of a wave)
 #define KPROF_BEGIN(bt) unsigned long long *kp_ = (bt).prof; unsigned long long kp_t_ = kp_? (unsigned long long)clock64() : 0
 #define KPROF(i) do { if (kp_ && (threadIdx.x & 63) == 0) { const unsigned long long t_ = (unsigned long long)clock64(); atomicAdd(&kp_[i], t_ - kp_t_); atomicMax(&kp_[32 + (i)], t_ - kp_t_); kp_t_ = t_; } } while (0)
-__global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
+template <bool HPC>
+__device__ __forceinline__ void sketch_lane_per_chunk(const DevIndex &ix, const DevBatch &bt, const DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
 {
 	MM355_LATENCY_KERNEL();
 	extern __shared__ mm128 ring[];   // w entries per lane, lane-interleaved
@@ -51,7 +52,16 @@ __global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSe
 	const int64_t off = bt.roff[r];
 	int ce = cs + SK_CHUNK;
 	if (ce > len) ce = len;
-	chunk_n[t] = sketch_chunk(bt.seq + off, len, ix.w, ix.k, cs, ce, sd.mz + off + cs, ring + threadIdx.x, WAVE);
+	chunk_n[t] = sketch_chunk<HPC>(bt.seq + off, len, ix.w, ix.k, cs, ce, sd.mz + off + cs, ring + threadIdx.x, WAVE);
+}
+__global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
+{
+	sketch_lane_per_chunk<false>(ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+}
+// the same on a homopolymer-compressed index (MM_I_HPC: map-pb / ava-pb)
+__global__ __launch_bounds__(WAVE) void k_sketch_hpc(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
+{
+	sketch_lane_per_chunk<true>(ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
 }
 
 // Small batches (a single read is ~20 chunks): lane 0 of a wave alone.  With a lane per chunk the wave executes the union of every lane's
@@ -61,7 +71,8 @@ __global__ __launch_bounds__(WAVE) void k_sketch(DevIndex ix, DevBatch bt, DevSe
 // range and wave 0 then packs them to its front, so the chunk looks as if one lane had done it.
 #define SKS_WAVES 12
 #define SKS_PIECE (SK_CHUNK / SKS_WAVES)
-__global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
+template <bool HPC>
+__device__ __forceinline__ void sketch_block_per_chunk(const DevIndex &ix, const DevBatch &bt, const DevSeeds &sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
 {
 	MM355_LATENCY_KERNEL();
 	extern __shared__ mm128 ring[];              // w entries per wave
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix,
 		const int ps = cs + wv * SKS_PIECE;
 		int pe = ps + SKS_PIECE;
 		if (pe > ce) pe = ce;
-		s_n[wv] = ps < pe? sketch_chunk(bt.seq + off, len, ix.w, ix.k, ps, pe, sd.mz + off + ps, ring + wv * ix.w, 1) : 0;
+		s_n[wv] = ps < pe? sketch_chunk<HPC>(bt.seq + off, len, ix.w, ix.k, ps, pe, sd.mz + off + ps, ring + wv * ix.w, 1) : 0;
 	}
 	KPROF(24);
 	__syncthreads();
@@ -94,6 +105,14 @@ __global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix,
 	}
 	if (lane == 0) chunk_n[t] = m;
 	KPROF(25);
+}
+__global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
+{
+	sketch_block_per_chunk<false>(ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+}
+__global__ __launch_bounds__(WAVE * SKS_WAVES) void k_sketch_sparse_hpc(DevIndex ix, DevBatch bt, DevSeeds sd, const int32_t *chunk_read, const int32_t *chunk_start, int n_chunks, int32_t *chunk_n)
+{
+	sketch_block_per_chunk<true>(ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
 }
 
 // packs the per-chunk outputs of a read to the front of its slot range (in place; destination never passes the source)
@@ -1210,12 +1229,13 @@ void mm355_launch_sketch(const DevIndex &ix, const DevBatch &bt, DevSeeds &sd, c
 	if (n_chunks > 0) {
 		const char *e = getenv("MM355_SKETCH_SPARSE_MAX");   // read per launch: the parity tests force either form
 		const int sparse_max = e? atoi(e) : 2048;             // chunks
+		const bool hpc = (ix.flag & 1) != 0;                  // MM_I_HPC
 		if (n_chunks <= sparse_max) {
-			hipLaunchKernelGGL(k_sketch_sparse, dim3(n_chunks), dim3(WAVE * SKS_WAVES), (size_t)ix.w * SKS_WAVES * sizeof(mm128), st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+			hipLaunchKernelGGL(hpc? k_sketch_sparse_hpc : k_sketch_sparse, dim3(n_chunks), dim3(WAVE * SKS_WAVES), (size_t)ix.w * SKS_WAVES * sizeof(mm128), st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
 		} else {
 			int blocks = (n_chunks + WAVE - 1) / WAVE;
 			size_t lds = (size_t)ix.w * WAVE * sizeof(mm128);
-			hipLaunchKernelGGL(k_sketch, dim3(blocks), dim3(WAVE), lds, st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
+			hipLaunchKernelGGL(hpc? k_sketch_hpc : k_sketch, dim3(blocks), dim3(WAVE), lds, st, ix, bt, sd, chunk_read, chunk_start, n_chunks, chunk_n);
 		}
 	}
 	hipLaunchKernelGGL(k_sketch_compact, dim3(bt.n_reads), dim3(WAVE), 0, st, bt, sd, read_chunk0, chunk_n);

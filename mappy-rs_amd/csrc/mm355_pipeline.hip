@@ -15,7 +15,6 @@
 // ------------------------------------------------------------------ options -> kernel parameters
 int mm355_check_opts(const mm355_mapopt_t *mo, const mm355_index *mi)
 {
-	if (mi->flag & 1) return MM355_EUNSUP;                                           // HPC index
 	if (mi->flag & 2) return MM355_EUNSUP;                                           // MM_I_NO_SEQ with MM_F_CIGAR (always set, lib.rs:339): "No sequence in this index" (lib.rs:710-714)
 	if (mo->flag & (MMF_SPLICE | 0x100LL | 0x200LL | MMF_SR | MMF_QSTRAND | MMF_HEAP_SORT)) return MM355_EUNSUP;   // 0x100/0x200: SPLICE_FOR/REV imply SPLICE (U:options.c::mm_mapopt_update)
 	if (!(mo->flag & MMF_CIGAR)) return MM355_EUNSUP;                                // the reference always sets it (lib.rs:339)

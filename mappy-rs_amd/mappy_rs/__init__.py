@@ -353,11 +353,11 @@ class Aligner:
         if preset is not None:
             rc = L.mm355_set_opt(str(preset).encode(), C.byref(io), C.byref(mo))
             # The reference ignores mm_set_opt's return value (lib.rs:336): an unknown name leaves the defaults in place, silently, and so
-            # does this mirror (MM355_EINVAL).  A preset minimap2 knows but this path does not implement (sr, splice, map-pb ...) must not be
+            # does this mirror (MM355_EINVAL).  A preset minimap2 knows but this path does not implement (sr, splice ...) must not be
             # mapped with other parameters behind the caller's back: refuse.
             if rc == _ffi.MM355_EUNSUP:
                 raise NotImplementedError("preset %r is not implemented by the MI355X mapping path (long-read presets only: map-ont, "
-                                          "map-hifi, asm5/asm10/asm20, ava-ont)" % (preset,))
+                                          "map-hifi, map-pb, asm5/asm10/asm20, ava-ont, ava-pb)" % (preset,))
         mo.flag |= 4                       # MM_F_CIGAR, lib.rs:339
         io.batch_size |= 0x7fffffffffffffff  # lib.rs:340
         if k is not None: io.k = k

@@ -3,13 +3,15 @@
  * mm_fix_bad_ends, mm_filter_bad_seeds(_alt), mm_adjust_minier, mm_test_zdrop,
  * mm_align1_inv, mm_update_extra, mm_fix_cigar, mm_append_cigar, mm_insert_reg.
  * Reached from R:src/lib.rs:482 / :587 via mm_map -> align_regs (MM_F_CIGAR is
- * forced on at R:src/lib.rs:339).  Splice / short-read / HPC / qstrand branches
- * are out of scope and omitted.
+ * forced on at R:src/lib.rs:339).  Splice / short-read / qstrand branches
+ * are out of scope and omitted; the HPC branch (map-pb / ava-pb)
+ * is mm_adjust_minier's only.
  */
 #include <stdlib.h>
 #include <string.h>
 #include <assert.h>
 #include "mmo.h"
+#define mm_seq4_get(s, i)    ((s)[(i)>>3] >> (((i)&7)<<2) & 0xf)
 
 #define kroundup32(x) (--(x), (x)|=(x)>>1, (x)|=(x)>>2, (x)|=(x)>>4, (x)|=(x)>>8, (x)|=(x)>>16, ++(x))
 
@@ -295,11 +297,33 @@ static void mm_align_pair(const mmo_mapopt_t *opt, int qlen, const uint8_t *qseq
 		mmo_ksw_extd2(qlen, qseq, tlen, tseq, 5, mat, opt->q, opt->e, opt->q2, opt->e2, w, zdrop, end_bonus, flag, ez);
 }
 
-static inline void mm_adjust_minier(const mmo_idx_t *mi, mm128_t *a, int32_t *r, int32_t *q)
+/* U:align.c::mm_get_hplen_back: length of the homopolymer run of the reference that ends at x (inside contig rid) */
+static int mm_get_hplen_back(const mmo_idx_t *mi, uint32_t rid, uint32_t x)
 {
-	/* non-HPC */
-	*r = (int32_t)a->x - (mi->k>>1);
-	*q = (int32_t)a->y - (mi->k>>1);
+	int64_t i, off0 = mi->seq[rid].offset, off = off0 + x;
+	int c = mm_seq4_get(mi->S, off);
+	for (i = off - 1; i >= off0; --i)
+		if (mm_seq4_get(mi->S, i) != c) break;
+	return (int)(off - i);
+}
+
+/* U:align.c::mm_adjust_minier.  HPC index (map-pb / ava-pb): a seed ends on the LAST base of a homopolymer run, on both
+ * sequences; the alignment is cut at the FIRST base of that run instead of the middle of the k-mer */
+static inline void mm_adjust_minier(const mmo_idx_t *mi, uint8_t *const qseq0[2], mm128_t *a, int32_t *r, int32_t *q)
+{
+	if (mi->flag & MM_I_HPC) {
+		const uint8_t *qseq = qseq0[a->x>>63];
+		int i, c;
+		*q = (int32_t)a->y;
+		for (i = *q - 1, c = qseq[*q]; i > 0; --i)
+			if (qseq[i] != c) break;
+		*q = i + 1;
+		c = mm_get_hplen_back(mi, a->x<<1>>33, (int32_t)a->x);
+		*r = (int32_t)a->x + 1 - c;
+	} else {
+		*r = (int32_t)a->x - (mi->k>>1);
+		*q = (int32_t)a->y - (mi->k>>1);
+	}
 }
 
 static int *collect_long_gaps(int as1, int cnt1, mm128_t *a, int min_gap, int *n_)
@@ -451,8 +475,8 @@ static void mm_align1(const mmo_mapopt_t *opt, const mmo_idx_t *mi, int qlen, ui
 	else as1 = r->as, cnt1 = r->cnt;
 	mm_filter_bad_seeds(as1, cnt1, a, 10, 40, opt->max_gap>>1, 10);
 	mm_filter_bad_seeds_alt(as1, cnt1, a, 30, opt->max_gap>>1);
-	mm_adjust_minier(mi, &a[as1], &rs, &qs);
-	mm_adjust_minier(mi, &a[as1 + cnt1 - 1], &re, &qe);
+	mm_adjust_minier(mi, qseq0, &a[as1], &rs, &qs);
+	mm_adjust_minier(mi, qseq0, &a[as1 + cnt1 - 1], &re, &qe);
 	assert(cnt1 > 0);
 
 	/* compute rs0 and qs0 */
@@ -533,7 +557,7 @@ static void mm_align1(const mmo_mapopt_t *opt, const mmo_idx_t *mi, int qlen, ui
 
 	for (i = 1; i < cnt1; ++i) { /* gap filling */
 		if ((a[as1+i].y & (MM_SEED_IGNORE|MM_SEED_TANDEM)) && i != cnt1 - 1) continue;
-		mm_adjust_minier(mi, &a[as1 + i], &re, &qe);
+		mm_adjust_minier(mi, qseq0, &a[as1 + i], &re, &qe);
 		re1 = re, qe1 = qe;
 		if (i == cnt1 - 1 || (a[as1+i].y&MM_SEED_LONG_JOIN) || (qe - qs >= opt->min_ksw_len && re - rs >= opt->min_ksw_len)) {
 			int j, bw1 = bw_long, zdrop_code;

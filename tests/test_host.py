@@ -60,7 +60,7 @@ def test_constructor_errors(ffi, golden_dir):
 
 def test_option_presets_match_oracle(ffi):
     L = ffi.lib()
-    for preset in (None, "map-ont", "map-hifi", "asm20"):
+    for preset in (None, "map-ont", "map-hifi", "asm20", "asm5", "ava-ont", "map-pb", "map10k", "ava-pb"):
         io, mo = ffi.IdxOpt(), ffi.MapOpt()
         L.mm355_set_opt(None, C.byref(io), C.byref(mo))
         oio, omo = O.IdxOpt(), O.MapOpt()
@@ -72,7 +72,7 @@ def test_option_presets_match_oracle(ffi):
         for name, _ in ffi.MapOpt._fields_:
             assert getattr(mo, name) == getattr(omo, name), (preset, name)
     before = bytes(mo), bytes(io)
-    for known in (b"sr", b"splice", b"splice:hq", b"map-pb", b"ava-pb", b"map10k", b"short", b"cdna"):
+    for known in (b"sr", b"splice", b"splice:hq", b"short", b"cdna"):
         assert L.mm355_set_opt(known, C.byref(io), C.byref(mo)) == ffi.MM355_EUNSUP
     for unknown in (b"map-ontt", b"asm7", b""):
         assert L.mm355_set_opt(unknown, C.byref(io), C.byref(mo)) == ffi.MM355_EINVAL    # U:options.c::mm_set_opt returns -1
@@ -83,7 +83,7 @@ def test_unsupported_presets_raise(ffi, golden_dir):
     """a preset minimap2 knows but this path does not implement must not be mapped with other parameters"""
     import mappy_rs
     mmi = os.path.join(golden_dir, "test.mmi")
-    for preset in ("sr", "splice", "map-pb", "ava-pb", "splice:hq"):
+    for preset in ("sr", "splice", "splice:hq"):
         with pytest.raises(NotImplementedError, match="not implemented by the MI355X mapping path"):
             mappy_rs.Aligner(mmi, preset=preset)
     al = mappy_rs.Aligner(mmi, preset="no-such-preset")      # the reference ignores mm_set_opt's -1 (lib.rs:336): defaults stay
@@ -317,3 +317,51 @@ def test_map_batch_list_fast_path_and_elementwise_errors(ffi, golden_dir, monkey
         with pytest.raises(exc):
             al.map_batch(broken)
     assert sorted(taken) == sorted(given)          # every worker context went back
+
+
+def _hp_genome(seed, lens, **kw):
+    """contigs with homopolymer runs of 2..40 bases at one position in ~12 (and one of 300): what MM_I_HPC compresses"""
+    import synthdata as S
+    rng = np.random.default_rng(seed)
+    out = []
+    for c in S.make_genome(seed, lens, **kw):
+        rep = np.ones(len(c), np.int64)
+        pos = rng.integers(0, len(c), len(c) // 12)
+        rep[pos] = rng.integers(2, 41, len(pos))
+        rep[int(rng.integers(0, len(c)))] = 300                      # a run whose k-mers have no record (span >= 256)
+        rep[c > 3] = 1
+        out.append(np.repeat(c, rep).astype(np.uint8))
+    return out
+
+
+def test_hpc_index_build_matches_oracle(ffi, tmp_path):
+    """MM_I_HPC (map-pb): the host builder's homopolymer-compressed index == the oracle's (U:sketch.c::mm_sketch with is_hpc)"""
+    import synthdata as S
+    g = _hp_genome(23, [60000, 25000], repeats=((1500, 5, 0.0), (400, 20, 0.01)), n_runs=2)
+    fa = str(tmp_path / "hp.fa")
+    S.write_fasta(fa, g, ["c0", "c1"])
+    orc = O.OracleAligner(fa, preset="map-pb")
+    assert orc.k == 19 and orc.w == 10
+    L = ffi.lib()
+    io, mo = ffi.IdxOpt(), ffi.MapOpt()
+    L.mm355_set_opt(None, C.byref(io), C.byref(mo))
+    assert L.mm355_set_opt(b"map-pb", C.byref(io), C.byref(mo)) == 0 and io.flag & 1 and io.k == 19
+    h = C.c_void_p()
+    assert L.mm355_index_load(fa.encode(), C.byref(io), 2, C.byref(h)) == 0
+    L.mm355_mapopt_update(C.byref(mo), h)
+    assert mo.mid_occ == orc.mo.mid_occ
+    seqs = [S.codes_to_str(c) for c in g]
+    keys = _all_minimizers(orc, seqs)
+    spans = {int(x) & 0xff for rid, s in enumerate(seqs) for x, _ in orc.sketch(s, rid)}
+    assert max(spans) > 60 and min(spans) >= 19                      # spans are sums of run lengths
+    nm, nd = C.c_int64(), C.c_int64()
+    L.mm355_index_stat(h, C.byref(nm), C.byref(nd), None, None)
+    ond = C.c_int64()
+    assert nm.value == O.lib().mmo_idx_n_minimizers(orc.idx, C.byref(ond)) and nd.value == ond.value == len(keys)
+    buf = np.zeros(4096, np.uint64)
+    for minier in keys:
+        n = L.mm355_index_get(h, minier, buf.ctypes.data, 4096)
+        on = C.c_int()
+        p = O.lib().mmo_idx_get(orc.idx, minier, C.byref(on))
+        assert n == on.value and [int(v) for v in buf[:n]] == [p[i] for i in range(n)]
+    L.mm355_index_free(h)

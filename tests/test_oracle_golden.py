@@ -4,6 +4,7 @@ G1  test.fa <-> test.mmi : mm_sketch + index key/value encoding + MMI\\2 format,
 G2  map_one (R:src/lib.rs:1094-1106, R:tests/python_test.py:124-137) + the derived full record
 plus the reference's property tests (k, w, n_seq, seq_names, seq).
 """
+import ctypes as C
 import os
 import struct
 
@@ -218,3 +219,35 @@ def test_committed_preset_vectors(golden_dir):
         assert got["cases"][label] == want["cases"][label], label
     assert any("X" in h["cigar_str"] for hits in want["cases"]["map-ont+EQX"] for h in hits)
     assert {h["strand"] for hits in want["cases"]["map-ont+REV_ONLY+NO_LJOIN"] for h in hits} == {-1}
+
+
+def test_hpc_sketch_is_the_plain_sketch_of_the_run_compressed_sequence():
+    """MM_I_HPC (map-pb / ava-pb).  The reference holds no fixture for it (test.mmi is a plain index): the HPC branch of the oracle's
+    mm_sketch is pinned to its plain branch -- which test.mmi pins -- by what homopolymer compression MEANS: the minimizers of a
+    sequence are those of its run-compressed image, at the position of each run's last base, with the run lengths of the k-mer as span."""
+    L = O.lib()
+    rng = np.random.default_rng(5)
+    for k, w in ((19, 10), (15, 5), (14, 8)):
+        codes = rng.integers(0, 4, 4000)
+        codes = codes[np.r_[True, codes[1:] != codes[:-1]]]                      # the compressed image: no two equal neighbours
+        rl = np.ones(len(codes), np.int64)
+        pos = rng.integers(0, len(codes), len(codes) // 5)
+        rl[pos] = rng.integers(2, 9, len(pos))                                   # (spans stay below 256)
+        full = "".join("ACGT"[c] * int(n) for c, n in zip(codes, rl)).encode()
+        comp = "".join("ACGT"[c] for c in codes).encode()
+        end = np.cumsum(rl) - 1                                                  # last base of every run
+        csum = np.r_[0, np.cumsum(rl)]
+        def sk(b, hpc):
+            v = O.MM128V()
+            L.mmo_sketch(b, len(b), w, k, 7, hpc, C.byref(v))
+            out = np.ctypeslib.as_array(C.cast(v.a, C.POINTER(C.c_uint64)), shape=(v.n, 2)).copy()
+            L.free(v.a)
+            return out
+        plain, hpc = sk(comp, 0), sk(full, 1)
+        assert len(plain) == len(hpc) > 300
+        p = (plain[:, 1] & 0xffffffff) >> 1                                      # position in the compressed image
+        assert np.all((plain[:, 0] & 0xff) == k)
+        assert np.array_equal(hpc[:, 0] >> 8, plain[:, 0] >> 8)                  # same k-mers chosen
+        assert np.array_equal((hpc[:, 1] & 0xffffffff) >> 1, end[p].astype(np.uint64))
+        assert np.array_equal(hpc[:, 1] & 1, plain[:, 1] & 1) and np.all(hpc[:, 1] >> 32 == 7)
+        assert np.array_equal(hpc[:, 0] & 0xff, (csum[p + 1] - csum[p + 1 - k]).astype(np.uint64))
