@@ -99,6 +99,20 @@ extern "C" int mm355_device_synchronize(int device_id)
 // Measured (round 3, default bench, alternating runs on one box): shared pool 853 / 795 Mbases/s against 876 / 865 with eight streams per
 // context -- the exact classes and the long chains of different contexts then wait for one another on their one stream, which costs more
 // than the occasional held turn.  Kept as an experiment switch (MM355_DP_SHARED_STREAMS=1); the default is a set of streams per context.
+// Priority of an extension stream (experiment, off by default).  The runtime keeps a pool of hardware queues PER PRIORITY LEVEL: with the wide
+// grids of the turn (classes 0, 2, 3) and the latency chains (1 exact register classes, 4 / 5 long targets, 6 k_ksw_rowl, 7 k_ksw_regw8) on
+// one level, a turn kernel of one context sometimes sits on the hardware queue of another context's k_ksw_rowl / k_ksw_regw8 and starts when
+// that chain ends, 6-19 ms late, with every other context's round waiting for the turn (rocprofv3 trace of the round-4 default bench: 12 such
+// starts in 96 turns).  A level of their own for the chains (MM355_DP_PRIO3=1: chains normal, turn least; =2: turn normal, chains least)
+// removes that -- and costs more than it saves: 1276 1279 1336 (=1) and 1320 1319 (=2) against 1380 1435 1428 / 1406 1422 Mbases/s with one
+// level for every extension stream (alternating runs on one box): a third level is eight more hardware queues, and more than sixteen in
+// use were slower in every sweep of GPU_MAX_HW_QUEUES as well (profiles/r04_knob_sweeps.txt).
+static int dp_stream_prio(const mm355_ctx *c, int sidx)
+{
+	static const int three = [] { const char *e = getenv("MM355_DP_PRIO3"); return e? atoi(e) : 0; }();   // 1: chains normal, turn least; 2: turn normal, chains least
+	const bool chain = sidx == 1 || sidx >= 4;
+	return three && (three == 1? chain : !chain) && c->prio_low - c->prio_high >= 2? (c->prio_low + c->prio_high) / 2 : c->prio_low;
+}
 struct StreamPool { hipStream_t main[8], aux[8]; bool ready; uint8_t used; };   // main + sort stream of up to eight contexts per device (mm355_ctx_create)
 static StreamPool g_pool[16];
 static std::mutex g_pool_mu;
@@ -110,7 +124,7 @@ int mm355_dp_stream(mm355_ctx *c, int sidx, hipStream_t *out)
 	static bool ready[16];
 	if (!mm355_dp_shared_streams()) {
 		hipStream_t *slot = &c->dp_st[sidx];
-		if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, c->prio_low)); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
+		if (*slot == 0) { if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(slot, hipStreamNonBlocking, dp_stream_prio(c, sidx))); else HIPCHK(hipStreamCreateWithFlags(slot, hipStreamNonBlocking)); }
 		*out = *slot;
 		return 0;
 	}
@@ -119,7 +133,7 @@ int mm355_dp_stream(mm355_ctx *c, int sidx, hipStream_t *out)
 		std::lock_guard<std::mutex> lk(mu);
 		if (!ready[d]) {
 			for (int i = 0; i < 8; ++i) {
-				if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&pool[d][i], hipStreamNonBlocking, c->prio_low));
+				if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&pool[d][i], hipStreamNonBlocking, dp_stream_prio(c, i)));
 				else HIPCHK(hipStreamCreateWithFlags(&pool[d][i], hipStreamNonBlocking));
 			}
 			ready[d] = true;
@@ -174,7 +188,7 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		c->ord = n_ctx.fetch_add(1);
 		if (!mm355_dp_shared_streams()) {
 			for (int i = 0; i < 6; ++i) {   // 0..3 the register classes, 4 and 5 the eight-wave kernel (mm355_dp_run): with the main and the sort stream, 8 per context
-				if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, c->prio_low));
+				if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, dp_stream_prio(c, i)));
 				else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[i], hipStreamNonBlocking));
 			}
 		} else { hipStream_t t; int rc = mm355_dp_stream(c, 0, &t); if (rc) { mm355_ctx_destroy(c); return rc; } }
