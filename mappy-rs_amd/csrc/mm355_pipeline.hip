@@ -187,7 +187,14 @@ extern "C" int mm355_ctx_create(const mm355_index_t *mi, int device_id, mm355_ct
 		static std::atomic<int> n_ctx(0);
 		c->ord = n_ctx.fetch_add(1);
 		if (!mm355_dp_shared_streams()) {
-			for (int i = 0; i < 6; ++i) {   // 0..3 the register classes, 4 and 5 the eight-wave kernel (mm355_dp_run): with the main and the sort stream, 8 per context
+			// MM355_DP_QALIGN=1 (experiment): all eight extension streams at once, the four of the turn first (0, 2, 3 and the exact classes 1), then the
+			// four chains (4 / 5 long targets, 6 k_ksw_rowl, 7 k_ksw_regw8) rotated by the context's ordinal: with eight queues handed out in turn, every
+			// context's turn streams sit on queues 0-3 -- shared only with other contexts' turn streams, and turns exclude one another -- and a chain
+			// of context j on queue 4 + (class + j) mod 4.
+			static const bool qalign = [] { const char *e = getenv("MM355_DP_QALIGN"); return e && atoi(e) != 0; }();
+			static const int turn_first[4] = { 0, 2, 3, 1 };
+			for (int t = 0; t < (qalign? 8 : 6); ++t) {   // 0..3 the register classes, 4 and 5 the eight-wave kernel (mm355_dp_run): with the main and the sort stream, 8 per context
+				const int i = !qalign? t : t < 4? turn_first[t] : 4 + ((t - c->ord) & 3);
 				if (c->use_prio) HIPCHK(hipStreamCreateWithPriority(&c->dp_st[i], hipStreamNonBlocking, dp_stream_prio(c, i)));
 				else HIPCHK(hipStreamCreateWithFlags(&c->dp_st[i], hipStreamNonBlocking));
 			}

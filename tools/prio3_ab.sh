@@ -8,7 +8,7 @@ import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[2], d['value'], d['ms_per_step'])
 P
 }
-for i in 1 2; do
-MM355_DP_PRIO3=2 run inv$i python3 bench.py --no-cpu --no-resident --steps 10 --warmup 1
+for i in 1 2 3; do
+MM355_DP_QALIGN=1 run qal$i python3 bench.py --no-cpu --no-resident --steps 10 --warmup 1
 MM355_DP_PRIO3=0 run off$i python3 bench.py --no-cpu --no-resident --steps 10 --warmup 1
 done
