@@ -5,8 +5,9 @@
 //  (1) mg_lchain_dp is local to an "x-component" -- a maximal run of the sorted array on one strand / contig whose consecutive reference
 //      positions differ by at most max_dist_x: the window start `st` of the first anchor of a component is that anchor itself, so no score,
 //      no t[] mark and no max_ii crosses a component boundary (the same argument that lets k_chain_segments cut the array).  A component
-//      with n anchors cannot reach f >= min_chain_score unless n * k >= min_chain_score (every step adds at most the k-mer span), and its
-//      chains have at most n anchors, so with n < T = max(min_cnt, ceil(min_chain_score / k)) nothing of it enters z[], mg_chain_backtrack
+//      with n anchors cannot reach f >= min_chain_score unless n * k >= min_chain_score (every step adds at most the k-mer span: k, or up to
+//      255 on a homopolymer-compressed index, where 255 takes k's place), and its
+//      chains have at most n anchors, so with n < T = ceil(min_chain_score / k) nothing of it enters z[], mg_chain_backtrack
 //      or compact_a.  Deleting such a component from the sorted array changes neither u[] nor the compacted anchors: indices only appear
 //      as p[] / z[].y inside the chainer, and the (unstable) sort of z[] by score looks at the scores alone.  n_a, rep_len and mini_pos are
 //      fixed before the sort.  On the GRCh38-scale workload nine anchors out of ten sit in such components: lone repeat hits.
@@ -344,7 +345,14 @@ int mm355_cull_sort(mm355_ctx *c, const DevParams &pr, int cull)
 	cp.ib = bits_for((uint64_t)max_na - 1) + 1;   // index in generation order, and the cull's decision in bit 0
 	if (bits_for(2 * cp.tot_len - 1) + cp.ib > 64) return MM355_EUNSUP;   // (a 2^40-base reference with 2^22 anchors on one read)
 	// T: the fewest anchors a chain that survives mg_chain_backtrack can have; D: the largest max_dist_x of any read (chain_dist)
-	const int T = std::max<int>(pr.min_cnt, (pr.min_chain_score + mi->k - 1) / mi->k);
+	// T: the fewest anchors with which a component can reach f >= min_chain_score, i.e. put anything into z[] (a step adds at most a seed's
+	// span: k, or a sum of k run lengths below 256 on an HPC index -- U:sketch.c keeps no record with kmer_span >= 256 -- where nothing can
+	// be culled: T = 1).  NOT max(min_cnt, ..): a component of fewer than min_cnt anchors leaves no chain, but an anchor of it with
+	// f >= min_chain_score is an element of z[] while mg_chain_backtrack sorts z[] by score with the UNSTABLE radix sort, and the order of
+	// equal scores decides which chain end claims a shared anchor first (tests/test_gpu_hpc.py::test_hpc_cull_threshold_counts_spans_not_k:
+	// 3 reads of 40 differed with min_cnt in the rule).  The presets' values are the same either way (map-ont, map-hifi: 3).
+	const int max_span = (mi->flag & 1)? 255 : mi->k;
+	const int T = (pr.min_chain_score + max_span - 1) / max_span;
 	int64_t D = pr.max_gap_ref > 0? pr.max_gap_ref : pr.max_frag_len > 0? std::max(pr.max_frag_len, pr.max_gap) : pr.max_gap;
 	if (D < pr.bw) D = pr.bw;
 	if (D < 1) D = 1;

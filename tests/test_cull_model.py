@@ -1,8 +1,8 @@
 """The claim k_cull (mappy-rs_amd/csrc/mm355_cullsort.hip) rests on, checked on the CPU with the oracle's literal mg_lchain_dp: anchors whose
-run of non-empty position bins holds fewer than T = max(min_cnt, ceil(min_chain_score / k)) anchors can be deleted from the SORTED array
+run of non-empty position bins holds fewer than T = ceil(min_chain_score / k) anchors can be deleted from the SORTED array
 before chaining -- u[] and the compacted anchors do not change.  The rule is restated here in numpy exactly as the kernel applies it (bins of
 2^sh >= max_dist_x bases of the concatenated, strand-doubled reference; a run = consecutive non-empty bins; counts as they are, no
-saturation -- the kernel only ever keeps MORE), on a genome whose repeat families scatter lone hits all over it; also with a larger min_cnt /
+saturation -- the kernel only ever keeps MORE), on a genome whose repeat families scatter lone hits all over it; also with a larger min_cnt (T unchanged: min_cnt is not part of the rule) /
 min_chain_score (larger T) and with bins that are too NARROW (sh below log2 max_dist_x), where the deletion must be seen to change results --
 the bin width is what the argument needs.  GPU side: tests/test_gpu_human.py::test_anchor_cull_and_sort_mid_scale."""
 import numpy as np
@@ -43,7 +43,7 @@ def test_culled_anchors_never_chain(world, kw):
     mo = orc.mo
     D = max(mo.max_gap_ref if mo.max_gap_ref > 0 else mo.max_gap, mo.bw)
     sh = int(np.ceil(np.log2(D)))
-    T = max(mo.min_cnt, -(-mo.min_chain_score // orc.k))
+    T = -(-mo.min_chain_score // orc.k)
     n_all = n_kept = n_chains = 0
     for rd in world["reads"]:
         a, _, _, _ = orc.anchors(rd, sorted_=True)
@@ -86,7 +86,7 @@ def test_equal_positions_share_the_decision(world):
     mo = orc.mo
     D = max(mo.max_gap_ref if mo.max_gap_ref > 0 else mo.max_gap, mo.bw)
     sh = int(np.ceil(np.log2(D)))
-    T = max(mo.min_cnt, -(-mo.min_chain_score // orc.k))
+    T = -(-mo.min_chain_score // orc.k)
     n_pairs = n_kept_pairs = 0
     for rd in world["reads"]:
         a, _, _, _ = orc.anchors(rd, sorted_=True)

@@ -109,3 +109,35 @@ def test_hpc_map_parity(built, tmp_path, preset):
     reads += [reads[0][:60], "A" * 500, reads[1][:700] + "N" * 12 + reads[1][700:1600]]
     n_hits, n_sec = check_reads(al, orc, reads)
     assert n_hits >= (80 if preset == "map-pb" else 24)
+
+
+def _fast_path_chains(al, orc, reads, expect_cull):
+    sr = al._stage_runner()
+    try:
+        got = sr.chains(reads)
+        st = sr.stats()
+        assert st.n_sort_fast_reads == len(reads), st.n_sort_fast_reads
+        assert (0 < st.n_a_kept < st.n_a) if expect_cull else st.n_a_kept == st.n_a, (st.n_a_kept, st.n_a)
+        n_short = 0
+        for i, rd in enumerate(reads):
+            ea, _, _, _ = orc.anchors(rd, sorted_=True)
+            eu, eb = orc.chains(ea, len(rd))
+            assert np.array_equal(got[i][0], eu) and np.array_equal(got[i][1], eb), i
+            n_short += int(((eu & 0xffffffff) < 6).sum())
+        return n_short
+    finally:
+        sr.close()
+
+
+def test_hpc_index_is_never_culled(built, tmp_path):
+    """row a6 on an HPC index: a seed's span is a sum of run lengths (up to 255), so ONE seed can reach min_chain_score and sit in z[]
+    while mg_chain_backtrack's unstable sort orders equal scores -- no component can be dropped before the sort (T = ceil(min_chain_score
+    / 255) = 1).  With the rule as it read before this test (T = max(min_cnt, ceil(min_chain_score / k))) 3 of these 40 reads got a chain
+    with one anchor more or less.  Anchor-rich reads (w = 5, 15-kb reads: the LDS-sort path is taken), chains == the oracle's."""
+    import mappy_rs
+    g = _hp_genome(57, [400000], repeats=((700, 60, 0.01), (300, 100, 0.02), (2000, 8, 0.005)), n_runs=1)
+    fa = str(tmp_path / "c.fa")
+    S.write_fasta(fa, g, ["c"])
+    reads, _ = S.make_reads(58, g, 40, n50=18000, lo=13000, sub=0.01, ins=0.02, dele=0.02)
+    n_short = _fast_path_chains(mappy_rs.Aligner(fa, preset="ava-pb"), O.OracleAligner(fa, preset="ava-pb"), reads, expect_cull=False)
+    assert n_short >= 100, n_short

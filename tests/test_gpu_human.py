@@ -198,6 +198,35 @@ def test_anchor_cull_and_sort_mid_scale(human_mid):
         L.mm355_index_free(idx)
 
 
+def test_anchor_cull_rule_does_not_lean_on_min_cnt(human_mid):
+    """min_chain_score = 25 with k = 15: two seeds reach it, so a component of two anchors puts elements into z[] although it leaves no chain
+    (min_cnt = 3) -- and z[] is sorted by score with the unstable radix sort, whose order of equal scores decides which chain end claims a
+    shared anchor first.  The cull's T is ceil(min_chain_score / k) = 2 (only lone anchors go), not max(min_cnt, ..) = 3; chains == the
+    oracle's chains of the WHOLE sorted array.  (Found on an HPC index, tests/test_gpu_hpc.py::test_hpc_index_is_never_culled.)"""
+    from mappy_rs import _ffi
+    L = _ffi.lib()
+    g, names = human_mid
+    reads, _ = S.make_read_block(4, 3, g, **ONT)
+    reads = reads[:48]
+    idx, mo = build_device_index(L, _ffi, g, names, "map-ont", extra={"min_chain_score": 25})
+    orc = O.OracleAligner(codes=g, names=names, preset="map-ont", min_chain_score=25, n_threads=16)
+    sr = _ffi.StageRunner(idx, mo, 0)
+    try:
+        ch = sr.chains(reads, cap=40_000_000)
+        st = sr.stats()
+        assert st.n_sort_fast_reads == len(reads) and 0 < st.n_a_kept < st.n_a, (st.n_sort_fast_reads, st.n_a_kept, st.n_a)
+        n_u = 0
+        for i, rd in enumerate(reads):
+            exp, _, _, _ = orc.anchors(rd, sorted_=True)
+            eu, eb = orc.chains(exp, len(rd))
+            assert np.array_equal(ch[i][0], eu) and np.array_equal(ch[i][1], eb), i
+            n_u += len(eu)
+        assert n_u > 500
+    finally:
+        sr.close()
+        L.mm355_index_free(idx)
+
+
 def test_anchor_cull_in_many_passes(built):
     """k_cull with 8192-bin tables (1 KB per bitmap level instead of 48 KB) and 256 threads: the mid-scale genome's 38 k bins then take five
     passes over a read's anchors -- the pass boundaries and their guard bins, which only the 3.1-Gbp genome reaches with the default table --

@@ -1,6 +1,6 @@
 """How many anchors of a GRCh38-scale read can never chain?  
 An anchor only ever interacts with anchors of its own x-component (maximal run of the x-sorted array with the same strand | rid and
-consecutive gaps <= max_dist_x); a component with fewer than max(min_cnt, ceil(min_chain_score / k)) anchors produces no chain.
+consecutive gaps <= max_dist_x); a component with fewer than ceil(min_chain_score / k) anchors puts nothing into z[].
 Prints, for a sample of configs[2]: the fraction of anchors in such components (exact components, 8192-base bins, hashed bins),
 the survivors per read, and the reads with equal keys before / after."""
 import sys, os, time, ctypes as C
