@@ -97,3 +97,30 @@ def test_equal_positions_share_the_decision(world):
         assert np.array_equal(keep[1:][same], keep[:-1][same])
         n_pairs += int(same.sum()); n_kept_pairs += int((same & keep[1:]).sum())
     assert n_pairs > 0 and n_kept_pairs < n_pairs, (n_pairs, n_kept_pairs)   # the data has such pairs, and the rule drops some of them
+
+
+def test_the_rule_counts_spans_not_min_cnt(built, tmp_path):
+    """Why T is ceil(min_chain_score / LARGEST SPAN) and nothing else.  On a homopolymer-compressed index (ava-pb: k = 19, min_chain_score 100,
+    min_cnt 3) a seed's span is a sum of run lengths up to 255: one or two seeds reach min_chain_score, sit in z[] while mg_chain_backtrack
+    sorts it with the unstable radix sort, and the order of equal scores decides which chain end claims a shared anchor first.  Dropping
+    components of fewer than ceil(100 / 19) = 6 anchors changes the chains of half the reads, fewer than min_cnt = 3 still of some (the GPU
+    path did exactly that for one session: tests/test_gpu_hpc.py::test_hpc_index_is_never_culled); T = ceil(100 / 255) = 1 drops nothing."""
+    from test_host import _hp_genome
+    g = _hp_genome(57, [400000], repeats=((700, 60, 0.01), (300, 100, 0.02), (2000, 8, 0.005)), n_runs=1)
+    fa = str(tmp_path / "c.fa")
+    S.write_fasta(fa, g, ["c"])
+    orc = O.OracleAligner(fa, preset="ava-pb")
+    mo = orc.mo
+    reads, _ = S.make_reads(58, g, 40, n50=18000, lo=13000, sub=0.01, ins=0.02, dele=0.02)
+    sh = int(np.ceil(np.log2(max(mo.max_gap, mo.bw))))
+    differ = {}
+    for T in (-(-mo.min_chain_score // 255), mo.min_cnt, -(-mo.min_chain_score // orc.k)):
+        d = 0
+        for rd in reads:
+            a, _, _, _ = orc.anchors(rd, sorted_=True)
+            keep = cull(a, np.array([0], np.int64), len(g[0]), sh, T)
+            u0, b0 = orc.chains(a, len(rd))
+            u1, b1 = orc.chains(a[keep], len(rd))
+            d += not (np.array_equal(u0, u1) and np.array_equal(b0, b1))
+        differ[T] = d
+    assert differ[1] == 0 and differ[3] > 0 and differ[6] > differ[3], differ
