@@ -365,3 +365,35 @@ def test_hpc_index_build_matches_oracle(ffi, tmp_path):
         p = O.lib().mmo_idx_get(orc.idx, minier, C.byref(on))
         assert n == on.value and [int(v) for v in buf[:n]] == [p[i] for i in range(n)]
     L.mm355_index_free(h)
+
+
+def test_hpc_mmi_file_is_loaded_with_its_flag(ffi, tmp_path):
+    """an .mmi written from an HPC index (minimap2 -H / map-pb; here: the oracle's writer) carries MM_I_HPC in its header: the loader keeps the
+    flag (it was refused until map-pb went in), the table equals the FASTA build's, and the preset given at load time does not override it"""
+    import synthdata as S
+    import mappy_rs
+    g = _hp_genome(29, [40000, 9000], repeats=((800, 6, 0.01),), n_runs=1)
+    fa = str(tmp_path / "hp.fa")
+    S.write_fasta(fa, g, ["c0", "c1"])
+    orc = O.OracleAligner(fa, preset="map-pb")
+    mmi = str(tmp_path / "hp.mmi")
+    assert O.lib().mmo_idx_dump(orc.idx, mmi.encode()) == 0
+    L = ffi.lib()
+    io, mo = ffi.IdxOpt(), ffi.MapOpt()
+    L.mm355_set_opt(None, C.byref(io), C.byref(mo))              # plain defaults: the FILE decides
+    h, h2 = C.c_void_p(), C.c_void_p()
+    assert L.mm355_index_load(mmi.encode(), C.byref(io), 2, C.byref(h)) == 0
+    assert L.mm355_set_opt(b"map-pb", C.byref(io), C.byref(mo)) == 0
+    assert L.mm355_index_load(fa.encode(), C.byref(io), 2, C.byref(h2)) == 0
+    a = mappy_rs.Aligner(mmi)
+    assert a.k == 19 and a.w == 10 and a.n_seq == 2
+    st = [C.c_int64() for _ in range(4)]
+    L.mm355_index_stat(h, C.byref(st[0]), C.byref(st[1]), None, None)
+    L.mm355_index_stat(h2, C.byref(st[2]), C.byref(st[3]), None, None)
+    assert (st[0].value, st[1].value) == (st[2].value, st[3].value) and st[0].value > 1000
+    buf, buf2 = np.zeros(4096, np.uint64), np.zeros(4096, np.uint64)
+    seqs = [S.codes_to_str(c) for c in g]
+    for minier in list(_all_minimizers(orc, seqs))[:3000]:
+        n, n2 = L.mm355_index_get(h, minier, buf.ctypes.data, 4096), L.mm355_index_get(h2, minier, buf2.ctypes.data, 4096)
+        assert n == n2 > 0 and np.array_equal(buf[:n], buf2[:n])
+    L.mm355_index_free(h); L.mm355_index_free(h2)
