@@ -60,8 +60,9 @@ __device__ inline void rs_walk_packed(uint32_t *cn, const uint32_t *fend, uint32
 // l's turn fills the next foreign slot.  So the final position of every element follows from (a) the order in which
 // foreign elements arrive at each bucket and (b) how many arrive before the bucket's turn.  (a)/(b) are produced by a
 // sequential walk over the 1-byte label queues only (lane 0, labels in LDS); everything else -- histogram, compaction
-// of foreign elements, the final scatter -- is done by all 64 lanes with coalesced traffic.  Exhaustively checked
-// against the literal permutation on the host (tests) and bit-compared through the anchor parity tests.
+// of foreign elements, the final scatter -- is done by all 64 lanes with coalesced traffic.  The argument is checked on the
+// CPU against the literal loop (tests/test_level_walk_model.py: exhaustively for short arrays, random ones of every bucket
+// structure), the kernel itself bit for bit through the anchor parity tests.
 template <typename T, typename Key>
 __device__ void wave_rs_level_walk(T *a, uint32_t beg, uint32_t end, int s, Key key, SortLds *L, const WalkScratch &ws, uint8_t *lds_lab, uint32_t lds_cap)
 {
