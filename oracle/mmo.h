@@ -286,6 +286,8 @@ void mmo_ksw_gen_simple_mat(int m, int8_t *mat, int8_t a, int8_t b, int8_t sc_am
 /* ---- align.c ---- */
 mmo_reg1_t *mmo_align_skeleton(const mmo_mapopt_t *opt, const mmo_idx_t *mi, int qlen, const char *qstr, int *n_regs_, mmo_reg1_t *regs, mm128_t *a);
 
+int mmo_test_zdrop(const mmo_mapopt_t *opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, uint32_t *cigar, const int8_t *mat);   /* test hook */
+
 /* ---- format.c ---- */
 char *mmo_gen_cs(const mmo_idx_t *mi, const mmo_reg1_t *r, const char *seq, int no_iden);  /* malloc'd, NUL-terminated */
 char *mmo_md_core(const uint32_t *cigar, int n_cigar, const uint8_t *qseq, const uint8_t *tseq, int *q_len, int *t_len);

@@ -89,6 +89,12 @@ static int mm_test_zdrop(const mmo_mapopt_t *opt, const uint8_t *qseq, const uin
 	return max_zdrop > opt->zdrop? 1 : 0;
 }
 
+/* test hook: mm_test_zdrop on its own (tests/test_zdrop_bound_model.py) */
+int mmo_test_zdrop(const mmo_mapopt_t *opt, const uint8_t *qseq, const uint8_t *tseq, uint32_t n_cigar, uint32_t *cigar, const int8_t *mat)
+{
+	return mm_test_zdrop(opt, qseq, tseq, n_cigar, cigar, mat);
+}
+
 static void mm_fix_cigar(mmo_reg1_t *r, const uint8_t *qseq, const uint8_t *tseq, int *qshift, int *tshift)
 {
 	mmo_extra_t *p = r->p;
